@@ -1,0 +1,108 @@
+"""Pin the CPU oracle (oracle/edgecape_oracle.py) to outputs of the REAL reference.
+
+The fixtures under tests/golden/ were produced by oracle/make_golden.py importing
+/root/reference (head, skeleton head, transformer, detector) and HF Dinov2Model (backbone
+cross-check).  Tolerance: 1e-5 abs (fp32 CPU both sides).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from edgecape_amd import synth
+from oracle import edgecape_oracle as orc
+
+HEAD = ["head_s1_c384_g16_kp17", "head_s5_c384_g16_mixed", "head_s1_c768_g18_edge", "head_s5_c768_g18_kp17"]
+TOL = 1e-5
+
+
+def _run_head(meta):
+    sd = synth.make_head_weights(C=meta["C"], seed=meta["weight_seed"])
+    inp = synth.make_head_inputs(len(meta["n_kps"]), meta["shots"], meta["C"], meta["g"], meta["input_seed"],
+                                 meta["n_kps"], meta["skeletons"])
+    taps = {}
+    with torch.no_grad():
+        out = orc.head_forward(sd, inp["feature_q"], inp["feature_s"], inp["target_s"], inp["mask_s"],
+                               inp["skeleton"], taps=taps)
+    return out, taps, inp
+
+
+@pytest.mark.parametrize("name", HEAD)
+def test_head_matches_reference(name):
+    gold, meta = load_golden(name)
+    out, taps, inp = _run_head(meta)
+    # argmax flips would show up as O(1/g) jumps; none are expected at 1e-5 agreement of the maps
+    checks = dict(
+        support_keypoints=taps["support_keypoints"], adj=out["adj"], attn_adj=out["attn_adj"],
+        unnormalized_adj=out["unnormalized_adj"], enc_kp=taps["enc_kp"], enc_img_first8=taps["enc_img"][:8],
+        enc_img_last8=taps["enc_img"][-8:], initial_proposals=out["initial_proposals"],
+        out_points=out["out_points"], output_kpts=out["output_kpts"], hs_last=out["hs"][-1].transpose(0, 1),
+    )
+    for k, v in checks.items():
+        err = np.abs(v.numpy() - gold[k]).max()
+        # initial_proposals is a soft-argmax over exp(similarity) with |similarity| up to ~50: fp32
+        # rounding of the logits (1e-5 relative) is amplified by the softmax, hence 3e-5 there.
+        tol = 3e-5 if k == "initial_proposals" else TOL
+        assert err <= tol, f"{name}:{k} max abs err {err}"
+    sim_err = np.abs(out["similarity_map"].numpy() - gold["similarity_map"]).max()
+    scale = np.abs(gold["similarity_map"]).max()
+    assert sim_err <= 1e-5 * max(1.0, scale), f"{name}: similarity_map err {sim_err} (scale {scale})"
+
+
+@pytest.mark.parametrize("name", HEAD)
+def test_structural_invariants(name):
+    """invariants derivable from the reference alone."""
+    gold, meta = load_golden(name)
+    adj, attn = gold["adj"], gold["attn_adj"]
+    for b, nk in enumerate(meta["n_kps"]):
+        valid = np.zeros(100, bool)
+        valid[:nk] = True
+        assert np.array_equal(adj[b, 0], np.diag(valid.astype(np.float32)))
+        rs = adj[b, 1].sum(-1)
+        if nk > 0:
+            assert np.allclose(rs[:nk], 1.0, atol=1e-5)
+        assert np.all(adj[b, 1][nk:] == 0) and np.all(adj[b, 1][:, nk:] == 0)
+        assert np.array_equal(attn[0, b], np.eye(100, dtype=np.float32))
+
+
+@pytest.mark.parametrize("name", ["det_vits14_224_s1", "det_vits14_224_s5"])
+def test_detector_matches_reference(name):
+    gold, meta = load_golden(name)
+    sd = synth.make_weights(meta["arch"], seed=meta["weight_seed"])
+    batch = synth.make_pairs(meta["bs"], meta["shots"], meta["image_size"], seed=meta["input_seed"])
+    res, _ = orc.forward_test(sd, batch, synth.ARCHS[meta["arch"]]["heads"])
+    assert np.abs(res["points"] - gold["points"]).max() <= TOL
+    assert np.abs(res["skeleton"] - gold["skeleton"]).max() <= TOL
+    assert np.abs(res["preds"] - gold["preds"]).max() <= 2e-3  # pixels (x224 of 1e-5)
+    assert np.array_equal(res["boxes"], gold["boxes"])
+    assert list(res["bbox_ids"]) == list(gold["bbox_ids"])
+    assert np.all(res["preds"][..., 2] == 1)  # head.py:374
+
+
+@pytest.mark.parametrize("name", ["bb_hf_vits14_224", "bb_hf_vitb14_256"])
+def test_backbone_matches_hf(name):
+    gold, meta = load_golden(name)
+    arch = meta["arch"]
+    sd = synth.make_backbone_weights(arch, seed=meta["weight_seed"])
+    rng = np.random.default_rng(meta["input_seed"])
+    img = np.stack([synth._smooth_image(rng, meta["image_size"])])
+    taps = {}
+    with torch.no_grad():
+        orc.dinov2_features(sd, img, synth.ARCHS[arch]["heads"], taps=taps)
+    assert np.abs(taps["tokens0"][0, :4].numpy() - gold["tokens0_first4"]).max() <= TOL
+    assert np.abs(taps["block0"][0, :4].numpy() - gold["block0_first4"]).max() <= 1e-4
+    f = taps["feat_tokens"][0]
+    assert np.abs(f[:8].numpy() - gold["feat_tokens_first8"]).max() <= 2e-4
+    assert np.abs(f[-8:].numpy() - gold["feat_tokens_last8"]).max() <= 2e-4
+    assert np.abs(f.mean(0).numpy() - gold["feat_mean"]).max() <= 2e-4
+
+
+def test_msra_target_invariants():
+    """top_down_transform.py:165-194: <=49 non-zeros, peak 1.0 at int(x/stride+0.5)."""
+    kp = np.array([[100.3, 57.9], [2.0, 220.0], [-50.0, -50.0]], np.float32)
+    t, w = synth.msra_target(kp, np.ones(3), 224)
+    assert (t[0] > 0).sum() == 49 and t[0].max() == 1.0
+    my, mx = np.unravel_index(t[0].argmax(), t[0].shape)
+    assert (mx, my) == (int(100.3 / 3.5 + 0.5), int(57.9 / 3.5 + 0.5))
+    assert 0 < (t[1] > 0).sum() < 49
+    assert w[2] == 0 and t[2].sum() == 0
