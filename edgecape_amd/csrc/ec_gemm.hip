@@ -1,0 +1,277 @@
+// GEMM kernels for gfx950 (MI355X).
+//
+// gemm_nt:  C[M,N] = epilogue(A[M,K] @ B[N,K]^T)  — every Linear / 1x1-conv / patch-embed of the
+// hot path (reference ops: SURVEY.md §2.3 rows B1,B4,B6,B7,H1,H4,H6,H7,H10-H14).  Both operands are
+// K-contiguous ("NT"), which is torch's nn.Linear weight layout, so no transposes are needed.
+//
+//   * operands fp32  -> v_mfma_f32_32x32x2_f32   (exact fp32 products, fp32 accumulate: parity mode)
+//   * operands bf16  -> v_mfma_f32_32x32x16_bf16 (fp32 accumulate: throughput mode)
+//
+// Tiling (MI355X-first, 64-wide waves): 128x128 output tile per 256-thread workgroup (4 waves, each a
+// 64x64 sub-tile = 2x2 MFMA 32x32 accumulators = 64 acc VGPRs), K step = 128 BYTES of K per row for
+// either dtype (32 fp32 / 64 bf16), so the LDS image and all address arithmetic are dtype-independent.
+// Global->LDS staging is the gfx950 direct path (global_load_lds_dwordx4: 64 lanes x 16 B = 8 rows x
+// 128 B per wave-instruction, no VGPR round trip), double-buffered.  The LDS destination is lane-linear,
+// so the bank-conflict swizzle is applied to the SOURCE address and undone on the ds_read_b128 side
+// (both use phys_chunk = chunk ^ ((row >> 1) & 7), an involution; conflict-free for the 16-lane groups
+// ds_read_b128 is serviced in).
+#include "ec_common.h"
+
+namespace ec {
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int KBYTES = 128;                 // bytes of K per row per stage
+constexpr int TILE_BYTES = BM * KBYTES;     // 16 KiB per operand per stage
+constexpr int STAGE_BYTES = 2 * TILE_BYTES; // A + B
+constexpr int GEMM_LDS = 2 * STAGE_BYTES;   // double buffered: 64 KiB -> 2 workgroups / CU
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ inline void stage_tile(const char* __restrict__ base, long ld_bytes, int row0, int nrows_total,
+                                  long kbyte0, char* lds_tile, int wave, int lane) {
+  // 128 rows x 128 B = 16 wave-instructions; 4 per wave.
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int rb = wave * 4 + j;            // 8-row block inside the tile
+    const int r = rb * 8 + (lane >> 3);     // row inside the tile
+    const int pc = lane & 7;                // physical 16-B chunk this lane fills
+    const int c = pc ^ ((r >> 1) & 7);      // logical chunk it must fetch
+    int gr = row0 + r;
+    gr = gr < nrows_total ? gr : nrows_total - 1;   // clamp: rows past the edge are never stored
+    const char* src = base + (long)gr * ld_bytes + kbyte0 + c * 16;
+    char* dst = lds_tile + rb * 1024;        // wave-uniform; hardware adds lane * 16
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+  }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int esz = BF16 ? 2 : 4;
+
+  // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8); give each XCD a
+  // contiguous run of tiles that share the same A row-panel so the panel stays in that XCD's L2.
+  const int ntn = gridDim.x, ntm = gridDim.y;
+  const int nwg = ntn * ntm;
+  int wg = blockIdx.y * ntn + blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective for any nwg
+  }
+  const int bm = wg / ntn, bn = wg % ntn;
+  const int bz = blockIdx.z;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  const char* A = (const char*)p.A + (long)bz * p.sA * esz;
+  const char* B = (const char*)p.B + (long)bz * p.sB * esz;
+  const long lda_b = p.lda * esz, ldb_b = p.ldb * esz;
+  const int nk = (p.K * esz) / KBYTES;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  stage_tile(A, lda_b, m0, p.M, 0, smem, wave, lane);
+  stage_tile(B, ldb_b, n0, p.N, 0, smem + TILE_BYTES, wave, lane);
+
+  const int lrow = lane & 31, hi = lane >> 5;
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) {
+      char* nxt = smem + (cur ^ 1) * STAGE_BYTES;
+      stage_tile(A, lda_b, m0, p.M, (long)(kt + 1) * KBYTES, nxt, wave, lane);
+      stage_tile(B, ldb_b, n0, p.N, (long)(kt + 1) * KBYTES, nxt + TILE_BYTES, wave, lane);
+    }
+    const char* At = smem + cur * STAGE_BYTES;
+    const char* Bt = At + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int chunk = 2 * kk + hi;
+      f32x4 a[2], b[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int ra = wm * 64 + t * 32 + lrow;
+        const int rb = wn * 64 + t * 32 + lrow;
+        a[t] = *(const f32x4*)(At + ra * KBYTES + ((chunk ^ ((ra >> 1) & 7)) << 4));
+        b[t] = *(const f32x4*)(Bt + rb * KBYTES + ((chunk ^ ((rb >> 1) & 7)) << 4));
+      }
+      if constexpr (BF16) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),
+                                                                __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+      }
+    }
+    cur ^= 1;
+  }
+
+  // ---- epilogue: acc reg r of lane (col = lane&31, hi) is row (r&3) + 8*(r>>2) + 4*hi ----
+  const float* bias = p.bias ? p.bias + (long)bz * p.sBias : nullptr;
+  const float* resid = p.resid ? p.resid + (long)bz * p.sR : nullptr;
+  const float* aux = p.aux ? p.aux + (long)bz * p.sAux : nullptr;
+  float* Cf = (float*)p.C + (long)bz * p.sC;
+  bf16_t* Ch = (bf16_t*)p.C + (long)bz * p.sC;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + lrow;
+    if (n >= p.N) continue;
+    const float bv = bias ? bias[n] : 0.f;
+    const float gv = p.gamma ? p.gamma[n] : 1.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (m >= p.M) continue;
+        float v = acc[i][j][r] + bv;
+        if (p.table) v += p.table[(long)(m % p.period) * p.ldt + n];
+        if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.act == ACT_GELU) v = gelu_erf(v);
+        else if (p.act == ACT_TANHGATE) v = (tanhf(v) + 1.f) * aux[(long)m * p.ldaux + n];
+        v *= gv;
+        if (resid) v += resid[(long)m * p.ldr + n];
+        if (p.c_bf16) Ch[(long)m * p.ldc + n] = f2bf(v);
+        else Cf[(long)m * p.ldc + n] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small batched fp32 GEMM on the vector ALU: 64x64 tile, 256 threads, 4x4 outputs per thread.
+// Used for the per-sample 100x100 / 100xHW contractions of the head (support-keypoint pooling,
+// cosine-similarity adjacency, Markov powers, GCN aggregation, similarity map) where M = K = 100.
+// ------------------------------------------------------------------------------------------------
+constexpr int SB = 64, SK = 16;
+
+__global__ __launch_bounds__(256) void bgemm_small_kernel(BgemmP p) {
+  __shared__ float As[SK][SB + 4];
+  __shared__ float Bs[SK][SB + 4];
+  const int tid = threadIdx.x;
+  const int bz = blockIdx.z;
+  const int m0 = blockIdx.y * SB, n0 = blockIdx.x * SB;
+  const float* A = p.A + (long)(p.modA > 0 ? bz % p.modA : bz) * p.sA;
+  const float* B = p.B + (long)(p.modB > 0 ? bz % p.modB : bz) * p.sB;
+  float* C = p.C + (long)bz * p.sC;
+  const int tx = tid & 15, ty = tid >> 4;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+  for (int k0 = 0; k0 < p.K; k0 += SK) {
+    // A tile: 64 rows x 16 k -> As[k][m]
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * 256;
+      const int r = idx >> 4, k = idx & 15;
+      const int gm = m0 + r, gk = k0 + k;
+      As[k][r] = (gm < p.M && gk < p.K) ? A[(long)gm * p.lda + gk] : 0.f;
+    }
+    if (p.transB) {  // B [N,K]
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = tid + it * 256;
+        const int r = idx >> 4, k = idx & 15;
+        const int gn = n0 + r, gk = k0 + k;
+        Bs[k][r] = (gn < p.N && gk < p.K) ? B[(long)gn * p.ldb + gk] : 0.f;
+      }
+    } else {  // B [K,N]
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = tid + it * 256;
+        const int k = idx >> 6, c = idx & 63;
+        const int gn = n0 + c, gk = k0 + k;
+        Bs[k][c] = (gn < p.N && gk < p.K) ? B[(long)gk * p.ldb + gn] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SK; ++k) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[k][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[k][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + tx * 4 + j;
+      if (n >= p.N) continue;
+      float v = p.alpha * acc[i][j];
+      if (p.beta != 0.f) v += p.beta * C[(long)m * p.ldc + n];
+      if (p.self) {
+        const float rs = p.rowscale[(long)(p.mod_rs > 0 ? bz % p.mod_rs : bz) * p.M + m];
+        v += rs * p.self[(long)bz * p.s_self + (long)m * p.ld_self + n];
+      }
+      if (p.relu) v = fmaxf(v, 0.f);
+      C[(long)m * p.ldc + n] = v;
+    }
+  }
+}
+
+}  // namespace
+
+int gemm_nt(const GemmP& p, hipStream_t st) {
+  const int esz = p.ab_bf16 ? 2 : 4;
+  EC_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0 && p.batch > 0, -1, "gemm_nt: empty problem");
+  EC_REQUIRE((p.K * esz) % KBYTES == 0, -1, "gemm_nt: K must be a multiple of 128 bytes");
+  EC_REQUIRE((p.lda * esz) % 16 == 0 && (p.ldb * esz) % 16 == 0, -1, "gemm_nt: row strides must be 16-byte multiples");
+  EC_REQUIRE(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0, -1, "gemm_nt: operands must be 16-byte aligned");
+  EC_REQUIRE(p.act != ACT_TANHGATE || p.aux, -1, "gemm_nt: tanh-gate epilogue needs aux");
+  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.batch);
+  static bool attr_done = false;
+  if (!attr_done) {
+    EC_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
+    EC_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
+    attr_done = true;
+  }
+  if (p.ab_bf16) hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), GEMM_LDS, st, p);
+  else hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), GEMM_LDS, st, p);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int bgemm_small(const BgemmP& p, hipStream_t st) {
+  EC_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0 && p.batch > 0, -1, "bgemm_small: empty problem");
+  dim3 grid((p.N + SB - 1) / SB, (p.M + SB - 1) / SB, p.batch);
+  hipLaunchKernelGGL(bgemm_small_kernel, grid, dim3(256), 0, st, p);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace ec

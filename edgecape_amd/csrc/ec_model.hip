@@ -1,0 +1,954 @@
+// libedgecape_hip.so — model state, weight loading and the forward_test orchestration (C ABI in
+// include/edgecape_hip.h).  The compute is exclusively the gfx950 kernels of ec_gemm / ec_attn / ec_ops;
+// there is no CPU fallback: every entry point fails with EC_ERR_NODEVICE / EC_ERR_HIP if no GPU runs it.
+//
+// Data layout in HBM: all activations are token-major [batch, token, channel] fp32
+// (bf16 for GEMM operands in bf16 mode), batch-first — unlike the reference's seq-first [L, bs, c] —
+// so every Linear is one NT GEMM over M = batch*tokens rows and attention reads heads as column slices.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/edgecape_hip.h"
+#include "ec_common.h"
+#include "ec_ops.h"
+
+namespace ec {
+
+static thread_local std::string g_err;
+void set_error(const std::string& s) { g_err = s; }
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  g_err = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what + " (" + file + ":" + std::to_string(line) + ")";
+  return EC_ERR_HIP;
+}
+
+struct Tensor {
+  std::vector<int64_t> shape;
+  std::vector<float> host;
+  float* dev = nullptr;
+  bf16_t* dev16 = nullptr;
+  long numel() const { long n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+struct Lin {  // a Linear layer view: W [N,K] (+ optional bf16 copy), bias [N]
+  const float* w = nullptr;
+  const bf16_t* w16 = nullptr;
+  const float* b = nullptr;
+  int N = 0, K = 0;
+};
+struct Norm { const float* w = nullptr; const float* b = nullptr; };
+
+struct BBlock { Norm n1, n2; Lin qkv, proj, fc1, fc2; const float* ls1 = nullptr; const float* ls2 = nullptr; };
+
+struct DecLayer {
+  Lin sa_in, sa_out;                 // self-attention in/out projections (fused [3d, d])
+  const float *m_w1 = nullptr, *m_b1 = nullptr, *m_w2 = nullptr, *m_b2 = nullptr;  // markov_structural_mlp
+  Lin ca_q, ca_kv, ca_fold;          // cross-attention: Q proj, fused K|V proj of image tokens, out_proj∘choker
+  const float* ca_kv_table = nullptr;  // [HW, 2E] positional part of K (+ biases)
+  Lin ffn1, ffn2;
+  Norm n1, n2, n3, n4;
+  Lin i2t_q, i2t_kv, i2t_fold;       // two-way (skeleton head only)
+  const float* i2t_q_table = nullptr;  // [HW, E]
+};
+struct EncLayer { Lin in, out, l1, l2; Norm n1, n2; };
+struct KptBranch { Lin l0, l2, l4; const float* w6 = nullptr; const float* b6 = nullptr; };
+
+}  // namespace ec
+
+using namespace ec;
+
+struct ec_model {
+  ec_config cfg;
+  int g = 0, HW = 0, T = 0, C = 0, K = 0, d = 0, L = 0, E = 0;
+  int Kp = 640;  // padded im2col width (588 -> 640: multiple of 128 bytes for fp32 and bf16)
+  bool finalized = false;
+  bool bb16 = false;
+  std::unordered_map<std::string, Tensor> tensors;
+  std::vector<void*> owned;  // every hipMalloc'd pointer
+  std::unordered_map<std::string, std::pair<const float*, long>> taps;
+
+  // backbone
+  Lin patch;
+  const float *cls = nullptr, *pos = nullptr;
+  Norm bnorm;
+  std::vector<BBlock> blocks;
+  // head
+  Lin input_proj, query_proj, image_project;
+  const float *zc_w = nullptr, *zc_b = nullptr;
+  const float *pos_img = nullptr, *pos_cat = nullptr, *dim_t = nullptr;
+  std::vector<DecLayer> skel, dec;
+  std::vector<EncLayer> enc;
+  Norm dec_norm;
+  Lin rp0, rp1, pg_support, pg_query, pg_dyn0, pg_dyn2;
+  std::vector<KptBranch> kpt;
+
+  // workspace (device)
+  int n_img_max = 0;
+  float* bb_x = nullptr; void* bb_xn = nullptr; void* bb_qkv = nullptr; void* bb_att = nullptr; void* bb_h = nullptr;
+  float* feat = nullptr;      // [n_img_max, HW, C] tokens; query first, then shot s at (1+s)*bs
+  float* feat_nchw_tmp = nullptr;
+  int32_t *d_edges = nullptr, *d_off = nullptr; int edges_cap = 0;
+  float *Wp, *pooled, *sk, *valid, *binary, *adj_r1, *adj1, *P, *kn, *kp_ref, *attn_adj;
+  uint8_t *kmask, *kmask_fixed;
+  float *s_mem, *s_x, *s_tmp, *s_qkv, *s_att, *s_qc, *s_kv, *s_y, *s_z, *s_qimg, *s_kvk, *s_attimg, *s_tmpimg;
+  float *e_x, *e_qkv, *e_att, *e_tmp, *e_h;
+  float *p_fs, *p_fq, *p_g1, *p_fs2, *prop;
+  float *d_qin, *d_sc, *d_rp, *d_bias, *d_qkv, *d_att, *d_tmp, *d_qc, *d_kv, *d_y, *d_z, *d_hs, *d_pts, *d_k1, *d_k2, *d_hn;
+  float *o_sim, *o_adj, *o_init, *o_out;
+};
+
+namespace ec {
+
+static int dmalloc(ec_model* m, void** p, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  EC_HIP(hipMalloc(p, bytes));
+  m->owned.push_back(*p);
+  return 0;
+}
+template <typename T> static int dalloc(ec_model* m, T** p, size_t n) { return dmalloc(m, (void**)p, n * sizeof(T)); }
+
+static int upload(ec_model* m, const std::vector<float>& h, const float** out) {
+  float* p = nullptr;
+  int rc = dalloc(m, &p, h.size());
+  if (rc) return rc;
+  EC_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  *out = p;
+  return 0;
+}
+static int upload16(ec_model* m, const std::vector<float>& h, const bf16_t** out) {
+  std::vector<bf16_t> t(h.size());
+  for (size_t i = 0; i < h.size(); ++i) t[i] = f2bf(h[i]);
+  bf16_t* p = nullptr;
+  int rc = dalloc(m, &p, t.size());
+  if (rc) return rc;
+  EC_HIP(hipMemcpy(p, t.data(), t.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+  *out = p;
+  return 0;
+}
+
+static const Tensor* find(ec_model* m, const std::string& name) {
+  auto it = m->tensors.find(name);
+  return it == m->tensors.end() ? nullptr : &it->second;
+}
+
+#define GET(var, name)                                                           \
+  const Tensor* var = find(m, name);                                             \
+  if (!var) { set_error(std::string("missing tensor: ") + (name)); return EC_ERR_STATE; }
+
+static int make_lin(ec_model* m, const std::string& wname, const std::string& bname, Lin* out, bool want16) {
+  GET(w, wname);
+  out->w = w->dev;
+  out->N = (int)w->shape[0];
+  out->K = (int)(w->numel() / w->shape[0]);
+  if (!bname.empty()) {
+    GET(b, bname);
+    out->b = b->dev;
+  }
+  if (want16) {
+    int rc = upload16(m, w->host, &out->w16);
+    if (rc) return rc;
+  }
+  return 0;
+}
+static int make_lin_host(ec_model* m, const std::vector<float>& W, const std::vector<float>& b, int N, int K, Lin* out) {
+  out->N = N; out->K = K;
+  int rc = upload(m, W, &out->w);
+  if (rc) return rc;
+  if (!b.empty()) rc = upload(m, b, &out->b);
+  return rc;
+}
+static int make_norm(ec_model* m, const std::string& p, Norm* out) {
+  GET(w, p + ".weight");
+  GET(b, p + ".bias");
+  out->w = w->dev; out->b = b->dev;
+  return 0;
+}
+
+// out[M,N] = A[M,K] @ B[N,K]^T in double (host, finalize-time folding of constant operands)
+static std::vector<float> host_nt(const float* A, long lda, const float* B, long ldb, int M, int N, int K) {
+  std::vector<float> o((size_t)M * N);
+  for (int i = 0; i < M; ++i)
+    for (int j = 0; j < N; ++j) {
+      double s = 0;
+      for (int k = 0; k < K; ++k) s += (double)A[i * lda + k] * (double)B[j * ldb + k];
+      o[(size_t)i * N + j] = (float)s;
+    }
+  return o;
+}
+
+// SinePositionalEncoding.forward on an all-False mask (positional_encoding.py:57-94) -> [HW, 2*nf] token-major
+static std::vector<float> sine_table(int g, int nf, std::vector<float>* dim_t_out) {
+  std::vector<float> dim_t(nf);
+  for (int i = 0; i < nf; ++i) dim_t[i] = powf(10000.f, (float)(2 * (i / 2)) / (float)nf);
+  const float scale = 2.f * (float)M_PI;
+  std::vector<float> t((size_t)g * g * 2 * nf);
+  for (int y = 0; y < g; ++y)
+    for (int x = 0; x < g; ++x) {
+      const float ye = (float)(y + 1) / ((float)g + 1e-6f) * scale;
+      const float xe = (float)(x + 1) / ((float)g + 1e-6f) * scale;
+      float* o = &t[((size_t)y * g + x) * 2 * nf];
+      for (int i = 0; i < nf; ++i) {
+        const float ay = ye / dim_t[i], ax = xe / dim_t[i];
+        o[i] = (i & 1) ? cosf(ay) : sinf(ay);
+        o[nf + i] = (i & 1) ? cosf(ax) : sinf(ax);
+      }
+    }
+  if (dim_t_out) *dim_t_out = dim_t;
+  return t;
+}
+
+// Build the derived weights of one TransformerDecoderLayer (encoder_decoder.py:527-651).
+static int build_dec_layer(ec_model* m, const std::string& P, bool biased, bool two_way, const std::vector<float>& pos_img,
+                           DecLayer* L) {
+  const int d = m->d, E = 2 * m->d, HW = m->HW;
+  int rc;
+  if (biased) {
+    GET(q, P + "self_attn.q_proj.weight"); GET(k, P + "self_attn.k_proj.weight"); GET(v, P + "self_attn.v_proj.weight");
+    GET(qb, P + "self_attn.q_proj.bias"); GET(kb, P + "self_attn.k_proj.bias"); GET(vb, P + "self_attn.v_proj.bias");
+    std::vector<float> W, b;
+    for (const Tensor* t : {q, k, v}) W.insert(W.end(), t->host.begin(), t->host.end());
+    for (const Tensor* t : {qb, kb, vb}) b.insert(b.end(), t->host.begin(), t->host.end());
+    if ((rc = make_lin_host(m, W, b, 3 * d, d, &L->sa_in))) return rc;
+    GET(w1, P + "self_attn.markov_structural_mlp.0.weight"); GET(b1, P + "self_attn.markov_structural_mlp.0.bias");
+    GET(w2, P + "self_attn.markov_structural_mlp.3.weight"); GET(b2, P + "self_attn.markov_structural_mlp.3.bias");
+    L->m_w1 = w1->dev; L->m_b1 = b1->dev; L->m_w2 = w2->dev; L->m_b2 = b2->dev;
+  } else {
+    if ((rc = make_lin(m, P + "self_attn.in_proj_weight", P + "self_attn.in_proj_bias", &L->sa_in, false))) return rc;
+  }
+  if ((rc = make_lin(m, P + "self_attn.out_proj.weight", P + "self_attn.out_proj.bias", &L->sa_out, false))) return rc;
+
+  auto cross = [&](const std::string& A, const std::string& choker, bool q_full, Lin* lq, const float** q_table, Lin* lkv,
+                   const float** kv_table, bool kv_from_tokens, Lin* fold) -> int {
+    GET(wq, A + "q_proj_weight"); GET(wk, A + "k_proj_weight"); GET(wv, A + "v_proj_weight");
+    GET(bi, A + "in_proj_bias"); GET(wo, A + "out_proj.weight"); GET(bo, A + "out_proj.bias");
+    GET(cw, choker + ".weight"); GET(cb, choker + ".bias");
+    EC_REQUIRE(wq->shape[0] == E && wq->shape[1] == E && wv->shape[1] == d, EC_ERR_ARG, "cross-attention weight shapes");
+    const float* bq = bi->host.data(); const float* bk = bq + E; const float* bv = bk + E;
+    int r;
+    // ---- Q side
+    if (q_full) {           // main decoder: Q = [x | qpe] @ Wq^T + bq (K = 2d)
+      if ((r = make_lin_host(m, wq->host, std::vector<float>(bq, bq + E), E, E, lq))) return r;
+    } else if (!q_table) {  // skeleton token->image: positional half of the query is zero
+      std::vector<float> Wa((size_t)E * d);
+      for (int n = 0; n < E; ++n) memcpy(&Wa[(size_t)n * d], &wq->host[(size_t)n * E], d * sizeof(float));
+      if ((r = make_lin_host(m, Wa, std::vector<float>(bq, bq + E), E, d, lq))) return r;
+    } else {                // skeleton image->token: query = [mem | pos_img]; fold the constant positional half
+      std::vector<float> Wa((size_t)E * d);
+      for (int n = 0; n < E; ++n) memcpy(&Wa[(size_t)n * d], &wq->host[(size_t)n * E], d * sizeof(float));
+      if ((r = make_lin_host(m, Wa, {}, E, d, lq))) return r;
+      std::vector<float> tb = host_nt(pos_img.data(), d, wq->host.data() + d, E, HW, E, d);
+      for (int t = 0; t < HW; ++t) for (int n = 0; n < E; ++n) tb[(size_t)t * E + n] += bq[n];
+      if ((r = upload(m, tb, q_table))) return r;
+    }
+    // ---- K|V side: one GEMM with stacked weights [2E, d]
+    std::vector<float> Wkv((size_t)2 * E * d);
+    for (int n = 0; n < E; ++n) memcpy(&Wkv[(size_t)n * d], &wk->host[(size_t)n * E], d * sizeof(float));
+    memcpy(&Wkv[(size_t)E * d], wv->host.data(), (size_t)E * d * sizeof(float));
+    if (kv_from_tokens) {   // keys = [x | 0]: plain biases
+      std::vector<float> b(bk, bk + 2 * E);
+      if ((r = make_lin_host(m, Wkv, b, 2 * E, d, lkv))) return r;
+    } else {                // keys = [mem | pos_img]: positional half is a constant [HW, E] table
+      if ((r = make_lin_host(m, Wkv, {}, 2 * E, d, lkv))) return r;
+      std::vector<float> tk = host_nt(pos_img.data(), d, wk->host.data() + d, E, HW, E, d);
+      std::vector<float> tb((size_t)HW * 2 * E);
+      for (int t = 0; t < HW; ++t) {
+        for (int n = 0; n < E; ++n) tb[(size_t)t * 2 * E + n] = tk[(size_t)t * E + n] + bk[n];
+        for (int n = 0; n < E; ++n) tb[(size_t)t * 2 * E + E + n] = bv[n];
+      }
+      if ((r = upload(m, tb, kv_table))) return r;
+    }
+    // ---- out_proj followed by choker, no non-linearity in between (encoder_decoder.py:624-631): fold
+    std::vector<float> Wf((size_t)d * E), bf(d);
+    for (int i = 0; i < d; ++i) {
+      for (int j = 0; j < E; ++j) {
+        double s = 0;
+        for (int k = 0; k < E; ++k) s += (double)cw->host[(size_t)i * E + k] * (double)wo->host[(size_t)k * E + j];
+        Wf[(size_t)i * E + j] = (float)s;
+      }
+      double s = cb->host[i];
+      for (int k = 0; k < E; ++k) s += (double)cw->host[(size_t)i * E + k] * (double)bo->host[k];
+      bf[i] = (float)s;
+    }
+    return make_lin_host(m, Wf, bf, d, E, fold);
+  };
+  if ((rc = cross(P + "multihead_attn.", P + "choker", biased, &L->ca_q, nullptr, &L->ca_kv, &L->ca_kv_table, false, &L->ca_fold)))
+    return rc;
+  if ((rc = make_lin(m, P + "ffn1.conv.weight", P + "ffn1.conv.bias", &L->ffn1, false))) return rc;
+  if ((rc = make_lin(m, P + "ffn2.weight", P + "ffn2.bias", &L->ffn2, false))) return rc;
+  if ((rc = make_norm(m, P + "norm1", &L->n1)) || (rc = make_norm(m, P + "norm2", &L->n2)) || (rc = make_norm(m, P + "norm3", &L->n3)))
+    return rc;
+  if (two_way) {
+    if ((rc = cross(P + "cross_attn_image_to_token.", P + "cross_attn_image_to_token_choker", false, &L->i2t_q, &L->i2t_q_table,
+                    &L->i2t_kv, nullptr, true, &L->i2t_fold)))
+      return rc;
+    if ((rc = make_norm(m, P + "norm4", &L->n4))) return rc;
+  }
+  return 0;
+}
+
+// ---- thin launch helpers -------------------------------------------------------------------------
+static int linear(const void* A, long lda, bool a16, const Lin& W, void* C, long ldc, bool c16, int M, int act, hipStream_t st,
+                  const float* gamma = nullptr, const float* resid = nullptr, long ldr = 0, const float* table = nullptr,
+                  long ldt = 0, int period = 1, const float* aux = nullptr, long ldaux = 0) {
+  GemmP p;
+  p.A = A; p.lda = lda; p.ab_bf16 = a16 ? 1 : 0;
+  p.B = a16 ? (const void*)W.w16 : (const void*)W.w; p.ldb = W.K;
+  EC_REQUIRE(p.B != nullptr, EC_ERR_STATE, "linear: weight copy for this precision was not built");
+  p.C = C; p.ldc = ldc; p.c_bf16 = c16 ? 1 : 0;
+  p.bias = W.b; p.gamma = gamma; p.resid = resid; p.ldr = ldr; p.table = table; p.ldt = ldt; p.period = period;
+  p.aux = aux; p.ldaux = ldaux;
+  p.M = M; p.N = W.N; p.K = W.K; p.act = act;
+  return gemm_nt(p, st);
+}
+
+static int ln(const float* x, long ldx, void* y, long ldy, bool y16, const Norm& n, int rows, int cols, float eps, hipStream_t st,
+              int drop_period = 0) {
+  LnP p;
+  p.x = x; p.ldx = ldx; p.y = y; p.ldy = ldy; p.y_bf16 = y16; p.w = n.w; p.b = n.b; p.rows = rows; p.cols = cols; p.eps = eps;
+  p.drop_period = drop_period;
+  return layernorm(p, st);
+}
+
+#define RUN(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Backbone: DINOv2 ViT.  n images -> m->feat [n, HW, C] fp32 token-major.
+// ---------------------------------------------------------------------------------------------
+static int run_backbone(ec_model* m, const float* img, int n, float* feat_out, hipStream_t st) {
+  const int C = m->C, T = m->T, HW = m->HW, g = m->g, H = m->cfg.image_size;
+  const bool h16 = m->bb16;
+  const int nh = m->cfg.num_heads;
+  const long M = (long)n * T;
+  RUN(im2col14(img, m->bb_h, h16, n, H, g, m->Kp, st));
+  {  // patch embedding GEMM, one batch entry per image so rows land at token 1.. of each image; + bias + pos[1:]
+    GemmP p;
+    p.A = m->bb_h; p.lda = m->Kp; p.sA = (long)HW * m->Kp; p.ab_bf16 = h16;
+    p.B = h16 ? (const void*)m->patch.w16 : (const void*)m->patch.w; p.ldb = m->Kp;
+    p.C = m->bb_x + C; p.ldc = C; p.sC = (long)T * C;
+    p.bias = m->patch.b; p.table = m->pos + C; p.ldt = C; p.period = HW;
+    p.M = HW; p.N = C; p.K = m->Kp; p.batch = n;
+    RUN(gemm_nt(p, st));
+  }
+  RUN(set_cls_rows(m->bb_x, C, m->cls, m->pos, n, T, C, st));
+  if (!feat_out) m->taps["tokens0"] = {m->bb_x, M * C};
+  for (size_t i = 0; i < m->blocks.size(); ++i) {
+    const BBlock& b = m->blocks[i];
+    RUN(ln(m->bb_x, C, m->bb_xn, C, h16, b.n1, (int)M, C, 1e-6f, st));
+    RUN(linear(m->bb_xn, C, h16, b.qkv, m->bb_qkv, 3 * C, h16, (int)M, ACT_NONE, st));
+    AttnP a;
+    const size_t es = h16 ? 2 : 4;
+    a.Q = m->bb_qkv; a.K = (const char*)m->bb_qkv + (size_t)C * es; a.V = (const char*)m->bb_qkv + (size_t)2 * C * es;
+    a.O = m->bb_att;
+    a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
+    a.sQ = a.sK = a.sV = (long)T * 3 * C; a.sO = (long)T * C;
+    a.B = n; a.H = nh; a.Lq = T; a.Lk = T; a.hd = C / nh; a.bf16 = h16;
+    RUN(attention(a, st));
+    RUN(linear(m->bb_att, C, h16, b.proj, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls1, m->bb_x, C));
+    RUN(ln(m->bb_x, C, m->bb_xn, C, h16, b.n2, (int)M, C, 1e-6f, st));
+    RUN(linear(m->bb_xn, C, h16, b.fc1, m->bb_h, 4 * C, h16, (int)M, ACT_GELU, st));
+    RUN(linear(m->bb_h, 4 * C, h16, b.fc2, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls2, m->bb_x, C));
+  }
+  RUN(ln(m->bb_x, C, feat_out ? feat_out : m->feat, C, false, m->bnorm, (int)M, C, 1e-6f, st, T));
+  return 0;
+}
+
+// One TransformerDecoderLayer (encoder_decoder.py:584-651) on nb = batch entries.
+//   x    [nb*K, d] fp32, row stride ldx (the main decoder keeps x as the left half of [x | qpe], ldx = 2d)
+//   mem  [nb, HW, d] with batch stride s_mem (row stride d)
+//   adjacency / masks are indexed by (batch % bs) so the S shots of the skeleton head share them.
+struct LayerIO {
+  float* x; long ldx;
+  float* mem; long s_mem;
+  const float* adj1; const float* valid; const uint8_t* kmask_fixed;
+  const float* bias;   // [nb, nhead, K, K] or null
+  int nb, bs;
+  bool update_mem;
+};
+
+static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool biased, bool two_way, float* qkv, float* att,
+                         float* tmp, float* qc, float* kv, float* y, float* z, float* qimg, float* kvk, float* attimg,
+                         float* tmpimg, int F, hipStream_t st) {
+  const int d = m->d, E = m->E, K = m->K, HW = m->HW, nh = m->cfg.nhead;
+  const int Mk = io.nb * K;
+  // ---- self attention over the K keypoint tokens (hd = d/nh = 32)
+  RUN(linear(io.x, io.ldx, false, L.sa_in, qkv, 3 * d, false, Mk, ACT_NONE, st));
+  {
+    AttnP a;
+    a.Q = qkv; a.K = qkv + d; a.V = qkv + 2 * d; a.O = att;
+    a.ldq = a.ldk = a.ldv = 3 * d; a.ldo = d;
+    a.sQ = a.sK = a.sV = (long)K * 3 * d; a.sO = (long)K * d;
+    a.kmask = io.kmask_fixed; a.mask_start = 0; a.mask_len = K; a.mask_mod = io.bs;
+    a.bias = io.bias;
+    a.B = io.nb; a.H = nh; a.Lq = K; a.Lk = K; a.hd = d / nh;
+    RUN(attention(a, st));
+  }
+  RUN(linear(att, d, false, L.sa_out, tmp, d, false, Mk, ACT_NONE, st, nullptr, io.x, io.ldx));
+  RUN(ln(tmp, d, io.x, io.ldx, false, L.n1, Mk, d, 1e-5f, st));
+  // ---- cross attention tokens -> image (hd = E/nh = 64); Q input is [x | init_pos] (K = 2d) in the main decoder
+  RUN(linear(io.x, io.ldx, false, L.ca_q, qc, E, false, Mk, ACT_NONE, st));
+  {
+    GemmP p;  // K|V of the image tokens, one batch entry per sample (mem may be a strided view)
+    p.A = io.mem; p.lda = d; p.sA = io.s_mem;
+    p.B = L.ca_kv.w; p.ldb = d;
+    p.C = kv; p.ldc = 2 * E; p.sC = (long)HW * 2 * E;
+    p.table = L.ca_kv_table; p.ldt = 2 * E; p.period = HW;
+    p.M = HW; p.N = 2 * E; p.K = d; p.batch = io.nb;
+    RUN(gemm_nt(p, st));
+    AttnP a;
+    a.Q = qc; a.K = kv; a.V = kv + E; a.O = att;
+    a.ldq = E; a.ldk = a.ldv = 2 * E; a.ldo = E;
+    a.sQ = (long)K * E; a.sK = a.sV = (long)HW * 2 * E; a.sO = (long)K * E;
+    a.B = io.nb; a.H = nh; a.Lq = K; a.Lk = HW; a.hd = E / nh;
+    RUN(attention(a, st));
+  }
+  RUN(linear(att, E, false, L.ca_fold, tmp, d, false, Mk, ACT_NONE, st, nullptr, io.x, io.ldx));
+  RUN(ln(tmp, d, io.x, io.ldx, false, L.n2, Mk, d, 1e-5f, st));
+  // ---- GCN feed-forward (encoder_decoder.py:508-524,634-637): y = conv1d(x) -> [.., 2F];
+  //      z = relu(valid * y[:, :F] + adj1 @ y[:, F:]);  x = LN3(x + ffn2(z))
+  RUN(linear(io.x, io.ldx, false, L.ffn1, y, 2 * F, false, Mk, ACT_NONE, st));
+  {
+    BgemmP p;
+    p.A = io.adj1; p.lda = K; p.sA = (long)K * K; p.modA = io.bs;
+    p.B = y + F; p.ldb = 2 * F; p.sB = (long)K * 2 * F; p.transB = 0;
+    p.C = z; p.ldc = F; p.sC = (long)K * F;
+    p.M = K; p.N = F; p.K = K; p.batch = io.nb;
+    p.self = y; p.ld_self = 2 * F; p.s_self = (long)K * 2 * F; p.rowscale = io.valid; p.mod_rs = io.bs; p.relu = 1;
+    RUN(bgemm_small(p, st));
+  }
+  RUN(linear(z, F, false, L.ffn2, tmp, d, false, Mk, ACT_NONE, st, nullptr, io.x, io.ldx));
+  RUN(ln(tmp, d, io.x, io.ldx, false, L.n3, Mk, d, 1e-5f, st));
+  if (two_way && io.update_mem) {
+    // ---- image -> token attention, NO masks (encoder_decoder.py:638-649)
+    const int Mi = io.nb * HW;
+    RUN(linear(io.mem, d, false, L.i2t_q, qimg, E, false, Mi, ACT_NONE, st, nullptr, nullptr, 0, L.i2t_q_table, E, HW));
+    RUN(linear(io.x, io.ldx, false, L.i2t_kv, kvk, 2 * E, false, Mk, ACT_NONE, st));
+    AttnP a;
+    a.Q = qimg; a.K = kvk; a.V = kvk + E; a.O = attimg;
+    a.ldq = E; a.ldk = a.ldv = 2 * E; a.ldo = E;
+    a.sQ = (long)HW * E; a.sK = a.sV = (long)K * 2 * E; a.sO = (long)HW * E;
+    a.B = io.nb; a.H = nh; a.Lq = HW; a.Lk = K; a.hd = E / nh;
+    RUN(attention(a, st));
+    RUN(linear(attimg, E, false, L.i2t_fold, tmpimg, d, false, Mi, ACT_NONE, st, nullptr, io.mem, d));
+    RUN(ln(tmpimg, d, io.mem, d, false, L.n4, Mi, d, 1e-5f, st));
+  }
+  return 0;
+}
+
+static int kpt_mlp(ec_model* m, const KptBranch& kb, const float* x, long ldx, int rows, const float* prev, float* out,
+                   hipStream_t st) {
+  const int d = m->d;
+  RUN(linear(x, ldx, false, kb.l0, m->d_k1, d, false, rows, ACT_GELU, st));
+  RUN(linear(m->d_k1, d, false, kb.l2, m->d_k2, d, false, rows, ACT_GELU, st));
+  RUN(linear(m->d_k2, d, false, kb.l4, m->d_k1, d, false, rows, ACT_GELU, st));
+  return kpt_out(m->d_k1, d, kb.w6, kb.b6, prev, out, rows, d, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Head: TwoStageHead.forward (head.py:161-222).  fq: [bs,HW,C] tokens, fs: S pointers [bs,HW,C].
+// ---------------------------------------------------------------------------------------------
+static int run_head(ec_model* m, const float* fq, const float* const* fs, const float* const* target_s, const float* mask_s,
+                    int bs, int S, hipStream_t st, const ec_outputs* out) {
+  const int C = m->C, d = m->d, E = m->E, K = m->K, HW = m->HW, L = m->L, g = m->g, nh = m->cfg.nhead;
+  const int Fd = m->cfg.ffn_dim, Fs = m->cfg.skel_ffn_dim, hops1 = m->cfg.max_hops + 1;
+  const int Mk = bs * K, Mi = bs * HW;
+  float* sim = out->similarity_map_dev;
+  float* adj_out = out->adj_dev;
+  float* attn_adj = out->attn_adj_dev ? out->attn_adj_dev : m->attn_adj;
+  float* pts = out->out_points_dev ? out->out_points_dev : m->d_pts;
+
+  // (1) input_proj on the query features, written straight into the encoder token buffer [bs, L, d] (rows 0..HW-1)
+  {
+    GemmP p;
+    p.A = fq; p.lda = C; p.sA = (long)HW * C;
+    p.B = m->input_proj.w; p.ldb = C; p.bias = m->input_proj.b;
+    p.C = m->e_x; p.ldc = d; p.sC = (long)L * d;
+    p.M = HW; p.N = d; p.K = C; p.batch = bs;
+    RUN(gemm_nt(p, st));
+  }
+  // (2) support keypoint pooling + query_proj (head.py:175-188)
+  for (int s = 0; s < S; ++s) {
+    RUN(pool_weights(target_s[s], mask_s, 1.f / (float)S, m->Wp, bs, K, m->cfg.heatmap_size, g, st));
+    BgemmP p;
+    p.A = m->Wp; p.lda = HW; p.sA = (long)K * HW;
+    p.B = fs[s]; p.ldb = C; p.sB = (long)HW * C; p.transB = 0;
+    p.C = m->pooled; p.ldc = C; p.sC = (long)K * C;
+    p.M = K; p.N = C; p.K = HW; p.batch = bs;
+    p.beta = s == 0 ? 0.f : 1.f;
+    RUN(bgemm_small(p, st));
+  }
+  RUN(linear(m->pooled, C, false, m->query_proj, m->sk, d, false, Mk, ACT_NONE, st));
+  m->taps["support_keypoints"] = {m->sk, (long)Mk * d};
+  RUN(copy3d(m->e_x + (long)HW * d, d, (long)L * d, m->sk, d, (long)K * d, bs, K, d, st));
+
+  // (3) skeleton head (skeleton.py:58-161)
+  RUN(adj_build(m->d_edges, m->d_off, mask_s, m->valid, m->kmask, m->kmask_fixed, m->binary, m->adj_r1, bs, K, st));
+  const int nb = S * bs;
+  for (int s = 0; s < S; ++s) {
+    RUN(linear(fs[s], C, false, m->image_project, m->s_mem + (long)s * Mi * d, d, false, Mi, ACT_NONE, st));
+    RUN(copy2d(m->s_x + (long)s * Mk * d, d, m->sk, d, Mk, d, st));
+  }
+  for (size_t i = 0; i < m->skel.size(); ++i) {
+    LayerIO io;
+    io.x = m->s_x; io.ldx = d; io.mem = m->s_mem; io.s_mem = (long)HW * d;
+    io.adj1 = m->adj_r1; io.valid = m->valid; io.kmask_fixed = m->kmask_fixed; io.bias = nullptr;
+    io.nb = nb; io.bs = bs;
+    io.update_mem = (i + 1 < m->skel.size());  // the last layer's image update is never read (skeleton.py:104-112)
+    RUN(run_dec_layer(m, m->skel[i], io, false, true, m->s_qkv, m->s_att, m->s_tmp, m->s_qc, m->s_kv, m->s_y, m->s_z, m->s_qimg,
+                      m->s_kvk, m->s_attimg, m->s_tmpimg, Fs, st));
+  }
+  RUN(mean_over(m->kp_ref, m->s_x, (long)Mk * d, S, (long)Mk * d, st));
+  m->taps["skel_kp_refined"] = {m->kp_ref, (long)Mk * d};
+  RUN(rownorm(m->kp_ref, m->kn, Mk, d, st));
+  {
+    BgemmP p;
+    p.A = m->kn; p.lda = d; p.sA = (long)K * d;
+    p.B = m->kn; p.ldb = d; p.sB = (long)K * d; p.transB = 1;
+    p.C = m->P; p.ldc = K; p.sC = (long)K * K;
+    p.M = K; p.N = K; p.K = d; p.batch = bs;
+    RUN(bgemm_small(p, st));
+  }
+  RUN(adj_combine(m->P, m->binary, m->valid, m->zc_w, m->zc_b, adj_out, m->adj1, attn_adj, bs, K, st));
+  {  // Markov powers: A^2 = A A, A^3 = A^2 A, A^4 = A^2 A^2 (torch.matrix_power's association)
+    const long KK = (long)K * K, hop = (long)bs * KK;
+    auto mm = [&](const float* a, const float* b, float* c) {
+      BgemmP p;
+      p.A = a; p.lda = K; p.sA = KK; p.B = b; p.ldb = K; p.sB = KK; p.transB = 0;
+      p.C = c; p.ldc = K; p.sC = KK; p.M = K; p.N = K; p.K = K; p.batch = bs;
+      return bgemm_small(p, st);
+    };
+    float* A1 = attn_adj + hop;
+    if (hops1 > 2) RUN(mm(A1, A1, attn_adj + 2 * hop));
+    if (hops1 > 3) RUN(mm(attn_adj + 2 * hop, A1, attn_adj + 3 * hop));
+    if (hops1 > 4) RUN(mm(attn_adj + 2 * hop, attn_adj + 2 * hop, attn_adj + 4 * hop));
+    EC_REQUIRE(hops1 <= 5, EC_ERR_ARG, "max_hops > 4 not supported");
+  }
+
+  // (4) encoder (encoder_decoder.py:276-310, 461-483) over [bs, L = HW + K, d]
+  const int Me = bs * L;
+  for (size_t i = 0; i < m->enc.size(); ++i) {
+    const EncLayer& e = m->enc[i];
+    RUN(add_table(m->e_x, d, m->pos_cat, d, L, Me, d, st));   // src = src + pos, every layer, feeds q,k,v
+    RUN(linear(m->e_x, d, false, e.in, m->e_qkv, 3 * d, false, Me, ACT_NONE, st));
+    AttnP a;
+    a.Q = m->e_qkv; a.K = m->e_qkv + d; a.V = m->e_qkv + 2 * d; a.O = m->e_att;
+    a.ldq = a.ldk = a.ldv = 3 * d; a.ldo = d;
+    a.sQ = a.sK = a.sV = (long)L * 3 * d; a.sO = (long)L * d;
+    a.kmask = m->kmask; a.mask_start = HW; a.mask_len = K; a.mask_mod = 0;
+    a.B = bs; a.H = nh; a.Lq = L; a.Lk = L; a.hd = d / nh;
+    RUN(attention(a, st));
+    RUN(linear(m->e_att, d, false, e.out, m->e_tmp, d, false, Me, ACT_NONE, st, nullptr, m->e_x, d));
+    RUN(ln(m->e_tmp, d, m->e_x, d, false, e.n1, Me, d, 1e-5f, st));
+    RUN(linear(m->e_x, d, false, e.l1, m->e_h, Fd, false, Me, ACT_RELU, st));
+    RUN(linear(m->e_h, Fd, false, e.l2, m->e_tmp, d, false, Me, ACT_NONE, st, nullptr, m->e_x, d));
+    RUN(ln(m->e_tmp, d, m->e_x, d, false, e.n2, Me, d, 1e-5f, st));
+  }
+  m->taps["enc"] = {m->e_x, (long)Me * d};
+  float* mem = m->e_x;                       // image tokens of sample b: rows b*L .. b*L+HW-1
+  float* kp = m->e_x + (long)HW * d;         // keypoint tokens: rows b*L+HW ..
+  const long s_tok = (long)L * d;
+
+  // (5) proposal generator (encoder_decoder.py:49-112)
+  {
+    GemmP p;
+    p.A = kp; p.lda = d; p.sA = s_tok; p.B = m->pg_support.w; p.ldb = d; p.bias = m->pg_support.b;
+    p.C = m->p_fs; p.ldc = d; p.sC = (long)K * d; p.M = K; p.N = d; p.K = d; p.batch = bs;
+    RUN(gemm_nt(p, st));
+    GemmP q;
+    q.A = mem; q.lda = d; q.sA = s_tok; q.B = m->pg_query.w; q.ldb = d; q.bias = m->pg_query.b;
+    q.C = m->p_fq; q.ldc = d; q.sC = (long)HW * d; q.M = HW; q.N = d; q.K = d; q.batch = bs;
+    RUN(gemm_nt(q, st));
+  }
+  RUN(linear(m->p_fs, d, false, m->pg_dyn0, m->p_g1, m->pg_dyn0.N, false, Mk, ACT_RELU, st));
+  RUN(linear(m->p_g1, m->pg_dyn0.N, false, m->pg_dyn2, m->p_fs2, d, false, Mk, ACT_TANHGATE, st, nullptr, nullptr, 0, nullptr, 0, 1,
+             m->p_fs, d));
+  {
+    BgemmP p;  // similarity[b, k, hw] = fs'[b,k,:] . fq[b,hw,:]
+    p.A = m->p_fs2; p.lda = d; p.sA = (long)K * d;
+    p.B = m->p_fq; p.ldb = d; p.sB = (long)HW * d; p.transB = 1;
+    p.C = sim; p.ldc = HW; p.sC = (long)K * HW; p.M = K; p.N = HW; p.K = d; p.batch = bs;
+    RUN(bgemm_small(p, st));
+  }
+  RUN(proposals(sim, out->initial_proposals_dev, pts, Mk, g, st));   // pts[0] = decoder proposals b_0
+
+  // (6) decoder (encoder_decoder.py:330-425): x lives as the left half of d_qin = [x | qpe]
+  RUN(copy3d(m->d_qin, 2 * d, (long)K * 2 * d, kp, d, s_tok, bs, K, d, st));
+  for (size_t li = 0; li < m->dec.size(); ++li) {
+    const DecLayer& Ld = m->dec[li];
+    float* bi = pts + (long)li * Mk * 2;
+    RUN(sincos_coords(bi, m->dim_t, m->d_sc, d, Mk, d / 2, st));
+    RUN(linear(m->d_sc, d, false, m->rp0, m->d_rp, d, false, Mk, ACT_GELU, st));
+    RUN(linear(m->d_rp, d, false, m->rp1, m->d_qin + d, 2 * d, false, Mk, ACT_NONE, st));
+    RUN(bias_mlp(attn_adj, Ld.m_w1, Ld.m_b1, Ld.m_w2, Ld.m_b2, m->d_bias, hops1, m->cfg.max_hops + nh, nh, bs, K, st));
+    LayerIO io;
+    io.x = m->d_qin; io.ldx = 2 * d; io.mem = mem; io.s_mem = s_tok;
+    io.adj1 = m->adj1; io.valid = m->valid; io.kmask_fixed = m->kmask_fixed; io.bias = m->d_bias;
+    io.nb = bs; io.bs = bs; io.update_mem = false;
+    RUN(run_dec_layer(m, Ld, io, true, false, m->d_qkv, m->d_att, m->d_tmp, m->d_qc, m->d_kv, m->d_y, m->d_z, nullptr, nullptr,
+                      nullptr, nullptr, Fd, st));
+    RUN(ln(m->d_qin, 2 * d, m->d_hs + (long)li * Mk * d, d, false, m->dec_norm, Mk, d, 1e-5f, st));
+    // b_{l+1} = sigmoid(inverse_sigmoid(b_l) + kpt_branch[l](x))   (un-normed x, :395-402)
+    RUN(kpt_mlp(m, m->kpt[li], m->d_qin, 2 * d, Mk, bi, pts + (long)(li + 1) * Mk * 2, st));
+  }
+  m->taps["hs"] = {m->d_hs, (long)m->dec.size() * Mk * d};
+  // (7) head output (head.py:216-220)
+  for (size_t li = 0; li < m->dec.size(); ++li)
+    RUN(kpt_mlp(m, m->kpt[li], m->d_hs + (long)li * Mk * d, d, Mk, pts + (long)li * Mk * 2,
+                out->output_kpts_dev + (long)li * Mk * 2, st));
+  return 0;
+}
+
+static int upload_edges(ec_model* m, const int32_t* edges, const int32_t* off, int bs, hipStream_t st) {
+  EC_REQUIRE(off && off[0] == 0, EC_ERR_ARG, "edge_offsets must start at 0");
+  const int ne = off[bs];
+  for (int b = 0; b < bs; ++b) EC_REQUIRE(off[b + 1] >= off[b], EC_ERR_ARG, "edge_offsets must be non-decreasing");
+  for (int e = 0; e < 2 * ne; ++e)
+    EC_REQUIRE(edges[e] >= 0 && edges[e] < m->K, EC_ERR_ARG, "skeleton edge index out of range [0, K)");  // reference: IndexError
+  if (ne > m->edges_cap) {
+    int cap = ne * 2 + 64;
+    RUN(dalloc(m, &m->d_edges, (size_t)cap * 2));
+    m->edges_cap = cap;
+  }
+  if (ne > 0) EC_HIP(hipMemcpyAsync(m->d_edges, edges, (size_t)ne * 2 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  EC_HIP(hipMemcpyAsync(m->d_off, off, (size_t)(bs + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  return 0;
+}
+
+}  // namespace ec
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+const char* ec_last_error(void) { return g_err.c_str(); }
+int ec_version(void) { return 1; }
+
+int ec_create(const ec_config* cfg, ec_handle* out) {
+  EC_REQUIRE(cfg && out, EC_ERR_ARG, "null argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    set_error("no HIP device visible: libedgecape_hip has no CPU fallback");
+    return EC_ERR_NODEVICE;
+  }
+  EC_REQUIRE(cfg->patch == 14, EC_ERR_ARG, "patch size must be 14");
+  EC_REQUIRE(cfg->embed_dim % 64 == 0 && cfg->embed_dim / cfg->num_heads == 64, EC_ERR_ARG, "backbone head dim must be 64");
+  EC_REQUIRE(cfg->d_model == 256 && cfg->nhead == 8, EC_ERR_ARG, "head d_model/nhead must be 256/8");
+  EC_REQUIRE(cfg->num_kpts > 0 && cfg->num_kpts <= 128 && cfg->num_kpts % 4 == 0, EC_ERR_ARG, "num_kpts must be a multiple of 4, <= 128");
+  EC_REQUIRE(cfg->max_hops == 4, EC_ERR_ARG, "max_hops must be 4");
+  EC_REQUIRE(cfg->head_precision == EC_F32, EC_ERR_ARG, "head_precision: only EC_F32 is built");
+  EC_REQUIRE(cfg->max_batch > 0 && cfg->max_shots > 0, EC_ERR_ARG, "max_batch / max_shots must be positive");
+  ec_model* m = new ec_model();
+  m->cfg = *cfg;
+  m->g = cfg->image_size / cfg->patch;
+  m->HW = m->g * m->g; m->T = m->HW + 1; m->C = cfg->embed_dim; m->K = cfg->num_kpts; m->d = cfg->d_model;
+  m->L = m->HW + m->K; m->E = 2 * m->d;
+  m->bb16 = cfg->backbone_precision == EC_BF16;
+  EC_REQUIRE(m->g >= 2 && m->g <= 32, EC_ERR_ARG, "token grid must be within 2..32");
+  *out = m;
+  return EC_OK;
+}
+
+int ec_destroy(ec_handle m) {
+  if (!m) return EC_OK;
+  for (void* p : m->owned) (void)hipFree(p);
+  delete m;
+  return EC_OK;
+}
+
+int ec_load_tensor(ec_handle m, const char* name, const void* host, const int64_t* shape, int ndim, int dtype) {
+  EC_REQUIRE(m && name && host && shape && ndim >= 0 && ndim <= 6, EC_ERR_ARG, "bad argument");
+  EC_REQUIRE(!m->finalized, EC_ERR_STATE, "model already finalized");
+  Tensor t;
+  t.shape.assign(shape, shape + ndim);
+  const long n = t.numel();
+  t.host.resize(n);
+  switch (dtype) {
+    case EC_DT_F32: memcpy(t.host.data(), host, n * sizeof(float)); break;
+    case EC_DT_F64: for (long i = 0; i < n; ++i) t.host[i] = (float)((const double*)host)[i]; break;
+    case EC_DT_BF16: for (long i = 0; i < n; ++i) t.host[i] = bf2f(((const bf16_t*)host)[i]); break;
+    case EC_DT_F16: for (long i = 0; i < n; ++i) t.host[i] = (float)((const _Float16*)host)[i]; break;
+    default: set_error("unknown dtype"); return EC_ERR_ARG;
+  }
+  RUN(dalloc(m, &t.dev, (size_t)n));
+  EC_HIP(hipMemcpy(t.dev, t.host.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  m->tensors[name] = std::move(t);
+  return EC_OK;
+}
+
+int ec_set_pos_embed(ec_handle m, const float* table, int64_t rows, int64_t cols) {
+  EC_REQUIRE(m && table, EC_ERR_ARG, "bad argument");
+  EC_REQUIRE(rows == m->T && cols == m->C, EC_ERR_ARG, "pos table must be [1+g*g, C]");
+  int64_t shape[2] = {rows, cols};
+  return ec_load_tensor(m, "@pos_table", table, shape, 2, EC_DT_F32);
+}
+
+int ec_finalize(ec_handle m) {
+  EC_REQUIRE(m && !m->finalized, EC_ERR_STATE, "bad handle or already finalized");
+  const int C = m->C, d = m->d, K = m->K, HW = m->HW, T = m->T, L = m->L, E = m->E;
+  const std::string bp = "encoder_query.", hp = "keypoint_head_module.";
+  int rc;
+  // ---------------- backbone
+  {
+    GET(pw, bp + "patch_embed.proj.weight"); GET(pb, bp + "patch_embed.proj.bias");
+    EC_REQUIRE(pw->shape[0] == C && pw->numel() == (long)C * 588, EC_ERR_ARG, "patch_embed weight shape");
+    std::vector<float> Wp((size_t)C * m->Kp, 0.f);
+    for (int n = 0; n < C; ++n) memcpy(&Wp[(size_t)n * m->Kp], &pw->host[(size_t)n * 588], 588 * sizeof(float));
+    m->patch.N = C; m->patch.K = m->Kp; m->patch.b = pb->dev;
+    if ((rc = upload(m, Wp, &m->patch.w))) return rc;
+    if (m->bb16 && (rc = upload16(m, Wp, &m->patch.w16))) return rc;
+    GET(cls, bp + "cls_token"); GET(pos, "@pos_table");
+    m->cls = cls->dev; m->pos = pos->dev;
+    if ((rc = make_norm(m, bp + "norm", &m->bnorm))) return rc;
+    m->blocks.resize(m->cfg.depth);
+    for (int i = 0; i < m->cfg.depth; ++i) {
+      const std::string p = bp + "blocks." + std::to_string(i) + ".";
+      BBlock& b = m->blocks[i];
+      if ((rc = make_norm(m, p + "norm1", &b.n1)) || (rc = make_norm(m, p + "norm2", &b.n2))) return rc;
+      if ((rc = make_lin(m, p + "attn.qkv.weight", p + "attn.qkv.bias", &b.qkv, m->bb16))) return rc;
+      if ((rc = make_lin(m, p + "attn.proj.weight", p + "attn.proj.bias", &b.proj, m->bb16))) return rc;
+      if ((rc = make_lin(m, p + "mlp.fc1.weight", p + "mlp.fc1.bias", &b.fc1, m->bb16))) return rc;
+      if ((rc = make_lin(m, p + "mlp.fc2.weight", p + "mlp.fc2.bias", &b.fc2, m->bb16))) return rc;
+      EC_REQUIRE(b.qkv.N == 3 * C && b.qkv.K == C && b.fc1.N == 4 * C && b.fc2.K == 4 * C, EC_ERR_ARG, "backbone block shapes");
+      GET(l1, p + "ls1.gamma"); GET(l2, p + "ls2.gamma");
+      b.ls1 = l1->dev; b.ls2 = l2->dev;
+    }
+  }
+  // ---------------- head
+  std::vector<float> dim_t;
+  std::vector<float> pos_img = sine_table(m->g, d / 2, &dim_t);
+  if ((rc = upload(m, pos_img, &m->pos_img)) || (rc = upload(m, dim_t, &m->dim_t))) return rc;
+  {
+    std::vector<float> pc((size_t)L * d, 0.f);
+    memcpy(pc.data(), pos_img.data(), pos_img.size() * sizeof(float));
+    if ((rc = upload(m, pc, &m->pos_cat))) return rc;
+  }
+  if ((rc = make_lin(m, hp + "input_proj.weight", hp + "input_proj.bias", &m->input_proj, false))) return rc;
+  if ((rc = make_lin(m, hp + "query_proj.weight", hp + "query_proj.bias", &m->query_proj, false))) return rc;
+  if ((rc = make_lin(m, hp + "skeleton_head.image_project.weight", hp + "skeleton_head.image_project.bias", &m->image_project, false)))
+    return rc;
+  EC_REQUIRE(m->input_proj.K == C && m->query_proj.K == C, EC_ERR_ARG, "head in_channels must equal backbone width");
+  EC_REQUIRE(m->image_project.K == C && m->cfg.skel_ffn_dim == C, EC_ERR_ARG,
+             "skeleton_head.dim_feedforward must equal the backbone width (skeleton.py:40,92)");
+  {
+    GET(zw, hp + "skeleton_head.zero_conv.weight"); GET(zb, hp + "skeleton_head.zero_conv.bias");
+    m->zc_w = zw->dev; m->zc_b = zb->dev;
+  }
+  m->skel.resize(m->cfg.skel_layers);
+  for (int i = 0; i < m->cfg.skel_layers; ++i)
+    if ((rc = build_dec_layer(m, hp + "skeleton_head.skeleton_predictor." + std::to_string(i) + ".", false, true, pos_img, &m->skel[i])))
+      return rc;
+  m->dec.resize(m->cfg.dec_layers);
+  for (int i = 0; i < m->cfg.dec_layers; ++i)
+    if ((rc = build_dec_layer(m, hp + "transformer.decoder.layers." + std::to_string(i) + ".", true, false, pos_img, &m->dec[i])))
+      return rc;
+  for (auto& l : m->skel) EC_REQUIRE(l.ffn1.N == 2 * m->cfg.skel_ffn_dim, EC_ERR_ARG, "skeleton GCN width mismatch");
+  for (auto& l : m->dec) EC_REQUIRE(l.ffn1.N == 2 * m->cfg.ffn_dim, EC_ERR_ARG, "decoder GCN width mismatch");
+  m->enc.resize(m->cfg.enc_layers);
+  for (int i = 0; i < m->cfg.enc_layers; ++i) {
+    const std::string p = hp + "transformer.encoder.layers." + std::to_string(i) + ".";
+    EncLayer& e = m->enc[i];
+    if ((rc = make_lin(m, p + "self_attn.in_proj_weight", p + "self_attn.in_proj_bias", &e.in, false))) return rc;
+    if ((rc = make_lin(m, p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias", &e.out, false))) return rc;
+    if ((rc = make_lin(m, p + "linear1.weight", p + "linear1.bias", &e.l1, false))) return rc;
+    if ((rc = make_lin(m, p + "linear2.weight", p + "linear2.bias", &e.l2, false))) return rc;
+    if ((rc = make_norm(m, p + "norm1", &e.n1)) || (rc = make_norm(m, p + "norm2", &e.n2))) return rc;
+  }
+  if ((rc = make_norm(m, hp + "transformer.decoder.norm", &m->dec_norm))) return rc;
+  if ((rc = make_lin(m, hp + "transformer.decoder.ref_point_head.layers.0.weight", hp + "transformer.decoder.ref_point_head.layers.0.bias", &m->rp0, false))) return rc;
+  if ((rc = make_lin(m, hp + "transformer.decoder.ref_point_head.layers.1.weight", hp + "transformer.decoder.ref_point_head.layers.1.bias", &m->rp1, false))) return rc;
+  const std::string pg = hp + "transformer.proposal_generator.";
+  if ((rc = make_lin(m, pg + "support_proj.weight", pg + "support_proj.bias", &m->pg_support, false))) return rc;
+  if ((rc = make_lin(m, pg + "query_proj.weight", pg + "query_proj.bias", &m->pg_query, false))) return rc;
+  if ((rc = make_lin(m, pg + "dynamic_proj.0.weight", pg + "dynamic_proj.0.bias", &m->pg_dyn0, false))) return rc;
+  if ((rc = make_lin(m, pg + "dynamic_proj.2.weight", pg + "dynamic_proj.2.bias", &m->pg_dyn2, false))) return rc;
+  m->kpt.resize(m->cfg.dec_layers);
+  for (int i = 0; i < m->cfg.dec_layers; ++i) {
+    const std::string p = hp + "kpt_branch." + std::to_string(i) + ".mlp.";
+    KptBranch& kb = m->kpt[i];
+    if ((rc = make_lin(m, p + "0.weight", p + "0.bias", &kb.l0, false))) return rc;
+    if ((rc = make_lin(m, p + "2.weight", p + "2.bias", &kb.l2, false))) return rc;
+    if ((rc = make_lin(m, p + "4.weight", p + "4.bias", &kb.l4, false))) return rc;
+    GET(w6, p + "6.weight"); GET(b6, p + "6.bias");
+    kb.w6 = w6->dev; kb.b6 = b6->dev;
+  }
+  // host copies are no longer needed
+  for (auto& kv : m->tensors) std::vector<float>().swap(kv.second.host);
+
+  // ---------------- workspace
+  const int bs = m->cfg.max_batch, S = m->cfg.max_shots;
+  const int n = (1 + S) * bs;
+  m->n_img_max = n;
+  const size_t es = m->bb16 ? 2 : 4;
+  const size_t MT = (size_t)n * T;
+  if ((rc = dalloc(m, &m->bb_x, MT * C))) return rc;
+  if ((rc = dmalloc(m, &m->bb_xn, MT * C * es))) return rc;
+  if ((rc = dmalloc(m, &m->bb_qkv, MT * 3 * C * es))) return rc;
+  if ((rc = dmalloc(m, &m->bb_att, MT * C * es))) return rc;
+  if ((rc = dmalloc(m, &m->bb_h, std::max(MT * 4 * C, (size_t)n * HW * m->Kp) * es))) return rc;
+  if ((rc = dalloc(m, &m->feat, (size_t)n * HW * C))) return rc;
+  if ((rc = dalloc(m, &m->feat_nchw_tmp, (size_t)n * HW * C))) return rc;
+  if ((rc = dalloc(m, &m->d_off, (size_t)bs + 1))) return rc;
+  const size_t Mk = (size_t)bs * K, Mi = (size_t)bs * HW, KK = (size_t)K * K;
+  const int Fs = m->cfg.skel_ffn_dim, Fd = m->cfg.ffn_dim;
+#define WS(ptr, count) if ((rc = dalloc(m, &m->ptr, (size_t)(count)))) return rc
+  WS(Wp, Mk * HW); WS(pooled, Mk * C); WS(sk, Mk * d); WS(valid, Mk); WS(kmask, Mk); WS(kmask_fixed, Mk);
+  WS(binary, bs * KK); WS(adj_r1, bs * KK); WS(adj1, bs * KK); WS(P, bs * KK); WS(kn, Mk * d); WS(kp_ref, Mk * d);
+  WS(attn_adj, 5 * bs * KK);
+  WS(s_mem, S * Mi * d); WS(s_x, S * Mk * d); WS(s_tmp, S * Mk * d); WS(s_qkv, S * Mk * 3 * d); WS(s_att, S * Mk * E);
+  WS(s_qc, S * Mk * E); WS(s_kv, S * Mi * 2 * E); WS(s_y, S * Mk * 2 * Fs); WS(s_z, S * Mk * Fs); WS(s_qimg, S * Mi * E);
+  WS(s_kvk, S * Mk * 2 * E); WS(s_attimg, S * Mi * E); WS(s_tmpimg, S * Mi * d);
+  const size_t Me = (size_t)bs * L;
+  WS(e_x, Me * d); WS(e_qkv, Me * 3 * d); WS(e_att, Me * d); WS(e_tmp, Me * d); WS(e_h, Me * Fd);
+  WS(p_fs, Mk * d); WS(p_fq, Mi * d); WS(p_g1, Mk * 128); WS(p_fs2, Mk * d);
+  WS(d_qin, Mk * 2 * d); WS(d_sc, Mk * d); WS(d_rp, Mk * d); WS(d_bias, (size_t)bs * m->cfg.nhead * KK); WS(d_qkv, Mk * 3 * d);
+  WS(d_att, Mk * E); WS(d_tmp, Mk * d); WS(d_qc, Mk * E); WS(d_kv, Mi * 2 * E); WS(d_y, Mk * 2 * Fd); WS(d_z, Mk * Fd);
+  WS(d_hs, 3 * Mk * d); WS(d_pts, 4 * Mk * 2); WS(d_k1, Mk * d); WS(d_k2, Mk * d);
+#undef WS
+  EC_REQUIRE(m->pg_dyn0.N <= 128, EC_ERR_ARG, "dynamic_proj_dim must be <= 128");
+  EC_HIP(hipDeviceSynchronize());
+  m->finalized = true;
+  return EC_OK;
+}
+
+int ec_backbone(ec_handle m, const float* img, int n_img, float* feat, int layout, void* stream) {
+  EC_REQUIRE(m && m->finalized, EC_ERR_STATE, "model not finalized");
+  EC_REQUIRE(img && feat && n_img > 0 && n_img <= m->n_img_max, EC_ERR_ARG, "bad image batch (n_img <= (1+max_shots)*max_batch)");
+  hipStream_t st = (hipStream_t)stream;
+  if (layout == EC_LAYOUT_TOKENS) return run_backbone(m, img, n_img, feat, st);
+  RUN(run_backbone(m, img, n_img, m->feat_nchw_tmp, st));
+  return tokens_to_nchw(m->feat_nchw_tmp, feat, n_img, m->C, m->HW, st);
+}
+
+static int check_head_args(ec_handle m, int bs, int S, const ec_outputs* out) {
+  EC_REQUIRE(m && m->finalized, EC_ERR_STATE, "model not finalized");
+  EC_REQUIRE(bs > 0 && bs <= m->cfg.max_batch && S > 0 && S <= m->cfg.max_shots, EC_ERR_ARG, "bs / S exceed the configured maxima");
+  EC_REQUIRE(out && out->output_kpts_dev && out->initial_proposals_dev && out->similarity_map_dev && out->adj_dev, EC_ERR_ARG,
+             "missing output buffer");
+  return 0;
+}
+
+int ec_head(ec_handle m, const float* fq, const float* const* fs, int layout, const float* const* target_s, const float* mask_s,
+            const int32_t* edges, const int32_t* off, int bs, int S, void* stream, const ec_outputs* out) {
+  RUN(check_head_args(m, bs, S, out));
+  EC_REQUIRE(fq && fs && target_s && mask_s, EC_ERR_ARG, "null input");
+  hipStream_t st = (hipStream_t)stream;
+  RUN(upload_edges(m, edges, off, bs, st));
+  const size_t per = (size_t)bs * m->HW * m->C;
+  std::vector<const float*> fsp(S);
+  const float* fqp = fq;
+  if (layout == EC_LAYOUT_NCHW) {
+    RUN(nchw_to_tokens(fq, m->feat, bs, m->C, m->HW, st));
+    fqp = m->feat;
+    for (int s = 0; s < S; ++s) {
+      RUN(nchw_to_tokens(fs[s], m->feat + (1 + s) * per, bs, m->C, m->HW, st));
+      fsp[s] = m->feat + (1 + s) * per;
+    }
+  } else {
+    for (int s = 0; s < S; ++s) fsp[s] = fs[s];
+  }
+  return run_head(m, fqp, fsp.data(), target_s, mask_s, bs, S, st, out);
+}
+
+int ec_forward(ec_handle m, const float* img_q, const float* const* img_s, const float* const* target_s, const float* mask_s,
+               const int32_t* edges, const int32_t* off, int bs, int S, void* stream, const ec_outputs* out) {
+  RUN(check_head_args(m, bs, S, out));
+  EC_REQUIRE(img_q && img_s && target_s && mask_s, EC_ERR_ARG, "null input");
+  hipStream_t st = (hipStream_t)stream;
+  RUN(upload_edges(m, edges, off, bs, st));
+  const size_t per = (size_t)bs * m->HW * m->C;
+  // EdgeCape.extract_features (EdgeCape.py:186-191): the same backbone on the query and on every support image
+  RUN(run_backbone(m, img_q, bs, m->feat, st));
+  std::vector<const float*> fsp(S);
+  for (int s = 0; s < S; ++s) {
+    RUN(run_backbone(m, img_s[s], bs, m->feat + (1 + s) * per, st));
+    fsp[s] = m->feat + (1 + s) * per;
+  }
+  m->taps["feature_q"] = {m->feat, (long)per};
+  return run_head(m, m->feat, fsp.data(), target_s, mask_s, bs, S, st, out);
+}
+
+int ec_debug_read(ec_handle m, const char* name, float* host_out, int64_t max_elems, int64_t* n_elems) {
+  EC_REQUIRE(m && name && n_elems, EC_ERR_ARG, "bad argument");
+  auto it = m->taps.find(name);
+  if (it == m->taps.end()) { set_error(std::string("unknown tap: ") + name); return EC_ERR_NAME; }
+  *n_elems = it->second.second;
+  if (!host_out) return EC_OK;
+  EC_REQUIRE(max_elems >= *n_elems, EC_ERR_ARG, "host buffer too small");
+  EC_HIP(hipDeviceSynchronize());
+  EC_HIP(hipMemcpy(host_out, it->second.first, (size_t)*n_elems * sizeof(float), hipMemcpyDeviceToHost));
+  return EC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// single ops
+// ------------------------------------------------------------------------------------------------
+int ec_op_linear(const float* A, const float* W, const float* bias, const float* gamma, const float* resid, float* C, int M, int N,
+                 int K, int act, int precision, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  GemmP p;
+  p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N; p.C = C; p.bias = bias; p.gamma = gamma; p.resid = resid; p.ldr = N;
+  p.act = act;
+  if (precision == EC_BF16) {
+    bf16_t *a16 = nullptr, *w16 = nullptr;
+    EC_HIP(hipMalloc((void**)&a16, (size_t)M * K * 2));
+    EC_HIP(hipMalloc((void**)&w16, (size_t)N * K * 2));
+    int rc = f32_to_bf16(A, a16, (long)M * K, st);
+    if (!rc) rc = f32_to_bf16(W, w16, (long)N * K, st);
+    p.A = a16; p.B = w16; p.ab_bf16 = 1;
+    if (!rc) rc = gemm_nt(p, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(a16); (void)hipFree(w16);
+    return rc;
+  }
+  p.A = A; p.B = W;
+  return gemm_nt(p, st);
+}
+
+int ec_op_gemm_bench(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int precision, int iters,
+                     void* stream, float* ms) {
+  EC_REQUIRE(iters > 0 && ms, EC_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  GemmP p;
+  p.A = A; p.B = W; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N;
+  p.ab_bf16 = precision == EC_BF16; p.c_bf16 = p.ab_bf16;
+  hipEvent_t e0, e1;
+  EC_HIP(hipEventCreate(&e0));
+  EC_HIP(hipEventCreate(&e1));
+  RUN(gemm_nt(p, st));  // warm
+  EC_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i) RUN(gemm_nt(p, st));
+  EC_HIP(hipEventRecord(e1, st));
+  EC_HIP(hipEventSynchronize(e1));
+  float t = 0.f;
+  EC_HIP(hipEventElapsedTime(&t, e0, e1));
+  *ms = t / (float)iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return EC_OK;
+}
+
+int ec_op_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int cols, float eps, void* stream) {
+  LnP p;
+  p.x = x; p.ldx = cols; p.y = y; p.ldy = cols; p.w = w; p.b = b; p.rows = rows; p.cols = cols; p.eps = eps;
+  return layernorm(p, (hipStream_t)stream);
+}
+
+int ec_op_attention(const float* q, const float* k, const float* v, const uint8_t* kmask, const float* bias, float* o, int B, int H,
+                    int Lq, int Lk, int hd, int precision, void* stream) {
+  EC_REQUIRE(precision == EC_F32, EC_ERR_ARG, "ec_op_attention: only EC_F32 is built");
+  AttnP a;
+  a.Q = q; a.K = k; a.V = v; a.O = o;
+  a.ldq = a.ldk = a.ldv = a.ldo = (long)H * hd;
+  a.sQ = a.sO = (long)Lq * H * hd; a.sK = a.sV = (long)Lk * H * hd;
+  a.kmask = kmask; a.mask_start = 0; a.mask_len = Lk; a.mask_mod = 0;
+  a.bias = bias;
+  a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.hd = hd;
+  return attention(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

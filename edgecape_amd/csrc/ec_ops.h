@@ -1,0 +1,53 @@
+// Launch wrappers for the non-GEMM kernels (ec_ops.hip). Internal.
+#pragma once
+#include "ec_common.h"
+
+namespace ec {
+
+// y = LayerNorm(x) * w + b over `cols`; one wave per row.  If drop_period > 0 the rows are grouped in
+// periods of that length, the first row of each period (the cls token) is skipped and the output is
+// packed (DINOv2 get_intermediate_layers: final norm, drop cls).  y may be fp32 or bf16.
+// Optional second output y2 (fp32) = y + table[row % period2] (encoder: `src + pos` of the NEXT layer).
+struct LnP {
+  const float* x = nullptr; long ldx = 0;
+  void* y = nullptr; long ldy = 0; int y_bf16 = 0;
+  const float* w = nullptr; const float* b = nullptr;
+  int rows = 0, cols = 0; float eps = 1e-5f;
+  int drop_period = 0;
+};
+int layernorm(const LnP& p, hipStream_t st);
+
+int add_table(float* x, long ldx, const float* table, long ldt, int period, int rows, int cols, hipStream_t st);
+int copy2d(float* dst, long ldd, const float* src, long lds, int rows, int cols, hipStream_t st);
+// dst[b][r][c] = src[b][r][c] for b < batch with batch strides
+int copy3d(float* dst, long ldd, long sd, const float* src, long lds, long ss, int batch, int rows, int cols, hipStream_t st);
+int mean_over(float* dst, const float* src, long stride, int n, long count, hipStream_t st);
+int f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t st);
+int im2col14(const float* img, void* patches, int out_bf16, int n_img, int H, int g, int Kp, hipStream_t st);
+int set_cls_rows(float* x, long ldx, const float* cls, const float* pos0, int n_img, int T, int C, hipStream_t st);
+int nchw_to_tokens(const float* src, float* dst, int n, int C, int HW, hipStream_t st);
+int tokens_to_nchw(const float* src, float* dst, int n, int C, int HW, hipStream_t st);
+
+// head.py:175-184 — bilinear(g->hm) + normalised-heatmap pooling expressed as weights over the g*g cells
+int pool_weights(const float* target, const float* mask_s, float inv_shots, float* Wp, int bs, int K, int hm, int g,
+                 hipStream_t st);
+// skeleton.py:171-205 — edges -> binary adjacency, validity vectors, soft-normalised adjacency
+int adj_build(const int32_t* edges, const int32_t* offsets, const float* mask_s, float* valid, uint8_t* kmask,
+              uint8_t* kmask_fixed, float* binary, float* adj_r1, int bs, int K, hipStream_t st);
+int rownorm(const float* x, float* y, int rows, int cols, hipStream_t st);
+// skeleton.py:134-161 — combine cosine similarity with the prior, soft-normalise, Markov matrix
+int adj_combine(const float* P, const float* binary, const float* valid, const float* zc_w, const float* zc_b,
+                float* adj_out, float* adj1, float* attn_adj, int bs, int K, hipStream_t st);
+int set_identity(float* dst, int bs, int K, hipStream_t st);
+// bias_attn.py:188-191 — MLP(hops+1 -> hops+nhead -> nhead) over the Markov stack
+int bias_mlp(const float* attn_adj, const float* w1, const float* b1, const float* w2, const float* b2, float* out,
+             int hops1, int hidden, int nhead, int bs, int K, hipStream_t st);
+// encoder_decoder.py:76-112 — softmax, soft-argmax, argmax 3x3 window local soft-argmax
+int proposals(const float* sim, float* prop_loss, float* prop, int rows, int g, hipStream_t st);
+// positional_encoding.py:96-122
+int sincos_coords(const float* coords, const float* inv_dim_t, float* out, long ldo, int rows, int num_feats, hipStream_t st);
+// head.py:216-220 / encoder_decoder.py:395-431 — Linear(d->2) + sigmoid(inverse_sigmoid(prev) + delta)
+int kpt_out(const float* h, long ldh, const float* W, const float* b, const float* prev, float* out, int rows, int d,
+            hipStream_t st);
+
+}  // namespace ec

@@ -1,0 +1,602 @@
+// Non-GEMM kernels of the EdgeCape hot path for gfx950: HBM-bound normalisation / layout kernels
+// and the small per-sample graph kernels of the skeleton head.  64-wide waves throughout.
+#include "ec_ops.h"
+
+namespace ec {
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, float4 loads, values kept in registers (cols <= 1024).
+// Reference: DINOv2 norm1/norm2/norm (eps 1e-6), head LayerNorms (eps 1e-5, encoder_decoder.py:450-451,566-576).
+// ------------------------------------------------------------------------------------------------
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void layernorm_kernel(LnP p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  long orow = row;
+  if (p.drop_period > 0) {
+    const int n = row / p.drop_period, t = row % p.drop_period;
+    if (t == 0) return;
+    orow = (long)n * (p.drop_period - 1) + (t - 1);
+  }
+  const float* x = p.x + (long)row * p.ldx;
+  f32x4 v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < p.cols) {
+      v[i] = *(const f32x4*)(x + c);
+      s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+  }
+  const float mean = wave_sum(s) / (float)p.cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < p.cols) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)p.cols + p.eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < p.cols) {
+      const f32x4 w = *(const f32x4*)(p.w + c);
+      const f32x4 b = *(const f32x4*)(p.b + c);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * w[e] + b[e];
+      if (OUT_BF16) {
+        bf16_t* y = (bf16_t*)p.y + orow * p.ldy + c;
+        bf16x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (short)f2bf(o[e]);
+        *(bf16x4*)y = h;
+      } else {
+        *(f32x4*)((float*)p.y + orow * p.ldy + c) = o;
+      }
+    }
+  }
+}
+
+__global__ void add_table_kernel(float* x, long ldx, const float* table, long ldt, int period, int rows, int cols4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * cols4) return;
+  const int r = i / cols4, c = (i % cols4) * 4;
+  f32x4 a = *(f32x4*)(x + (long)r * ldx + c);
+  const f32x4 t = *(const f32x4*)(table + (long)(r % period) * ldt + c);
+  a += t;
+  *(f32x4*)(x + (long)r * ldx + c) = a;
+}
+
+__global__ void copy3d_kernel(float* dst, long ldd, long sd, const float* src, long lds, long ss, int rows, int cols4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * cols4) return;
+  const int b = blockIdx.y;
+  const int r = i / cols4, c = (i % cols4) * 4;
+  *(f32x4*)(dst + b * sd + (long)r * ldd + c) = *(const f32x4*)(src + b * ss + (long)r * lds + c);
+}
+
+__global__ void mean_over_kernel(float* dst, const float* src, long stride, int n, long count) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.f;
+  for (int k = 0; k < n; ++k) s += src[k * stride + i];
+  dst[i] = s / (float)n;
+}
+
+__global__ void f32_to_bf16_kernel(const float* src, bf16_t* dst, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = f2bf(src[i]);
+}
+
+// im2col for Conv2d(3, C, k=14, s=14) (DINOv2 PatchEmbed): patches[(n*g+py)*g+px][c*196+ky*14+kx],
+// row length Kp >= 588 (zero padded) so the GEMM K is a multiple of 128 bytes.
+template <bool OUT_BF16>
+__global__ void im2col14_kernel(const float* img, void* out, int H, int g, int Kp) {
+  const int patch = blockIdx.x;   // n*g*g + py*g + px
+  const int n = patch / (g * g), pp = patch % (g * g);
+  const int py = pp / g, px = pp % g;
+  const float* src = img + (long)n * 3 * H * H;
+  for (int k = threadIdx.x; k < Kp; k += blockDim.x) {
+    float v = 0.f;
+    if (k < 588) {
+      const int c = k / 196, r = k % 196, ky = r / 14, kx = r % 14;
+      v = src[((long)c * H + (py * 14 + ky)) * H + px * 14 + kx];
+    }
+    if (OUT_BF16) ((bf16_t*)out)[(long)patch * Kp + k] = f2bf(v);
+    else ((float*)out)[(long)patch * Kp + k] = v;
+  }
+}
+
+__global__ void set_cls_kernel(float* x, long ldx, const float* cls, const float* pos0, int T, int C) {
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) x[(long)n * T * ldx + c] = cls[c] + pos0[c];
+}
+
+// [n, C, HW] <-> [n, HW, C] via a 32x32 LDS tile
+__global__ void transpose_kernel(const float* src, float* dst, int R, int Cc) {
+  // src [n][R][Cc] -> dst [n][Cc][R]
+  __shared__ float t[32][33];
+  const int n = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    t[i][tx] = (r < R && c < Cc) ? src[((long)n * R + r) * Cc + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < Cc && r < R) dst[((long)n * Cc + c) * R + r] = t[tx][i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Support-keypoint pooling weights (head.py:175-184).  The reference upsamples the g x g feature
+// map to hm x hm bilinearly (align_corners=False) and takes a heatmap-weighted mean.  Bilinear
+// interpolation is linear, so  sum_p t[p] * interp(feat)[p] = sum_cell W[cell] * feat[cell]  with
+// W = (R_y^T t R_x) / (sum t + 1e-8): one block per (sample, keypoint) builds W separably in LDS;
+// a batched GEMM then contracts W with the features.  Works for arbitrary (dense) heatmaps.
+// ------------------------------------------------------------------------------------------------
+__device__ inline void bilinear_src(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
+  float s = scale * ((float)dst + 0.5f) - 0.5f;   // ATen area_pixel_compute_source_index, align_corners=False
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  i0 = i0 < in_size - 1 ? i0 : in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void pool_weights_kernel(const float* target, const float* mask_s, float inv_shots,
+                                                           float* Wp, int K, int hm, int g) {
+  extern __shared__ float sm[];
+  float* t = sm;                 // hm*hm
+  float* tmp = t + hm * hm;      // g*hm : tmp[cy][x]
+  float* red = tmp + g * hm;     // 4
+  const int bk = blockIdx.x;     // b*K + k
+  const int tid = threadIdx.x;
+  const float msk = mask_s[bk];
+  float* out = Wp + (long)bk * g * g;
+  const float* src = target + (long)bk * hm * hm;
+  float s = 0.f;
+  for (int i = tid; i < hm * hm; i += 256) {
+    const float v = src[i];
+    t[i] = v;
+    s += v;
+  }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  const float total = red[0] + red[1] + red[2] + red[3];
+  const float scale = (float)g / (float)hm;
+  for (int i = tid; i < g * hm; i += 256) tmp[i] = 0.f;
+  __syncthreads();
+  // tmp[cy][x] = sum_y wy(cy, y) t[y][x]   (thread per x column, serial over y: deterministic)
+  for (int x = tid; x < hm; x += 256) {
+    for (int y = 0; y < hm; ++y) {
+      int y0, y1; float ly;
+      bilinear_src(y, scale, g, y0, y1, ly);
+      const float v = t[y * hm + x];
+      tmp[y0 * hm + x] += (1.f - ly) * v;
+      tmp[y1 * hm + x] += ly * v;
+    }
+  }
+  __syncthreads();
+  const float norm = msk * inv_shots / (total + 1e-8f);
+  for (int cell = tid; cell < g * g; cell += 256) {
+    const int cy = cell / g, cx = cell % g;
+    float acc = 0.f;
+    for (int x = 0; x < hm; ++x) {
+      int x0, x1; float lx;
+      bilinear_src(x, scale, g, x0, x1, lx);
+      float w = 0.f;
+      if (x0 == cx) w += 1.f - lx;
+      if (x1 == cx) w += lx;
+      if (w != 0.f) acc += w * tmp[cy * hm + x];
+    }
+    out[cell] = acc * norm;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// adj_mx_from_edges + normalize_adj + (gt_adj > 0) + soft_normalize_adj  (skeleton.py:171-205,72,91)
+// one block per sample
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adj_build_kernel(const int32_t* edges, const int32_t* offsets, const float* mask_s,
+                                                        float* valid, uint8_t* kmask, uint8_t* kmask_fixed, float* binary,
+                                                        float* adj_r1, int K) {
+  extern __shared__ unsigned char flag[];   // K*K
+  __shared__ int nvalid;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) nvalid = 0;
+  for (int i = tid; i < K * K; i += 256) flag[i] = 0;
+  __syncthreads();
+  const int e0 = offsets[b], e1 = offsets[b + 1];
+  for (int e = e0 + tid; e < e1; e += 256) {
+    const int a = edges[2 * e], c = edges[2 * e + 1];
+    if (a >= 0 && a < K && c >= 0 && c < K) {
+      flag[a * K + c] = 1;
+      flag[c * K + a] = 1;
+    }
+  }
+  int cnt = 0;
+  for (int k = tid; k < K; k += 256) {
+    const bool v = mask_s[b * K + k] != 0.f;   // kp_mask = ~mask_s.bool() (head.py:189)
+    valid[b * K + k] = v ? 1.f : 0.f;
+    kmask[b * K + k] = v ? 0 : 1;
+    cnt += v ? 1 : 0;
+  }
+  if (cnt) atomicAdd(&nvalid, cnt);
+  __syncthreads();
+  for (int k = tid; k < K; k += 256) {
+    const bool v = mask_s[b * K + k] != 0.f;
+    // tgt_key_padding_mask_remove_all_true (skeleton.py:98-99): un-mask key 0 of all-padded samples
+    kmask_fixed[b * K + k] = (v || (nvalid == 0 && k == 0)) ? 0 : 1;
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int i = wave; i < K; i += 4) {
+    const bool vi = mask_s[b * K + i] != 0.f;
+    float rs = 0.f;
+    for (int j = lane; j < K; j += 64) {
+      const bool vj = mask_s[b * K + j] != 0.f;
+      rs += (vi && vj && flag[i * K + j]) ? 1.f : 0.f;
+    }
+    rs = wave_sum(rs);
+    for (int j = lane; j < K; j += 64) {
+      const bool vj = mask_s[b * K + j] != 0.f;
+      const float u = (vi && vj && flag[i * K + j]) ? 1.f : 0.f;
+      binary[((long)b * K + i) * K + j] = u;
+      adj_r1[((long)b * K + i) * K + j] = u / (rs + 1e-8f);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void rownorm_kernel(const float* x, float* y, int rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) {
+    const float v = x[(long)row * cols + c];
+    s += v * v;
+  }
+  const float inv = 1.f / (sqrtf(wave_sum(s)) + 1e-8f);   // skeleton.py:137
+  for (int c = lane; c < cols; c += 64) y[(long)row * cols + c] = x[(long)row * cols + c] * inv;
+}
+
+// predict_skeleton tail + markov normalisation (skeleton.py:139-150,158): one block per sample
+__global__ __launch_bounds__(256) void adj_combine_kernel(const float* P, const float* binary, const float* valid,
+                                                          const float* zc_w, const float* zc_b, float* adj_out, float* adj1,
+                                                          float* attn_adj, int bs, int K) {
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float w = zc_w[0], c0 = zc_b[0];
+  const float* Pb = P + (long)b * K * K;
+  const float* Bb = binary + (long)b * K * K;
+  float* a0 = adj_out + (long)b * 2 * K * K;
+  float* a1 = a0 + (long)K * K;
+  float* i0 = attn_adj + (long)b * K * K;                       // hop 0 = I
+  float* m1 = attn_adj + ((long)bs + b) * K * K;                // hop 1 = A
+  float* A1 = adj1 + (long)b * K * K;
+  for (int i = wave; i < K; i += 4) {
+    const float vi = valid[b * K + i];
+    float u[2], rs = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int j = lane + t * 64;
+      u[t] = 0.f;
+      if (j < K) {
+        const float sym = (Pb[i * K + j] + Pb[j * K + i]) / 2.f;
+        float v = Bb[i * K + j] + (sym * w + c0);
+        v = fmaxf(v, 0.f);
+        u[t] = v * (vi * valid[b * K + j]);
+        rs += u[t];
+      }
+    }
+    rs = wave_sum(rs);
+    float rs2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      u[t] = u[t] / (rs + 1e-8f);
+      rs2 += u[t];
+    }
+    rs2 = wave_sum(rs2);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int j = lane + t * 64;
+      if (j < K) {
+        a0[i * K + j] = (i == j) ? vi : 0.f;
+        a1[i * K + j] = u[t];
+        A1[i * K + j] = u[t];
+        i0[i * K + j] = (i == j) ? 1.f : 0.f;
+        m1[i * K + j] = u[t] / (rs2 + 1e-8f);
+      }
+    }
+  }
+}
+
+__global__ void bias_mlp_kernel(const float* attn_adj, const float* w1, const float* b1, const float* w2, const float* b2,
+                                float* out, int hops1, int hidden, int nhead, int bs, int K) {
+  extern __shared__ float wsm[];
+  float* sw1 = wsm;                       // hidden*hops1
+  float* sb1 = sw1 + hidden * hops1;
+  float* sw2 = sb1 + hidden;              // nhead*hidden
+  float* sb2 = sw2 + nhead * hidden;
+  for (int i = threadIdx.x; i < hidden * hops1; i += blockDim.x) sw1[i] = w1[i];
+  for (int i = threadIdx.x; i < hidden; i += blockDim.x) sb1[i] = b1[i];
+  for (int i = threadIdx.x; i < nhead * hidden; i += blockDim.x) sw2[i] = w2[i];
+  for (int i = threadIdx.x; i < nhead; i += blockDim.x) sb2[i] = b2[i];
+  __syncthreads();
+  const long KK = (long)K * K;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= bs * KK) return;
+  const int b = idx / KK;
+  const long ij = idx % KK;
+  float a[8], hdn[16];
+  for (int d = 0; d < hops1; ++d) a[d] = attn_adj[((long)d * bs + b) * KK + ij];
+  for (int o = 0; o < hidden; ++o) {
+    float s = sb1[o];
+    for (int d = 0; d < hops1; ++d) s += sw1[o * hops1 + d] * a[d];
+    hdn[o] = fmaxf(s, 0.f);
+  }
+  for (int hh = 0; hh < nhead; ++hh) {
+    float s = sb2[hh];
+    for (int o = 0; o < hidden; ++o) s += sw2[hh * hidden + o] * hdn[o];
+    out[((long)b * nhead + hh) * KK + ij] = s;
+  }
+}
+
+// ProposalGenerator tail (encoder_decoder.py:76-112): one wave per (sample, keypoint) row of the similarity map
+__global__ __launch_bounds__(256) void proposals_kernel(const float* sim, float* prop_loss, float* prop, int rows, int g) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int HW = g * g;
+  const float* s = sim + (long)row * HW;
+  constexpr int MAXC = 16;  // g <= 32
+  float v[MAXC];
+  float mx = -INFINITY;
+  int am = 0x7fffffff;
+#pragma unroll
+  for (int t = 0; t < MAXC; ++t) {
+    const int p = lane + t * 64;
+    v[t] = p < HW ? s[p] : -INFINITY;
+    if (v[t] > mx) { mx = v[t]; am = p; }
+  }
+  // wave arg-max, first index on ties (torch.argmax)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(mx, o, 64);
+    const int oi = __shfl_xor(am, o, 64);
+    if (ov > mx || (ov == mx && oi < am)) { mx = ov; am = oi; }
+  }
+  float se = 0.f;
+#pragma unroll
+  for (int t = 0; t < MAXC; ++t) {
+    const int p = lane + t * 64;
+    v[t] = p < HW ? expf(v[t] - mx) : 0.f;
+    se += v[t];
+  }
+  se = wave_sum(se);
+  // the reference reshapes the one-hot to (w, h) before the 3x3 max-pool (:93); for square maps this is the
+  // natural (row, col) = (p / g, p % g)
+  const int ar = am / g, ac = am % g;
+  float sx = 0.f, sy = 0.f, lx = 0.f, ly = 0.f, ls = 0.f;
+#pragma unroll
+  for (int t = 0; t < MAXC; ++t) {
+    const int p = lane + t * 64;
+    if (p < HW) {
+      const float pr = v[t] / se;
+      const int r = p / g, c = p % g;
+      const float gx = (float)c + 0.5f, gy = (float)r + 0.5f;
+      sx += pr * gx;
+      sy += pr * gy;
+      const int dr = r - ar, dc = c - ac;
+      if (dr >= -1 && dr <= 1 && dc >= -1 && dc <= 1) {
+        ls += pr;
+        lx += pr * gx;
+        ly += pr * gy;
+      }
+    }
+  }
+  sx = wave_sum(sx); sy = wave_sum(sy); lx = wave_sum(lx); ly = wave_sum(ly); ls = wave_sum(ls);
+  if (lane == 0) {
+    prop_loss[row * 2 + 0] = sx / (float)g;
+    prop_loss[row * 2 + 1] = sy / (float)g;
+    const float d = ls + 1e-10f;
+    prop[row * 2 + 0] = (lx / d) / (float)g;
+    prop[row * 2 + 1] = (ly / d) / (float)g;
+  }
+}
+
+// SinePositionalEncoding.forward_coordinates (positional_encoding.py:96-122): out = cat(pos_y, pos_x)
+__global__ void sincos_kernel(const float* coords, const float* dim_t, float* out, long ldo, int rows, int nf) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)rows * 2 * nf) return;
+  const int row = idx / (2 * nf), c = idx % (2 * nf);
+  const int isx = c >= nf;            // first nf features come from y
+  const int i = isx ? c - nf : c;
+  const float e = coords[row * 2 + (isx ? 0 : 1)] * 6.283185307179586f;
+  const float a = e / dim_t[i];
+  out[(long)row * ldo + c] = (i & 1) ? cosf(a) : sinf(a);
+}
+
+__device__ inline float inv_sigmoid(float x) {   // head.py:27-31, eps 1e-3
+  x = fminf(fmaxf(x, 0.f), 1.f);
+  const float x1 = fmaxf(x, 1e-3f), x2 = fmaxf(1.f - x, 1e-3f);
+  return logf(x1 / x2);
+}
+
+__global__ __launch_bounds__(256) void kpt_out_kernel(const float* h, long ldh, const float* W, const float* b,
+                                                      const float* prev, float* out, int rows, int d) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int c = lane; c < d; c += 64) {
+    const float v = h[(long)row * ldh + c];
+    s0 += v * W[c];
+    s1 += v * W[d + c];
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  if (lane < 2) {
+    const float dl = (lane == 0 ? s0 : s1) + b[lane];
+    const float z = dl + inv_sigmoid(prev[row * 2 + lane]);
+    out[row * 2 + lane] = 1.f / (1.f + expf(-z));
+  }
+}
+
+__global__ void set_identity_kernel(float* dst, int K) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < K * K) dst[(long)b * K * K + i] = (i / K == i % K) ? 1.f : 0.f;
+}
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace
+
+int layernorm(const LnP& p, hipStream_t st) {
+  EC_REQUIRE(p.cols % 4 == 0 && p.cols <= 1024, -1, "layernorm: cols must be a multiple of 4 and <= 1024");
+  EC_REQUIRE(p.ldx % 4 == 0 && p.ldy % 4 == 0, -1, "layernorm: strides must be multiples of 4");
+  if (p.y_bf16) hipLaunchKernelGGL(layernorm_kernel<true>, dim3(cdiv(p.rows, 4)), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(layernorm_kernel<false>, dim3(cdiv(p.rows, 4)), dim3(256), 0, st, p);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int add_table(float* x, long ldx, const float* table, long ldt, int period, int rows, int cols, hipStream_t st) {
+  EC_REQUIRE(cols % 4 == 0 && ldx % 4 == 0 && ldt % 4 == 0, -1, "add_table: cols/strides must be multiples of 4");
+  hipLaunchKernelGGL(add_table_kernel, dim3(cdiv((long)rows * cols / 4, 256)), dim3(256), 0, st, x, ldx, table, ldt, period,
+                     rows, cols / 4);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int copy3d(float* dst, long ldd, long sd, const float* src, long lds, long ss, int batch, int rows, int cols, hipStream_t st) {
+  EC_REQUIRE(cols % 4 == 0 && ldd % 4 == 0 && lds % 4 == 0 && sd % 4 == 0 && ss % 4 == 0, -1, "copy3d: alignment");
+  hipLaunchKernelGGL(copy3d_kernel, dim3(cdiv((long)rows * cols / 4, 256), batch), dim3(256), 0, st, dst, ldd, sd, src, lds, ss,
+                     rows, cols / 4);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int copy2d(float* dst, long ldd, const float* src, long lds, int rows, int cols, hipStream_t st) {
+  return copy3d(dst, ldd, 0, src, lds, 0, 1, rows, cols, st);
+}
+
+int mean_over(float* dst, const float* src, long stride, int n, long count, hipStream_t st) {
+  hipLaunchKernelGGL(mean_over_kernel, dim3(cdiv(count, 256)), dim3(256), 0, st, dst, src, stride, n, count);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t st) {
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, src, dst, n);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int im2col14(const float* img, void* patches, int out_bf16, int n_img, int H, int g, int Kp, hipStream_t st) {
+  if (out_bf16) hipLaunchKernelGGL(im2col14_kernel<true>, dim3(n_img * g * g), dim3(256), 0, st, img, patches, H, g, Kp);
+  else hipLaunchKernelGGL(im2col14_kernel<false>, dim3(n_img * g * g), dim3(256), 0, st, img, patches, H, g, Kp);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int set_cls_rows(float* x, long ldx, const float* cls, const float* pos0, int n_img, int T, int C, hipStream_t st) {
+  hipLaunchKernelGGL(set_cls_kernel, dim3(n_img), dim3(256), 0, st, x, ldx, cls, pos0, T, C);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int nchw_to_tokens(const float* src, float* dst, int n, int C, int HW, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), n), dim3(256), 0, st, src, dst, C, HW);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+int tokens_to_nchw(const float* src, float* dst, int n, int C, int HW, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 32), cdiv(HW, 32), n), dim3(256), 0, st, src, dst, HW, C);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int pool_weights(const float* target, const float* mask_s, float inv_shots, float* Wp, int bs, int K, int hm, int g,
+                 hipStream_t st) {
+  const size_t lds = (size_t)(hm * hm + g * hm + 4) * sizeof(float);
+  EC_REQUIRE(lds <= 64 * 1024, -1, "pool_weights: heatmap too large for LDS");
+  hipLaunchKernelGGL(pool_weights_kernel, dim3(bs * K), dim3(256), lds, st, target, mask_s, inv_shots, Wp, K, hm, g);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int adj_build(const int32_t* edges, const int32_t* offsets, const float* mask_s, float* valid, uint8_t* kmask,
+              uint8_t* kmask_fixed, float* binary, float* adj_r1, int bs, int K, hipStream_t st) {
+  EC_REQUIRE(K * K <= 64 * 1024, -1, "adj_build: K too large");
+  hipLaunchKernelGGL(adj_build_kernel, dim3(bs), dim3(256), (size_t)K * K, st, edges, offsets, mask_s, valid, kmask, kmask_fixed,
+                     binary, adj_r1, K);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int rownorm(const float* x, float* y, int rows, int cols, hipStream_t st) {
+  hipLaunchKernelGGL(rownorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, y, rows, cols);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int adj_combine(const float* P, const float* binary, const float* valid, const float* zc_w, const float* zc_b, float* adj_out,
+                float* adj1, float* attn_adj, int bs, int K, hipStream_t st) {
+  EC_REQUIRE(K <= 128, -1, "adj_combine: K must be <= 128");
+  hipLaunchKernelGGL(adj_combine_kernel, dim3(bs), dim3(256), 0, st, P, binary, valid, zc_w, zc_b, adj_out, adj1, attn_adj, bs, K);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int set_identity(float* dst, int bs, int K, hipStream_t st) {
+  hipLaunchKernelGGL(set_identity_kernel, dim3(cdiv(K * K, 256), bs), dim3(256), 0, st, dst, K);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int bias_mlp(const float* attn_adj, const float* w1, const float* b1, const float* w2, const float* b2, float* out, int hops1,
+             int hidden, int nhead, int bs, int K, hipStream_t st) {
+  EC_REQUIRE(hops1 <= 8 && hidden <= 16, -1, "bias_mlp: unsupported MLP size");
+  const size_t lds = (size_t)(hidden * hops1 + hidden + nhead * hidden + nhead) * sizeof(float);
+  hipLaunchKernelGGL(bias_mlp_kernel, dim3(cdiv((long)bs * K * K, 256)), dim3(256), lds, st, attn_adj, w1, b1, w2, b2, out, hops1,
+                     hidden, nhead, bs, K);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int proposals(const float* sim, float* prop_loss, float* prop, int rows, int g, hipStream_t st) {
+  EC_REQUIRE(g * g <= 16 * 64, -1, "proposals: grid too large");
+  hipLaunchKernelGGL(proposals_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, sim, prop_loss, prop, rows, g);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int sincos_coords(const float* coords, const float* dim_t, float* out, long ldo, int rows, int num_feats, hipStream_t st) {
+  hipLaunchKernelGGL(sincos_kernel, dim3(cdiv((long)rows * 2 * num_feats, 256)), dim3(256), 0, st, coords, dim_t, out, ldo, rows,
+                     num_feats);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int kpt_out(const float* h, long ldh, const float* W, const float* b, const float* prev, float* out, int rows, int d,
+            hipStream_t st) {
+  hipLaunchKernelGGL(kpt_out_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, h, ldh, W, b, prev, out, rows, d);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace ec

@@ -1,0 +1,197 @@
+"""HipEngine: one ec_handle (include/edgecape_hip.h) = weights + workspace for one
+(backbone arch, image size, max batch, max shots, precision).  Thin plumbing around the C ABI:
+torch is used only to own device buffers and the stream; no torch op computes anything here.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .posembed import interpolate_pos_embed
+from .synth import ARCHS, PATCH
+
+_TORCH_DT = {torch.float32: _lib.EC_DT_F32, torch.float16: _lib.EC_DT_F16, torch.bfloat16: _lib.EC_DT_BF16,
+             torch.float64: _lib.EC_DT_F64}
+_NP_DT = {np.dtype("float32"): _lib.EC_DT_F32, np.dtype("float16"): _lib.EC_DT_F16, np.dtype("float64"): _lib.EC_DT_F64}
+
+
+def _host_array(v):
+    """state-dict value (numpy / torch, any float dtype) -> (contiguous host buffer keeper, ptr, shape, dtype code)."""
+    if isinstance(v, torch.Tensor):
+        t = v.detach().cpu().contiguous()
+        if t.dtype not in _TORCH_DT:
+            t = t.float()
+        return t, t.data_ptr(), tuple(t.shape), _TORCH_DT[t.dtype]
+    a = np.ascontiguousarray(v)
+    if a.dtype not in _NP_DT:
+        a = a.astype(np.float32)
+    return a, a.ctypes.data, tuple(a.shape), _NP_DT[a.dtype]
+
+
+def normalize_state_dict(sd):
+    """Reference checkpoint key handling (test.py:124, EdgeCape.py:36, bias_attn.py:236-265):
+    strip an outer 'state_dict', map encoder_sample.* onto encoder_query.* (same module twice), and split a
+    fused decoder self_attn.in_proj_{weight,bias} (stage-2 checkpoints) into q/k/v_proj."""
+    if "state_dict" in sd and isinstance(sd["state_dict"], dict):
+        sd = sd["state_dict"]
+    out = {}
+    for k, v in sd.items():
+        if k.startswith("encoder_sample."):
+            k2 = "encoder_query." + k[len("encoder_sample."):]
+            if k2 in sd:
+                continue
+            k = k2
+        out[k] = v
+    for k in list(out.keys()):
+        if ".transformer.decoder.layers." in k and k.endswith("self_attn.in_proj_weight"):
+            p = k[: -len("in_proj_weight")]
+            w = out.pop(k)
+            w = w.detach().cpu().numpy() if isinstance(w, torch.Tensor) else np.asarray(w)
+            dd = w.shape[0] // 3
+            for i, n in enumerate(("q_proj", "k_proj", "v_proj")):
+                out[p + n + ".weight"] = w[i * dd:(i + 1) * dd]
+            if p + "in_proj_bias" in out:
+                b = out.pop(p + "in_proj_bias")
+                b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+                for i, n in enumerate(("q_proj", "k_proj", "v_proj")):
+                    out[p + n + ".bias"] = b[i * dd:(i + 1) * dd]
+    return out
+
+
+class HipEngine:
+    def __init__(self, state_dict, arch="dinov2_vits14", image_size=224, max_batch=2, max_shots=1, num_kpts=100,
+                 ffn_dim=384, skel_ffn_dim=None, backbone_precision="fp32", head_precision="fp32", heatmap_size=64,
+                 d_model=256, nhead=8, enc_layers=3, dec_layers=3, skel_layers=3, max_hops=4):
+        if not torch.cuda.is_available():
+            raise _lib.EdgeCapeHipError("no MI355X / HIP device visible: the EdgeCape hot path has no CPU fallback")
+        self.lib = _lib.load()
+        a = ARCHS[arch]
+        self.arch, self.C, self.image_size = arch, a["C"], image_size
+        self.g = image_size // PATCH
+        self.HW = self.g * self.g
+        self.K, self.max_batch, self.max_shots = num_kpts, max_batch, max_shots
+        self.dec_layers, self.max_hops = dec_layers, max_hops
+        prec = {"fp32": _lib.EC_F32, "bf16": _lib.EC_BF16}
+        cfg = _lib.EcConfig(embed_dim=a["C"], depth=a["depth"], num_heads=a["heads"], image_size=image_size, patch=PATCH,
+                            num_kpts=num_kpts, d_model=d_model, nhead=nhead, enc_layers=enc_layers, dec_layers=dec_layers,
+                            skel_layers=skel_layers, ffn_dim=ffn_dim, skel_ffn_dim=skel_ffn_dim or a["C"], max_hops=max_hops,
+                            heatmap_size=heatmap_size, max_shots=max_shots, max_batch=max_batch,
+                            backbone_precision=prec[backbone_precision], head_precision=prec[head_precision])
+        self.backbone_precision, self.head_precision = backbone_precision, head_precision
+        h = C.c_void_p()
+        _lib.check(self.lib.ec_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        sd = normalize_state_dict(state_dict)
+        pos = None
+        for name, v in sd.items():
+            if not (name.startswith("encoder_query.") or name.startswith("keypoint_head_module.")):
+                continue
+            if name == "encoder_query.pos_embed":
+                pv = v.detach().cpu().float().numpy() if isinstance(v, torch.Tensor) else np.asarray(v, np.float32)
+                pos = interpolate_pos_embed(pv, self.g)
+                continue
+            keep, ptr, shape, dt = _host_array(v)
+            shp = (C.c_int64 * len(shape))(*shape)
+            _lib.check(self.lib.ec_load_tensor(self.h, name.encode(), C.c_void_p(ptr), shp, len(shape), dt))
+        if pos is None:
+            raise KeyError("state dict has no encoder_query.pos_embed")
+        pos = np.ascontiguousarray(pos, np.float32)
+        _lib.check(self.lib.ec_set_pos_embed(self.h, C.c_void_p(pos.ctypes.data), pos.shape[0], pos.shape[1]))
+        _lib.check(self.lib.ec_finalize(self.h))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.ec_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- helpers ---------------------------------------------------------------------------------
+    @staticmethod
+    def _dev(x):
+        t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+        return t.to(device="cuda", dtype=torch.float32).contiguous()
+
+    @staticmethod
+    def _edges(skeletons, bs):
+        flat, off = [], [0]
+        for b in range(bs):
+            e = np.asarray(skeletons[b], np.int64)
+            if e.ndim == 2 and e.shape[0] > 0:   # skeleton.py:177 — an empty list contributes no edges
+                flat.append(e.reshape(-1, 2))
+                off.append(off[-1] + e.shape[0])
+            else:
+                off.append(off[-1])
+        edges = np.ascontiguousarray(np.concatenate(flat, 0) if flat else np.zeros((0, 2)), np.int32)
+        return edges, np.asarray(off, np.int32)
+
+    def _outputs(self, bs):
+        dev = "cuda"
+        o = dict(output_kpts=torch.empty(self.dec_layers, bs, self.K, 2, device=dev),
+                 initial_proposals=torch.empty(bs, self.K, 2, device=dev),
+                 similarity_map=torch.empty(bs, self.K, self.g, self.g, device=dev),
+                 adj=torch.empty(bs, 2, self.K, self.K, device=dev),
+                 attn_adj=torch.empty(self.max_hops + 1, bs, self.K, self.K, device=dev),
+                 out_points=torch.empty(self.dec_layers + 1, bs, self.K, 2, device=dev))
+        eo = _lib.EcOutputs(o["output_kpts"].data_ptr(), o["initial_proposals"].data_ptr(), o["similarity_map"].data_ptr(),
+                            o["adj"].data_ptr(), o["attn_adj"].data_ptr(), o["out_points"].data_ptr())
+        return o, eo
+
+    @staticmethod
+    def _ptr_array(tensors):
+        return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+    # ---- entry points ----------------------------------------------------------------------------
+    def backbone(self, img, nchw=True):
+        """EdgeCape.extract_features for one image batch -> [n,C,g,g] (or [n,HW,C] tokens)."""
+        img = self._dev(img)
+        n = img.shape[0]
+        out = torch.empty((n, self.C, self.g, self.g) if nchw else (n, self.HW, self.C), device="cuda")
+        _lib.check(self.lib.ec_backbone(self.h, img.data_ptr(), n, out.data_ptr(),
+                                        _lib.EC_LAYOUT_NCHW if nchw else _lib.EC_LAYOUT_TOKENS, _lib.current_stream()))
+        return out
+
+    def head(self, feature_q, feature_s, target_s, mask_s, skeletons):
+        """TwoStageHead.forward on NCHW features (the reference's layout)."""
+        fq = self._dev(feature_q)
+        fs = [self._dev(f) for f in feature_s]
+        ts = [self._dev(t) for t in target_s]
+        ms = self._dev(mask_s).reshape(fq.shape[0], self.K)
+        bs, S = fq.shape[0], len(fs)
+        edges, off = self._edges(skeletons, bs)
+        o, eo = self._outputs(bs)
+        _lib.check(self.lib.ec_head(self.h, fq.data_ptr(), self._ptr_array(fs), _lib.EC_LAYOUT_NCHW, self._ptr_array(ts),
+                                    ms.data_ptr(), edges.ctypes.data, off.ctypes.data, bs, S, _lib.current_stream(),
+                                    C.byref(eo)))
+        return o
+
+    def forward(self, img_q, img_s, target_s, mask_s, skeletons):
+        """Device part of EdgeCape.predict: backbone on query + supports, then the head. Asynchronous."""
+        iq = self._dev(img_q)
+        is_ = [self._dev(x) for x in img_s]
+        ts = [self._dev(t) for t in target_s]
+        bs, S = iq.shape[0], len(is_)
+        ms = self._dev(mask_s).reshape(bs, self.K)
+        edges, off = self._edges(skeletons, bs)
+        o, eo = self._outputs(bs)
+        _lib.check(self.lib.ec_forward(self.h, iq.data_ptr(), self._ptr_array(is_), self._ptr_array(ts), ms.data_ptr(),
+                                       edges.ctypes.data, off.ctypes.data, bs, S, _lib.current_stream(), C.byref(eo)))
+        o["_keep"] = (iq, is_, ts, ms)
+        return o
+
+    def forward_resident(self, iq, is_, ts, ms, edges, off, outputs):
+        """Same as forward() on tensors already resident in HBM and pre-packed edges (bench timed region)."""
+        o, eo = outputs
+        _lib.check(self.lib.ec_forward(self.h, iq.data_ptr(), self._ptr_array(is_), self._ptr_array(ts), ms.data_ptr(),
+                                       edges.ctypes.data, off.ctypes.data, iq.shape[0], len(is_), _lib.current_stream(),
+                                       C.byref(eo)))
+        return o
+
+    def debug(self, name):
+        n = C.c_int64()
+        _lib.check(self.lib.ec_debug_read(self.h, name.encode(), None, 0, C.byref(n)))
+        buf = np.empty(n.value, np.float32)
+        _lib.check(self.lib.ec_debug_read(self.h, name.encode(), buf.ctypes.data, n.value, C.byref(n)))
+        return buf

@@ -1,0 +1,135 @@
+/*
+ * edgecape_hip.h — C ABI of libedgecape_hip.so: the MI355X (gfx950) implementation of the
+ * EdgeCape inference hot path (reference: orhir/EdgeCape `EdgeCape.forward_test`).
+ *
+ * The reference is pure Python/PyTorch and has NO FFI boundary; this header is the
+ * boundary the build introduces.  Each entry point names the reference interface it stands in for:
+ *
+ *   ec_create / ec_load_tensor / ec_finalize
+ *       EdgeCape.__init__ + mmcv load_checkpoint      EdgeCape/models/detectors/EdgeCape.py:28-45, test.py:120-124
+ *       tensor names = the reference's state_dict keys (encoder_query.* = upstream dinov2 names,
+ *       keypoint_head_module.* = SURVEY Appendix B)
+ *   ec_backbone       EdgeCape.extract_features       EdgeCape.py:186-191  (dinov2 get_intermediate_layers(n=1, reshape=True))
+ *   ec_head           TwoStageHead.forward            EdgeCape/models/keypoint_heads/head.py:161-222
+ *                     (+ SkeletonPredictor.forward    keypoint_heads/skeleton.py:58-161,
+ *                        TwoStageSupportRefineTransformer.forward  keypoint_heads/encoder_decoder.py:183-260)
+ *   ec_forward        EdgeCape.predict                EdgeCape.py:165-184 (backbone x(1+S) + head), device-side part of forward_test
+ *   ec_op_*           single fused ops, exported for the parity tests (each vs a torch fp32 reference)
+ *
+ * Conventions
+ *   - plain C types only; every pointer named *_dev is DEVICE memory owned by the caller
+ *     (e.g. torch tensor .data_ptr()); weights/workspace are owned by the library.
+ *   - return 0 on success, negative ec_status on failure; ec_last_error() gives the text.
+ *     No exceptions cross the ABI.  No hidden synchronisation: work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the legacy default stream).
+ *   - a handle is not thread-safe; use one handle per stream.
+ *   - layouts: images NCHW fp32; heatmaps [bs,K,hm,hm] fp32; features token-major [n,HW,C] fp32
+ *     (EC_LAYOUT_TOKENS) or the reference's NCHW (EC_LAYOUT_NCHW).
+ */
+#ifndef EDGECAPE_HIP_H
+#define EDGECAPE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ec_model* ec_handle;
+
+enum ec_status {
+  EC_OK = 0,
+  EC_ERR_ARG = -1,       /* bad argument / shape */
+  EC_ERR_HIP = -2,       /* HIP runtime error */
+  EC_ERR_STATE = -3,     /* call order (e.g. forward before finalize), missing tensor */
+  EC_ERR_NAME = -4,      /* unknown tensor name */
+  EC_ERR_NODEVICE = -5   /* no gfx950 device visible */
+};
+
+enum ec_precision { EC_F32 = 0, EC_BF16 = 1 };
+enum ec_dtype { EC_DT_F32 = 0, EC_DT_F16 = 1, EC_DT_BF16 = 2, EC_DT_F64 = 3 };
+enum ec_layout { EC_LAYOUT_TOKENS = 0, EC_LAYOUT_NCHW = 1 };
+
+typedef struct ec_config {
+  int32_t embed_dim;          /* backbone width C: 384 / 768 / 1024 */
+  int32_t depth;              /* 12 / 24 */
+  int32_t num_heads;          /* C / 64 */
+  int32_t image_size;         /* square input, e.g. 224 / 256 / 384; grid g = image_size / patch (floor) */
+  int32_t patch;              /* 14 */
+  int32_t num_kpts;           /* K = 100 (configs/test/1shot_split1.py:31) */
+  int32_t d_model;            /* 256 */
+  int32_t nhead;              /* 8 */
+  int32_t enc_layers;         /* 3 */
+  int32_t dec_layers;         /* 3 */
+  int32_t skel_layers;        /* 3 */
+  int32_t ffn_dim;            /* transformer dim_feedforward F_d = 384 */
+  int32_t skel_ffn_dim;       /* SkeletonPredictor dim_feedforward F_s (= embed_dim) */
+  int32_t max_hops;           /* 4 */
+  int32_t heatmap_size;       /* 64 */
+  int32_t max_shots;          /* S_max */
+  int32_t max_batch;          /* bs_max (pairs per call) */
+  int32_t backbone_precision; /* ec_precision: operand type of the backbone MFMA GEMMs/attention (fp32 accumulate always) */
+  int32_t head_precision;     /* ec_precision for the head */
+} ec_config;
+
+typedef struct ec_outputs {
+  float* output_kpts_dev;        /* [dec_layers, bs, K, 2]   head.py:222 */
+  float* initial_proposals_dev;  /* [bs, K, 2]               encoder_decoder.py:87-89 (proposal_for_loss) */
+  float* similarity_map_dev;     /* [bs, K, g, g]            encoder_decoder.py:75 */
+  float* adj_dev;                /* [bs, 2, K, K]            skeleton.py:142 */
+  float* attn_adj_dev;           /* optional (may be NULL): [max_hops+1, bs, K, K]  skeleton.py:152-161 */
+  float* out_points_dev;         /* optional (may be NULL): [dec_layers+1, bs, K, 2] encoder_decoder.py:357,403 */
+} ec_outputs;
+
+const char* ec_last_error(void);
+int ec_version(void);
+
+int ec_create(const ec_config* cfg, ec_handle* out);
+int ec_destroy(ec_handle h);
+
+/* Copy one host tensor into the model. `name` is the reference state_dict key. */
+int ec_load_tensor(ec_handle h, const char* name, const void* host_ptr, const int64_t* shape, int ndim, int dtype);
+/* Positional table for the backbone, ALREADY interpolated to [1+g*g, C] fp32 (host). */
+int ec_set_pos_embed(ec_handle h, const float* host_table, int64_t rows, int64_t cols);
+/* Check completeness, build derived tables (folded projections, sine tables, bf16 copies). */
+int ec_finalize(ec_handle h);
+
+/* n_img images [n_img,3,H,W] fp32 -> features [n_img,HW,C] (tokens) or [n_img,C,g,g] (NCHW). */
+int ec_backbone(ec_handle h, const float* img_dev, int n_img, float* feat_dev, int layout, void* stream);
+
+/* Head on given features. feature_s_dev/target_s_dev: arrays (host) of S device pointers.
+ * mask_s_dev [bs,K] fp32 (product of target weights, EdgeCape.py:175-177).
+ * edges: host int32 pairs (0-based, < K), edge_offsets: host int32 [bs+1] offsets in PAIRS. */
+int ec_head(ec_handle h, const float* feature_q_dev, const float* const* feature_s_dev, int layout,
+            const float* const* target_s_dev, const float* mask_s_dev, const int32_t* edges,
+            const int32_t* edge_offsets, int bs, int S, void* stream, const ec_outputs* out);
+
+/* Whole device-side forward_test: backbone on query + S supports, then the head. */
+int ec_forward(ec_handle h, const float* img_q_dev, const float* const* img_s_dev,
+               const float* const* target_s_dev, const float* mask_s_dev, const int32_t* edges,
+               const int32_t* edge_offsets, int bs, int S, void* stream, const ec_outputs* out);
+
+/* Copy a named intermediate of the LAST forward/head call to a host fp32 buffer (tests only; synchronises). */
+int ec_debug_read(ec_handle h, const char* name, float* host_out, int64_t max_elems, int64_t* n_elems);
+
+/* ---- single ops (parity tests / microbenchmarks) -------------------------------------------- */
+/* C[M,N] = epilogue(A[M,K] @ W[N,K]^T): precision EC_F32 -> fp32 operands, EC_BF16 -> operands are
+ * rounded to bf16 on device first.  act: 0 none, 1 relu, 2 gelu(erf).  bias/gamma/resid may be NULL. */
+int ec_op_linear(const float* A_dev, const float* W_dev, const float* bias_dev, const float* gamma_dev,
+                 const float* resid_dev, float* C_dev, int M, int N, int K, int act, int precision, void* stream);
+/* Same GEMM on operands already in the precision's storage type (bf16 as uint16_t bit patterns), repeated
+ * `iters` times; returns mean kernel time in ms via *ms (HIP events on `stream`).  Used by bench.py roofline. */
+int ec_op_gemm_bench(const void* A_dev, const void* W_dev, const float* bias_dev, void* C_dev, int M, int N, int K,
+                     int precision, int iters, void* stream, float* ms);
+int ec_op_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev, int rows, int cols,
+                    float eps, void* stream);
+/* softmax(q k^T * hd^-0.5 + bias, key mask) v ; q [B,Lq,H*hd], k,v [B,Lk,H*hd]; kmask [B,Lk] uint8 (1 = masked) or NULL;
+ * bias [B,H,Lq,Lk] or NULL. */
+int ec_op_attention(const float* q_dev, const float* k_dev, const float* v_dev, const uint8_t* kmask_dev,
+                    const float* bias_dev, float* o_dev, int B, int H, int Lq, int Lk, int hd, int precision,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDGECAPE_HIP_H */

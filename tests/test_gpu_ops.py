@@ -1,0 +1,126 @@
+"""-m gpu: each HIP kernel exported through the C ABI vs a plain PyTorch fp32 reference of the same op."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from edgecape_amd import _lib
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return _lib.load()
+
+
+def _chk(lib, rc):
+    assert rc == 0, lib.ec_last_error().decode()
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 256, 256), (1000, 384, 640), (325 * 2, 1152, 384), (77, 128, 128)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear_fp32(lib, M, N, K, act):
+    g = torch.Generator().manual_seed(M + N + K + act)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5   # asymmetric operands: catches transposed C writes
+    b = torch.randn(N, generator=g)
+    gam = torch.rand(N, generator=g) + 0.5
+    R = torch.randn(M, N, generator=g)
+    ref = A.double() @ W.double().T + b.double()
+    ref = {0: ref, 1: ref.relu(), 2: torch.nn.functional.gelu(ref)}[act]
+    ref = (ref * gam.double() + R.double()).float()
+    Ad, Wd, bd, gd, Rd = (x.cuda() for x in (A, W, b, gam, R))
+    Cd = torch.empty(M, N, device="cuda")
+    _chk(lib, lib.ec_op_linear(_p(Ad), _p(Wd), _p(bd), _p(gd), _p(Rd), _p(Cd), M, N, K, act, 0, None))
+    torch.cuda.synchronize()
+    err = (Cd.cpu() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+def test_linear_identity_layout(lib):
+    """A = I with an asymmetric W: C must equal W^T exactly (transpose-detecting)."""
+    N = K = 128
+    A = torch.eye(K).cuda()
+    W = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251).cuda()
+    Cd = torch.empty(K, N, device="cuda")
+    _chk(lib, lib.ec_op_linear(_p(A), _p(W), None, None, None, _p(Cd), K, N, K, 0, 0, None))
+    torch.cuda.synchronize()
+    assert torch.equal(Cd, W.T)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (650, 1152, 384), (1000, 768, 3072)])
+def test_linear_bf16(lib, M, N, K):
+    g = torch.Generator().manual_seed(1)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    ref = (A.bfloat16().double() @ W.bfloat16().double().T + b.double()).float()  # exact products of bf16 operands
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
+    Cd = torch.empty(M, N, device="cuda")
+    _chk(lib, lib.ec_op_linear(_p(Ad), _p(Wd), _p(bd), None, None, _p(Cd), M, N, K, 0, 1, None))
+    torch.cuda.synchronize()
+    err = (Cd.cpu() - ref).abs().max().item()
+    assert err < 2e-4, err   # fp32 accumulation-order noise only
+
+
+@pytest.mark.parametrize("rows,cols,eps", [(100, 256, 1e-5), (650, 384, 1e-6), (37, 768, 1e-6), (9, 1024, 1e-6)])
+def test_layernorm(lib, rows, cols, eps):
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, cols, generator=g) * 3 + 1
+    w, b = torch.randn(cols, generator=g), torch.randn(cols, generator=g)
+    ref = torch.nn.functional.layer_norm(x, (cols,), w, b, eps)
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    yd = torch.empty_like(xd)
+    _chk(lib, lib.ec_op_layernorm(_p(xd), _p(wd), _p(bd), _p(yd), rows, cols, eps, None))
+    torch.cuda.synchronize()
+    assert (yd.cpu() - ref).abs().max().item() < 2e-5
+
+
+def _attn_ref(q, k, v, H, hd, kmask, bias):
+    B, Lq, _ = q.shape
+    Lk = k.shape[1]
+    qh = q.double().reshape(B, Lq, H, hd).transpose(1, 2) * hd ** -0.5
+    kh = k.double().reshape(B, Lk, H, hd).transpose(1, 2)
+    vh = v.double().reshape(B, Lk, H, hd).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2)
+    if bias is not None:
+        s = s + bias.double()
+    if kmask is not None:
+        s = s.masked_fill(kmask.bool()[:, None, None, :], float("-inf"))
+    return (s.softmax(-1) @ vh).transpose(1, 2).reshape(B, Lq, H * hd).float()
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,hd,masked,biased", [
+    (2, 6, 257, 257, 64, False, False),    # ViT-S backbone block
+    (2, 8, 356, 356, 32, True, False),     # head encoder (image + keypoint tokens, key padding)
+    (3, 8, 100, 100, 32, True, True),      # decoder biased self-attention
+    (2, 8, 100, 324, 64, False, False),    # token -> image cross attention
+    (2, 8, 324, 100, 64, False, False),    # image -> token (two-way)
+    (1, 12, 130, 70, 64, True, False),     # ragged tile edges
+])
+def test_attention_fp32(lib, B, H, Lq, Lk, hd, masked, biased):
+    g = torch.Generator().manual_seed(B * 1000 + Lq + Lk)
+    q = torch.randn(B, Lq, H * hd, generator=g)
+    k = torch.randn(B, Lk, H * hd, generator=g)
+    v = torch.randn(B, Lk, H * hd, generator=g)
+    kmask = None
+    if masked:
+        kmask = (torch.rand(B, Lk, generator=g) < 0.4).to(torch.uint8)
+        kmask[:, 0] = 0
+        kmask[0, 1:] = 1 if Lk <= 128 else kmask[0, 1:]   # one sample with a single visible key
+    bias = torch.randn(B, H, Lq, Lk, generator=g) if biased else None
+    ref = _attn_ref(q, k, v, H, hd, kmask, bias)
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    md = kmask.cuda() if masked else None
+    bd = bias.cuda() if biased else None
+    od = torch.empty(B, Lq, H * hd, device="cuda")
+    _chk(lib, lib.ec_op_attention(_p(qd), _p(kd), _p(vd), _p(md), _p(bd), _p(od), B, H, Lq, Lk, hd, 0, None))
+    torch.cuda.synchronize()
+    err = (od.cpu() - ref).abs().max().item()
+    assert err < 2e-5, err
