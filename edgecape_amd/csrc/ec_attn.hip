@@ -146,14 +146,170 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnP p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// bf16 path (backbone, hd = 64): v_mfma_f32_32x32x16_bf16, fp32 softmax statistics, exp2 domain.
+//   K tile   [64 keys][64 d]  bf16 = 64 rows x 128 B, straight from the qkv buffer
+//   V^T tile [64 d][64 keys]  bf16 = 64 rows x 128 B, from the transposed V copy the QKV GEMM epilogue writes
+// Both tiles are staged with global_load_lds_dwordx4 (no VGPR round trip) into the same XOR-swizzled
+// 128-byte-row LDS image the GEMM uses, double-buffered.  With the transposed formulation the S^T
+// accumulator registers r = 8u..8u+7 of a lane are exactly the eight k-slots that lane must feed to the
+// second MFMA, so P goes accumulator -> v_cvt_pk_bf16_f32 -> B operand without leaving the lane.
+// ------------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16v8;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+constexpr int A16_TILE = 64 * 128;           // 8 KiB per tile
+constexpr int A16_STAGE = 2 * A16_TILE;      // K + V^T
+constexpr int A16_LDS = 2 * A16_STAGE;       // double buffered: 32 KiB
+
+__global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, hi = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const char* Qb = (const char*)p.Q + ((long)b * p.sQ + h * 64) * 2;
+  const char* Kb = (const char*)p.K + ((long)b * p.sK + h * 64) * 2;
+  const char* Vt = (const char*)p.V + ((long)(b * p.H + h) * 64) * p.ldv * 2;   // V^T rows: [(b*H + h)*64 + d][ldv]
+  const long ldk_b = p.ldk * 2, ldv_b = p.ldv * 2;
+
+  bf16x8 qf[4];
+  {
+    int qr = q0 + j;
+    qr = qr < p.Lq ? qr : p.Lq - 1;
+    const char* src = Qb + (long)qr * p.ldq * 2 + hi * 16;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) qf[m] = *(const bf16x8*)(src + m * 32);
+  }
+  f32x16 ot[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
+  float mrun = -1e30f, lrun = 0.f;
+  const float c = 0.125f * 1.44269504088896340736f;   // hd^-0.5 * log2(e)
+
+  auto stage = [&](int k0, char* buf) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int rb = wave * 2 + jj;
+      const int r = rb * 8 + (lane >> 3);
+      const int cc = (lane & 7) ^ ((r >> 1) & 7);
+      int key = k0 + r;
+      key = key < p.Lk ? key : p.Lk - 1;
+      __builtin_amdgcn_global_load_lds((gptr_t)(Kb + (long)key * ldk_b + cc * 16), (lptr_t)(buf + rb * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Vt + (long)r * ldv_b + (long)k0 * 2 + cc * 16),
+                                       (lptr_t)(buf + A16_TILE + rb * 1024), 16, 0, 0);
+    }
+  };
+
+  stage(0, smem);
+  int cur = 0;
+  for (int k0 = 0; k0 < p.Lk; k0 += 64) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (k0 + 64 < p.Lk) stage(k0 + 64, smem + (cur ^ 1) * A16_STAGE);
+    const char* Kt = smem + cur * A16_STAGE;
+    const char* Vtt = Kt + A16_TILE;
+    f32x16 s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+      const int row = t * 32 + j;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const bf16x8 a = *(const bf16x8*)(Kt + row * 128 + (((2 * m + hi) ^ ((row >> 1) & 7)) << 4));
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[m], s[t], 0, 0, 0);
+      }
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kg = k0 + t * 32 + acc_row(r, hi);
+        const float v = kg < p.Lk ? s[t][r] * c : -INFINITY;
+        s[t][r] = v;
+        tmax = fmaxf(tmax, v);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mnew = fmaxf(mrun, tmax);
+    const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+    mrun = mnew;
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[t][r] - mnew);
+        s[t][r] = e;
+        psum += e;
+      }
+    lrun = lrun * alpha + psum;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) {
+        f32x8 pv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pv[e] = s[t][8 * uu + e];
+        const bf16x8 pb = __builtin_bit_cast(bf16x8, __builtin_convertvector(pv, bf16v8));
+        const int chunk = 4 * t + 2 * uu;   // 16 keys = two 16-byte chunks of the V^T row
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const int row = d * 32 + j;
+          const int sw = (row >> 1) & 7;
+          const f32x2 lo = *(const f32x2*)(Vtt + row * 128 + ((chunk ^ sw) << 4) + hi * 8);
+          const f32x2 hi2 = *(const f32x2*)(Vtt + row * 128 + (((chunk + 1) ^ sw) << 4) + hi * 8);
+          f32x4 av;
+          av[0] = lo[0]; av[1] = lo[1]; av[2] = hi2[0]; av[3] = hi2[1];
+          ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), pb, ot[d], 0, 0, 0);
+        }
+      }
+    cur ^= 1;
+  }
+  lrun += __shfl_xor(lrun, 32, 64);
+  const float inv = 1.f / lrun;
+  if (q0 + j < p.Lq) {
+    char* O = (char*)p.O + ((long)b * p.sO + (long)(q0 + j) * p.ldo + h * 64) * 2;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (short)f2bf(ot[d][4 * g + e] * inv);
+        *(bf16x4*)(O + (d * 32 + 8 * g + 4 * hi) * 2) = o;
+      }
+  }
+}
+
 }  // namespace
 
 int attention(const AttnP& p, hipStream_t st) {
   EC_REQUIRE(p.B > 0 && p.H > 0 && p.Lq > 0 && p.Lk > 0, -1, "attention: empty problem");
   EC_REQUIRE(p.hd == 32 || p.hd == 64, -1, "attention: head dim must be 32 or 64");
-  EC_REQUIRE(!p.bf16, -1, "attention: bf16 path not built");
-  EC_REQUIRE(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldv % 4 == 0 && p.ldo % 4 == 0, -1, "attention: strides must be multiples of 4");
   dim3 grid((p.Lq + 127) / 128, p.H, p.B);
+  if (p.bf16) {
+    // V must be the TRANSPOSED copy [(b*H + h)*64 + d][ldv] with ldv >= round_up(Lk, 64) and a finite (zeroed) tail
+    EC_REQUIRE(p.hd == 64 && !p.kmask && !p.bias, -1, "attention(bf16): hd = 64, no mask / bias (backbone only)");
+    EC_REQUIRE(p.ldq % 8 == 0 && p.ldk % 64 == 0 && p.ldv % 64 == 0 && p.ldv >= ((p.Lk + 63) / 64) * 64 && p.ldo % 4 == 0, -1,
+               "attention(bf16): stride alignment");
+    hipLaunchKernelGGL(attn_bf16_kernel, grid, dim3(256), A16_LDS, st, p);
+    EC_LAUNCH_CHECK();
+    return 0;
+  }
+  EC_REQUIRE(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldv % 4 == 0 && p.ldo % 4 == 0, -1, "attention: strides must be multiples of 4");
   if (p.hd == 64) hipLaunchKernelGGL(attn_f32_kernel<64>, grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL(attn_f32_kernel<32>, grid, dim3(256), 0, st, p);
   EC_LAUNCH_CHECK();

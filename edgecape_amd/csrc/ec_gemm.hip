@@ -47,7 +47,9 @@ __device__ inline void stage_tile(const char* __restrict__ base, long ld_bytes, 
   }
 }
 
-template <bool BF16>
+// TAG only gives the backbone call sites their own kernel symbols (1 qkv, 2 proj, 3 fc1, 4 fc2, 0 everything else)
+// so that rocprofv3 --kernel-trace --stats reports the north-star QKV GEMM separately.
+template <bool BF16, int TAG>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -153,8 +155,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
         else if (p.act == ACT_TANHGATE) v = (tanhf(v) + 1.f) * aux[(long)m * p.ldaux + n];
         v *= gv;
         if (resid) v += resid[(long)m * p.ldr + n];
-        if (p.c_bf16) Ch[(long)m * p.ldc + n] = f2bf(v);
-        else Cf[(long)m * p.ldc + n] = v;
+        if (p.c_bf16) {
+          const bf16_t hv = f2bf(v);
+          Ch[(long)m * p.ldc + n] = hv;
+          if (TAG == 1 && p.vt && n >= p.vt_col0) {
+            const int bi = m / p.vt_T, t = m - bi * p.vt_T;
+            ((bf16_t*)p.vt)[((long)bi * (p.N - p.vt_col0) + (n - p.vt_col0)) * p.vt_ld + t] = hv;
+          }
+        } else {
+          Cf[(long)m * p.ldc + n] = v;
+        }
       }
     }
   }
@@ -254,14 +264,19 @@ int gemm_nt(const GemmP& p, hipStream_t st) {
   EC_REQUIRE(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0, -1, "gemm_nt: operands must be 16-byte aligned");
   EC_REQUIRE(p.act != ACT_TANHGATE || p.aux, -1, "gemm_nt: tanh-gate epilogue needs aux");
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.batch);
+  typedef void (*kern_t)(GemmP);
+  static const kern_t table[2][5] = {
+      {gemm_nt_kernel<false, 0>, gemm_nt_kernel<false, 1>, gemm_nt_kernel<false, 2>, gemm_nt_kernel<false, 3>, gemm_nt_kernel<false, 4>},
+      {gemm_nt_kernel<true, 0>, gemm_nt_kernel<true, 1>, gemm_nt_kernel<true, 2>, gemm_nt_kernel<true, 3>, gemm_nt_kernel<true, 4>}};
   static bool attr_done = false;
   if (!attr_done) {
-    EC_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
-    EC_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
+    for (int a = 0; a < 2; ++a)
+      for (int t = 0; t < 5; ++t)
+        EC_HIP(hipFuncSetAttribute((const void*)table[a][t], hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
     attr_done = true;
   }
-  if (p.ab_bf16) hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), GEMM_LDS, st, p);
-  else hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), GEMM_LDS, st, p);
+  EC_REQUIRE(p.tag >= 0 && p.tag < 5, -1, "gemm_nt: bad tag");
+  hipLaunchKernelGGL(table[p.ab_bf16 ? 1 : 0][p.tag], grid, dim3(256), GEMM_LDS, st, p);
   EC_LAUNCH_CHECK();
   return 0;
 }

@@ -71,6 +71,9 @@ struct ec_model {
   std::unordered_map<std::string, Tensor> tensors;
   std::vector<void*> owned;  // every hipMalloc'd pointer
   std::unordered_map<std::string, std::pair<const float*, long>> taps;
+  bool prof_on = false;            // ec_profile: HIP events around every backbone QKV GEMM launch
+  std::vector<hipEvent_t> prof_ev;
+  size_t prof_used = 0;
 
   // backbone
   Lin patch;
@@ -89,6 +92,7 @@ struct ec_model {
 
   // workspace (device)
   int n_img_max = 0;
+  void* bb_vt = nullptr; int Tpad = 0;   // transposed V for the bf16 attention kernel: [n*C][Tpad] bf16
   float* bb_x = nullptr; void* bb_xn = nullptr; void* bb_qkv = nullptr; void* bb_att = nullptr; void* bb_h = nullptr;
   float* feat = nullptr;      // [n_img_max, HW, C] tokens; query first, then shot s at (1+s)*bs
   float* feat_nchw_tmp = nullptr;
@@ -294,8 +298,9 @@ static int build_dec_layer(ec_model* m, const std::string& P, bool biased, bool 
 // ---- thin launch helpers -------------------------------------------------------------------------
 static int linear(const void* A, long lda, bool a16, const Lin& W, void* C, long ldc, bool c16, int M, int act, hipStream_t st,
                   const float* gamma = nullptr, const float* resid = nullptr, long ldr = 0, const float* table = nullptr,
-                  long ldt = 0, int period = 1, const float* aux = nullptr, long ldaux = 0) {
+                  long ldt = 0, int period = 1, const float* aux = nullptr, long ldaux = 0, int tag = 0) {
   GemmP p;
+  p.tag = tag;
   p.A = A; p.lda = lda; p.ab_bf16 = a16 ? 1 : 0;
   p.B = a16 ? (const void*)W.w16 : (const void*)W.w; p.ldb = W.K;
   EC_REQUIRE(p.B != nullptr, EC_ERR_STATE, "linear: weight copy for this precision was not built");
@@ -319,12 +324,17 @@ static int ln(const float* x, long ldx, void* y, long ldy, bool y16, const Norm&
 // ---------------------------------------------------------------------------------------------
 // Backbone: DINOv2 ViT.  n images -> m->feat [n, HW, C] fp32 token-major.
 // ---------------------------------------------------------------------------------------------
-static int run_backbone(ec_model* m, const float* img, int n, float* feat_out, hipStream_t st) {
+// The images may come from several tensors of n_each images (query batch + S support batches): they are
+// gathered by the im2col step so that the whole ViT runs ONCE over n = n_src * n_each images (one large-M GEMM
+// per layer instead of 1+S smaller ones).
+static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_each, float* feat_out, hipStream_t st) {
   const int C = m->C, T = m->T, HW = m->HW, g = m->g, H = m->cfg.image_size;
   const bool h16 = m->bb16;
   const int nh = m->cfg.num_heads;
+  const int n = n_src * n_each;
   const long M = (long)n * T;
-  RUN(im2col14(img, m->bb_h, h16, n, H, g, m->Kp, st));
+  for (int s = 0; s < n_src; ++s)
+    RUN(im2col14(imgs[s], (char*)m->bb_h + (size_t)s * n_each * HW * m->Kp * (h16 ? 2 : 4), h16, n_each, H, g, m->Kp, st));
   {  // patch embedding GEMM, one batch entry per image so rows land at token 1.. of each image; + bias + pos[1:]
     GemmP p;
     p.A = m->bb_h; p.lda = m->Kp; p.sA = (long)HW * m->Kp; p.ab_bf16 = h16;
@@ -339,19 +349,32 @@ static int run_backbone(ec_model* m, const float* img, int n, float* feat_out, h
   for (size_t i = 0; i < m->blocks.size(); ++i) {
     const BBlock& b = m->blocks[i];
     RUN(ln(m->bb_x, C, m->bb_xn, C, h16, b.n1, (int)M, C, 1e-6f, st));
-    RUN(linear(m->bb_xn, C, h16, b.qkv, m->bb_qkv, 3 * C, h16, (int)M, ACT_NONE, st));
+    const bool prof = m->prof_on && m->prof_used + 2 <= m->prof_ev.size();
+    if (prof) EC_HIP(hipEventRecord(m->prof_ev[m->prof_used++], st));
+    {
+      GemmP p;
+      p.tag = 1;
+      p.A = m->bb_xn; p.lda = C; p.ab_bf16 = h16;
+      p.B = h16 ? (const void*)b.qkv.w16 : (const void*)b.qkv.w; p.ldb = C;
+      p.C = m->bb_qkv; p.ldc = 3 * C; p.c_bf16 = h16; p.bias = b.qkv.b;
+      p.M = (int)M; p.N = 3 * C; p.K = C;
+      if (h16) { p.vt = m->bb_vt; p.vt_col0 = 2 * C; p.vt_T = T; p.vt_ld = m->Tpad; }
+      RUN(gemm_nt(p, st));
+    }
+    if (prof) EC_HIP(hipEventRecord(m->prof_ev[m->prof_used++], st));
     AttnP a;
     const size_t es = h16 ? 2 : 4;
     a.Q = m->bb_qkv; a.K = (const char*)m->bb_qkv + (size_t)C * es; a.V = (const char*)m->bb_qkv + (size_t)2 * C * es;
     a.O = m->bb_att;
     a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
+    if (h16) { a.V = m->bb_vt; a.ldv = m->Tpad; }
     a.sQ = a.sK = a.sV = (long)T * 3 * C; a.sO = (long)T * C;
     a.B = n; a.H = nh; a.Lq = T; a.Lk = T; a.hd = C / nh; a.bf16 = h16;
     RUN(attention(a, st));
-    RUN(linear(m->bb_att, C, h16, b.proj, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls1, m->bb_x, C));
+    RUN(linear(m->bb_att, C, h16, b.proj, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls1, m->bb_x, C, nullptr, 0, 1, nullptr, 0, 2));
     RUN(ln(m->bb_x, C, m->bb_xn, C, h16, b.n2, (int)M, C, 1e-6f, st));
-    RUN(linear(m->bb_xn, C, h16, b.fc1, m->bb_h, 4 * C, h16, (int)M, ACT_GELU, st));
-    RUN(linear(m->bb_h, 4 * C, h16, b.fc2, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls2, m->bb_x, C));
+    RUN(linear(m->bb_xn, C, h16, b.fc1, m->bb_h, 4 * C, h16, (int)M, ACT_GELU, st, nullptr, nullptr, 0, nullptr, 0, 1, nullptr, 0, 3));
+    RUN(linear(m->bb_h, 4 * C, h16, b.fc2, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls2, m->bb_x, C, nullptr, 0, 1, nullptr, 0, 4));
   }
   RUN(ln(m->bb_x, C, feat_out ? feat_out : m->feat, C, false, m->bnorm, (int)M, C, 1e-6f, st, T));
   return 0;
@@ -656,6 +679,7 @@ int ec_create(const ec_config* cfg, ec_handle* out) {
 int ec_destroy(ec_handle m) {
   if (!m) return EC_OK;
   for (void* p : m->owned) (void)hipFree(p);
+  for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
   delete m;
   return EC_OK;
 }
@@ -789,6 +813,11 @@ int ec_finalize(ec_handle m) {
   if ((rc = dmalloc(m, &m->bb_xn, MT * C * es))) return rc;
   if ((rc = dmalloc(m, &m->bb_qkv, MT * 3 * C * es))) return rc;
   if ((rc = dmalloc(m, &m->bb_att, MT * C * es))) return rc;
+  m->Tpad = ((T + 63) / 64) * 64;
+  if (m->bb16) {
+    if ((rc = dmalloc(m, &m->bb_vt, (size_t)n * C * m->Tpad * 2))) return rc;
+    EC_HIP(hipMemset(m->bb_vt, 0, (size_t)n * C * m->Tpad * 2));   // the padded key tail must stay finite (P = 0 there)
+  }
   if ((rc = dmalloc(m, &m->bb_h, std::max(MT * 4 * C, (size_t)n * HW * m->Kp) * es))) return rc;
   if ((rc = dalloc(m, &m->feat, (size_t)n * HW * C))) return rc;
   if ((rc = dalloc(m, &m->feat_nchw_tmp, (size_t)n * HW * C))) return rc;
@@ -819,8 +848,8 @@ int ec_backbone(ec_handle m, const float* img, int n_img, float* feat, int layou
   EC_REQUIRE(m && m->finalized, EC_ERR_STATE, "model not finalized");
   EC_REQUIRE(img && feat && n_img > 0 && n_img <= m->n_img_max, EC_ERR_ARG, "bad image batch (n_img <= (1+max_shots)*max_batch)");
   hipStream_t st = (hipStream_t)stream;
-  if (layout == EC_LAYOUT_TOKENS) return run_backbone(m, img, n_img, feat, st);
-  RUN(run_backbone(m, img, n_img, m->feat_nchw_tmp, st));
+  if (layout == EC_LAYOUT_TOKENS) return run_backbone(m, &img, 1, n_img, feat, st);
+  RUN(run_backbone(m, &img, 1, n_img, m->feat_nchw_tmp, st));
   return tokens_to_nchw(m->feat_nchw_tmp, feat, n_img, m->C, m->HW, st);
 }
 
@@ -862,14 +891,41 @@ int ec_forward(ec_handle m, const float* img_q, const float* const* img_s, const
   RUN(upload_edges(m, edges, off, bs, st));
   const size_t per = (size_t)bs * m->HW * m->C;
   // EdgeCape.extract_features (EdgeCape.py:186-191): the same backbone on the query and on every support image
-  RUN(run_backbone(m, img_q, bs, m->feat, st));
-  std::vector<const float*> fsp(S);
+  std::vector<const float*> srcs(1 + S), fsp(S);
+  srcs[0] = img_q;
   for (int s = 0; s < S; ++s) {
-    RUN(run_backbone(m, img_s[s], bs, m->feat + (1 + s) * per, st));
+    srcs[1 + s] = img_s[s];
     fsp[s] = m->feat + (1 + s) * per;
   }
+  RUN(run_backbone(m, srcs.data(), 1 + S, bs, m->feat, st));
   m->taps["feature_q"] = {m->feat, (long)per};
   return run_head(m, m->feat, fsp.data(), target_s, mask_s, bs, S, st, out);
+}
+
+int ec_profile(ec_handle m, int enable, int max_launches) {
+  EC_REQUIRE(m, EC_ERR_ARG, "null handle");
+  m->prof_on = enable != 0;
+  m->prof_used = 0;
+  while (enable && m->prof_ev.size() < (size_t)2 * max_launches) {
+    hipEvent_t e;
+    EC_HIP(hipEventCreate(&e));
+    m->prof_ev.push_back(e);
+  }
+  return EC_OK;
+}
+
+int ec_profile_read(ec_handle m, float* total_ms, int* launches) {
+  EC_REQUIRE(m && total_ms && launches, EC_ERR_ARG, "null argument");
+  float tot = 0.f;
+  for (size_t i = 0; i + 1 < m->prof_used; i += 2) {
+    EC_HIP(hipEventSynchronize(m->prof_ev[i + 1]));
+    float t = 0.f;
+    EC_HIP(hipEventElapsedTime(&t, m->prof_ev[i], m->prof_ev[i + 1]));
+    tot += t;
+  }
+  *total_ms = tot;
+  *launches = (int)(m->prof_used / 2);
+  return EC_OK;
 }
 
 int ec_debug_read(ec_handle m, const char* name, float* host_out, int64_t max_elems, int64_t* n_elems) {
@@ -940,7 +996,36 @@ int ec_op_layernorm(const float* x, const float* w, const float* b, float* y, in
 
 int ec_op_attention(const float* q, const float* k, const float* v, const uint8_t* kmask, const float* bias, float* o, int B, int H,
                     int Lq, int Lk, int hd, int precision, void* stream) {
-  EC_REQUIRE(precision == EC_F32, EC_ERR_ARG, "ec_op_attention: only EC_F32 is built");
+  if (precision == EC_BF16) {
+    // test path: round q,k,v to bf16 on device, build V^T, run the bf16 kernel, widen the result
+    EC_REQUIRE(hd == 64 && !kmask && !bias, EC_ERR_ARG, "ec_op_attention(bf16): hd = 64, no mask / bias");
+    hipStream_t st = (hipStream_t)stream;
+    const int E = H * hd, Tp = ((Lk + 63) / 64) * 64;
+    bf16_t *q16 = nullptr, *k16 = nullptr, *vt16 = nullptr, *o16 = nullptr;
+    EC_HIP(hipMalloc((void**)&q16, (size_t)B * Lq * E * 2));
+    EC_HIP(hipMalloc((void**)&k16, (size_t)B * Lk * E * 2));
+    EC_HIP(hipMalloc((void**)&vt16, (size_t)B * E * Tp * 2));
+    EC_HIP(hipMalloc((void**)&o16, (size_t)B * Lq * E * 2));
+    int rc = f32_to_bf16(q, q16, (long)B * Lq * E, st);
+    if (!rc) rc = f32_to_bf16(k, k16, (long)B * Lk * E, st);
+    if (!rc) rc = transpose_pad_bf16(v, vt16, B, Lk, E, Tp, st);   // [B][Lk][E] fp32 -> [B][E][Tp] bf16, zero tail
+    AttnP a;
+    a.Q = q16; a.K = k16; a.V = vt16; a.O = o16;
+    a.ldq = a.ldk = a.ldo = E; a.ldv = Tp;
+    a.sQ = a.sO = (long)Lq * E; a.sK = (long)Lk * E;
+    a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.hd = hd; a.bf16 = 1;
+    if (!rc) rc = attention(a, st);
+    (void)hipStreamSynchronize(st);
+    if (!rc) {
+      std::vector<bf16_t> ho((size_t)B * Lq * E);
+      std::vector<float> hf(ho.size());
+      EC_HIP(hipMemcpy(ho.data(), o16, ho.size() * 2, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < ho.size(); ++i) hf[i] = bf2f(ho[i]);
+      EC_HIP(hipMemcpy(o, hf.data(), hf.size() * 4, hipMemcpyHostToDevice));
+    }
+    (void)hipFree(q16); (void)hipFree(k16); (void)hipFree(vt16); (void)hipFree(o16);
+    return rc;
+  }
   AttnP a;
   a.Q = q; a.K = k; a.V = v; a.O = o;
   a.ldq = a.ldk = a.ldv = a.ldo = (long)H * hd;

@@ -23,6 +23,8 @@ int copy2d(float* dst, long ldd, const float* src, long lds, int rows, int cols,
 int copy3d(float* dst, long ldd, long sd, const float* src, long lds, long ss, int batch, int rows, int cols, hipStream_t st);
 int mean_over(float* dst, const float* src, long stride, int n, long count, hipStream_t st);
 int f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t st);
+// src [B][L][E] fp32 -> dst [B][E][Lp] bf16 (columns >= L zeroed); test helper for the bf16 attention kernel
+int transpose_pad_bf16(const float* src, bf16_t* dst, int B, int L, int E, int Lp, hipStream_t st);
 int im2col14(const float* img, void* patches, int out_bf16, int n_img, int H, int g, int Kp, hipStream_t st);
 int set_cls_rows(float* x, long ldx, const float* cls, const float* pos0, int n_img, int T, int C, hipStream_t st);
 int nchw_to_tokens(const float* src, float* dst, int n, int C, int HW, hipStream_t st);

@@ -98,6 +98,14 @@ __global__ void f32_to_bf16_kernel(const float* src, bf16_t* dst, long n) {
   if (i < n) dst[i] = f2bf(src[i]);
 }
 
+__global__ void transpose_pad_bf16_kernel(const float* src, bf16_t* dst, int L, int E, int Lp) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over E*Lp of batch blockIdx.y
+  if (i >= (long)E * Lp) return;
+  const int e = i / Lp, t = i % Lp;
+  const int b = blockIdx.y;
+  dst[(long)b * E * Lp + i] = t < L ? f2bf(src[((long)b * L + t) * E + e]) : (bf16_t)0;
+}
+
 // im2col for Conv2d(3, C, k=14, s=14) (DINOv2 PatchEmbed): patches[(n*g+py)*g+px][c*196+ky*14+kx],
 // row length Kp >= 588 (zero padded) so the GEMM K is a multiple of 128 bytes.
 template <bool OUT_BF16>
@@ -502,6 +510,12 @@ int mean_over(float* dst, const float* src, long stride, int n, long count, hipS
 
 int f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t st) {
   hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, src, dst, n);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int transpose_pad_bf16(const float* src, bf16_t* dst, int B, int L, int E, int Lp, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_pad_bf16_kernel, dim3(cdiv((long)E * Lp, 256), B), dim3(256), 0, st, src, dst, L, E, Lp);
   EC_LAUNCH_CHECK();
   return 0;
 }

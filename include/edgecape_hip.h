@@ -112,6 +112,12 @@ int ec_forward(ec_handle h, const float* img_q_dev, const float* const* img_s_de
 /* Copy a named intermediate of the LAST forward/head call to a host fp32 buffer (tests only; synchronises). */
 int ec_debug_read(ec_handle h, const char* name, float* host_out, int64_t max_elems, int64_t* n_elems);
 
+/* Measurement hook for bench.py (§ roofline): when enabled, a HIP event pair brackets every launch of the
+ * backbone QKV GEMM (the north-star kernel) on the caller's stream; ec_profile_read synchronises on them and
+ * returns the summed kernel time and the number of launches since the last ec_profile(h, 1, n). */
+int ec_profile(ec_handle h, int enable, int max_launches);
+int ec_profile_read(ec_handle h, float* total_ms, int* launches);
+
 /* ---- single ops (parity tests / microbenchmarks) -------------------------------------------- */
 /* C[M,N] = epilogue(A[M,K] @ W[N,K]^T): precision EC_F32 -> fp32 operands, EC_BF16 -> operands are
  * rounded to bf16 on device first.  act: 0 none, 1 relu, 2 gelu(erf).  bias/gamma/resid may be NULL. */

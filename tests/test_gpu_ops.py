@@ -124,3 +124,23 @@ def test_attention_fp32(lib, B, H, Lq, Lk, hd, masked, biased):
     torch.cuda.synchronize()
     err = (od.cpu() - ref).abs().max().item()
     assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("B,H,L", [(2, 6, 257), (2, 12, 325), (1, 16, 730), (1, 6, 64)])
+def test_attention_bf16(lib, B, H, L):
+    """bf16 MFMA attention (backbone shape) vs fp64 math on the bf16-rounded operands."""
+    hd = 64
+    g = torch.Generator().manual_seed(L)
+    q = torch.randn(B, L, H * hd, generator=g)
+    k = torch.randn(B, L, H * hd, generator=g)
+    v = torch.randn(B, L, H * hd, generator=g)
+    r16 = lambda x: x.bfloat16().float()
+    ref = _attn_ref(r16(q), r16(k), r16(v), H, hd, None, None)
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    od = torch.empty(B, L, H * hd, device="cuda")
+    _chk(lib, lib.ec_op_attention(_p(qd), _p(kd), _p(vd), None, None, _p(od), B, H, L, L, hd, 1, None))
+    torch.cuda.synchronize()
+    err = (od.cpu() - ref).abs().max().item()
+    # P and O are rounded to bf16 (8 mantissa bits): |O| <~ 1 -> a few 1e-3 absolute
+    assert err < 2e-2, err
+    assert (od.cpu() - ref).abs().mean().item() < 2e-3
