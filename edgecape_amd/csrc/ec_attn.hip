@@ -149,18 +149,21 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnP p) {
 
 // ------------------------------------------------------------------------------------------------
 // bf16 path (backbone, hd = 64): v_mfma_f32_32x32x16_bf16, fp32 softmax statistics, exp2 domain.
-//   K tile   [64 keys][64 d]  bf16 = 64 rows x 128 B, straight from the qkv buffer
-//   V^T tile [64 d][64 keys]  bf16 = 64 rows x 128 B, from the transposed V copy the QKV GEMM epilogue writes
-// Both tiles are staged with global_load_lds_dwordx4 (no VGPR round trip) into the same XOR-swizzled
-// 128-byte-row LDS image the GEMM uses, double-buffered.  With the transposed formulation the S^T
-// accumulator registers r = 8u..8u+7 of a lane are exactly the eight k-slots that lane must feed to the
-// second MFMA, so P goes accumulator -> v_cvt_pk_bf16_f32 -> B operand without leaving the lane.
+//   K tile [64 keys][64 d] and V tile [64 keys][64 d], bf16 = 64 rows x 128 B each, straight from the qkv buffer.
+// Both are staged with global_load_lds_dwordx4 (no VGPR round trip) into the same XOR-swizzled 128-byte-row
+// LDS image the GEMM uses, double-buffered.  The second MFMA needs V^T (keys contiguous per lane): that is the
+// gfx950 transposing LDS read ds_read_b64_tr_b16 — a 16-lane group reads a [4 keys][16 d] block, lane i supplying
+// the address of (key i>>2, d-quad i&3) and receiving the 4 keys of column i (probed on hardware:
+// tools/probe_tr_read.hip).  With the transposed formulation the S^T accumulator registers r = 8u..8u+7 of a lane
+// are exactly the eight k-slots that lane must feed to the second MFMA, so P goes accumulator ->
+// v_cvt_pk_bf16_f32 -> B operand without leaving the lane.
 // ------------------------------------------------------------------------------------------------
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16v8;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
 
 constexpr int A16_TILE = 64 * 128;           // 8 KiB per tile
 constexpr int A16_STAGE = 2 * A16_TILE;      // K + V^T
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
   const int q0 = blockIdx.x * 128 + wave * 32;
   const char* Qb = (const char*)p.Q + ((long)b * p.sQ + h * 64) * 2;
   const char* Kb = (const char*)p.K + ((long)b * p.sK + h * 64) * 2;
-  const char* Vt = (const char*)p.V + ((long)(b * p.H + h) * 64) * p.ldv * 2;   // V^T rows: [(b*H + h)*64 + d][ldv]
+  const char* Vb = (const char*)p.V + ((long)b * p.sV + h * 64) * 2;
   const long ldk_b = p.ldk * 2, ldv_b = p.ldv * 2;
 
   bf16x8 qf[4];
@@ -203,8 +206,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
       int key = k0 + r;
       key = key < p.Lk ? key : p.Lk - 1;
       __builtin_amdgcn_global_load_lds((gptr_t)(Kb + (long)key * ldk_b + cc * 16), (lptr_t)(buf + rb * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(Vt + (long)r * ldv_b + (long)k0 * 2 + cc * 16),
-                                       (lptr_t)(buf + A16_TILE + rb * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Vb + (long)key * ldv_b + cc * 16), (lptr_t)(buf + A16_TILE + rb * 1024), 16, 0, 0);
     }
   };
 
@@ -264,16 +266,22 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) pv[e] = s[t][8 * uu + e];
         const bf16x8 pb = __builtin_bit_cast(bf16x8, __builtin_convertvector(pv, bf16v8));
-        const int chunk = 4 * t + 2 * uu;   // 16 keys = two 16-byte chunks of the V^T row
+        // V^T fragment by transposing reads: this lane's 16-lane group covers d = 32*dt + 16*G .. +15; lane i of
+        // the group points at key row (i>>2) of a 4-key block and d-quad (i&3), and gets the 4 keys of column i.
+        const int i16 = lane & 15, G = (lane >> 4) & 1;
+        const int krow = 32 * t + 16 * uu + 4 * hi + (i16 >> 2);   // second block: + 8
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
-          const int row = d * 32 + j;
-          const int sw = (row >> 1) & 7;
-          const f32x2 lo = *(const f32x2*)(Vtt + row * 128 + ((chunk ^ sw) << 4) + hi * 8);
-          const f32x2 hi2 = *(const f32x2*)(Vtt + row * 128 + (((chunk + 1) ^ sw) << 4) + hi * 8);
-          f32x4 av;
-          av[0] = lo[0]; av[1] = lo[1]; av[2] = hi2[0]; av[3] = hi2[1];
-          ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), pb, ot[d], 0, 0, 0);
+          const int chunk = 4 * d + 2 * G + ((i16 >> 1) & 1);
+          const int off = (i16 & 1) * 8;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (lds_s16x4_t)(Vtt + krow * 128 + ((chunk ^ ((krow >> 1) & 7)) << 4) + off));
+          const s16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (lds_s16x4_t)(Vtt + (krow + 8) * 128 + ((chunk ^ (((krow + 8) >> 1) & 7)) << 4) + off));
+          bf16x8 av;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { av[e] = lo[e]; av[4 + e] = hi2[e]; }
+          ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pb, ot[d], 0, 0, 0);
         }
       }
     cur ^= 1;
@@ -301,10 +309,8 @@ int attention(const AttnP& p, hipStream_t st) {
   EC_REQUIRE(p.hd == 32 || p.hd == 64, -1, "attention: head dim must be 32 or 64");
   dim3 grid((p.Lq + 127) / 128, p.H, p.B);
   if (p.bf16) {
-    // V must be the TRANSPOSED copy [(b*H + h)*64 + d][ldv] with ldv >= round_up(Lk, 64) and a finite (zeroed) tail
     EC_REQUIRE(p.hd == 64 && !p.kmask && !p.bias, -1, "attention(bf16): hd = 64, no mask / bias (backbone only)");
-    EC_REQUIRE(p.ldq % 8 == 0 && p.ldk % 64 == 0 && p.ldv % 64 == 0 && p.ldv >= ((p.Lk + 63) / 64) * 64 && p.ldo % 4 == 0, -1,
-               "attention(bf16): stride alignment");
+    EC_REQUIRE(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0, -1, "attention(bf16): stride alignment");
     hipLaunchKernelGGL(attn_bf16_kernel, grid, dim3(256), A16_LDS, st, p);
     EC_LAUNCH_CHECK();
     return 0;

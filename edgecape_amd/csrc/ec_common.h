@@ -99,12 +99,6 @@ struct GemmP {
   int c_bf16 = 0;   // store C as bf16
   int ab_bf16 = 0;  // A and B are bf16 (else fp32)
   int tag = 0;      // kernel-symbol tag (profiling only): 1 qkv, 2 proj, 3 fc1, 4 fc2
-  // QKV epilogue for the bf16 attention kernel: columns >= vt_col0 (the V third) are ALSO written transposed,
-  // vt[(m / vt_T) * (N - vt_col0) + (n - vt_col0)][m % vt_T] with row stride vt_ld (bf16), so V^T tiles can be
-  // staged with direct global->LDS loads.
-  void* vt = nullptr;
-  int vt_col0 = 0, vt_T = 1;
-  long vt_ld = 0;
 };
 int gemm_nt(const GemmP& p, hipStream_t st);
 

@@ -15,158 +15,234 @@
 // so the bank-conflict swizzle is applied to the SOURCE address and undone on the ds_read_b128 side
 // (both use phys_chunk = chunk ^ ((row >> 1) & 7), an involution; conflict-free for the 16-lane groups
 // ds_read_b128 is serviced in).
+#include <stdlib.h>
+
 #include "ec_common.h"
 
 namespace ec {
 
 namespace {
 
-constexpr int BM = 128, BN = 128;
-constexpr int KBYTES = 128;                 // bytes of K per row per stage
-constexpr int TILE_BYTES = BM * KBYTES;     // 16 KiB per operand per stage
-constexpr int STAGE_BYTES = 2 * TILE_BYTES; // A + B
-constexpr int GEMM_LDS = 2 * STAGE_BYTES;   // double buffered: 64 KiB -> 2 workgroups / CU
+constexpr int KBYTES = 128;   // bytes of K per row per stage (32 fp32 / 64 bf16)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-__device__ inline void stage_tile(const char* __restrict__ base, long ld_bytes, int row0, int nrows_total,
-                                  long kbyte0, char* lds_tile, int wave, int lane) {
-  // 128 rows x 128 B = 16 wave-instructions; 4 per wave.
+// Stage ROWS rows x 128 B of a K-contiguous operand into LDS with NW waves (ROWS/8 wave-instructions).
+template <int ROWS, int NW>
+__device__ inline void stage_rows(const char* __restrict__ base, long ld_bytes, int row0, int nrows_total, long kbyte0,
+                                  char* lds_tile, int wave, int lane) {
+  constexpr int PER = ROWS / 8 / NW;
+  static_assert(ROWS % (8 * NW) == 0, "tile rows must split evenly over the waves");
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int rb = wave * 4 + j;            // 8-row block inside the tile
-    const int r = rb * 8 + (lane >> 3);     // row inside the tile
-    const int pc = lane & 7;                // physical 16-B chunk this lane fills
-    const int c = pc ^ ((r >> 1) & 7);      // logical chunk it must fetch
+  for (int j = 0; j < PER; ++j) {
+    const int rb = wave * PER + j;           // 8-row block inside the tile
+    const int r = rb * 8 + (lane >> 3);      // row inside the tile
+    const int c = (lane & 7) ^ ((r >> 1) & 7);   // logical 16-B chunk this lane fetches (swizzle on the SOURCE side)
     int gr = row0 + r;
-    gr = gr < nrows_total ? gr : nrows_total - 1;   // clamp: rows past the edge are never stored
+    gr = gr < nrows_total ? gr : nrows_total - 1;   // clamp: rows past the edge are computed but never stored
     const char* src = base + (long)gr * ld_bytes + kbyte0 + c * 16;
-    char* dst = lds_tile + rb * 1024;        // wave-uniform; hardware adds lane * 16
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + rb * 1024), 16, 0, 0);   // + lane*16 by hardware
   }
 }
 
-// TAG only gives the backbone call sites their own kernel symbols (1 qkv, 2 proj, 3 fc1, 4 fc2, 0 everything else)
-// so that rocprofv3 --kernel-trace --stats reports the north-star QKV GEMM separately.
-template <bool BF16, int TAG>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
+// erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7): used for GELU when the result is rounded to bf16 anyway.
+__device__ inline float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float e = 1.f - poly * t * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+  const float erfv = x < 0.f ? -e : e;
+  return 0.5f * x * (1.f + erfv);
+}
+
+// Persistent NT GEMM.  Workgroup = WGM x WGN waves; tile BM x BN; each wave owns (BM/WGM) x (BN/WGN).
+// The MFMA roles are SWAPPED (A-operand <- weight rows n, B-operand <- activation rows m) so that an
+// accumulator lane holds ONE output row m and 4 consecutive columns n per register quad: the epilogue
+// then writes 16-byte row segments (after a v_permlane32_swap pairing of the two half-waves) instead of
+// scalar elements.  TAG only separates kernel symbols for rocprof (1 qkv, 2 proj, 3 fc1, 4 fc2).
+template <bool BF16, int BM, int BN, int WGM, int WGN, int TAG>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_nt_kernel(GemmP p) {
+  constexpr int NW = WGM * WGN;
+  constexpr int MT = BM / WGM / 32, NT = BN / WGN / 32;
+  constexpr int A_BYTES = BM * KBYTES, B_BYTES = BN * KBYTES, STAGE = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
   const int esz = BF16 ? 2 : 4;
+  const int lrow = lane & 31, hi = lane >> 5;
 
-  // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8); give each XCD a
-  // contiguous run of tiles that share the same A row-panel so the panel stays in that XCD's L2.
-  const int ntn = gridDim.x, ntm = gridDim.y;
-  const int nwg = ntn * ntm;
-  int wg = blockIdx.y * ntn + blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective for any nwg
-  }
-  const int bm = wg / ntn, bn = wg % ntn;
-  const int bz = blockIdx.z;
-  const int m0 = bm * BM, n0 = bn * BN;
-
-  const char* A = (const char*)p.A + (long)bz * p.sA * esz;
-  const char* B = (const char*)p.B + (long)bz * p.sB * esz;
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+  const int per_batch = ntm * ntn;
+  const int ntiles = per_batch * p.batch;
   const long lda_b = p.lda * esz, ldb_b = p.ldb * esz;
   const int nk = (p.K * esz) / KBYTES;
 
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // XCD-aware persistent schedule: workgroup b runs on XCD b % 8 (observed); XCD x walks the contiguous tile
+  // range [x*chunk, (x+1)*chunk) (row-major, n fastest) so tiles in flight on one L2 share operand panels.
+  const int nxcd = (gridDim.x >= 8 && gridDim.x % 8 == 0) ? 8 : 1;
+  const int chunk = (ntiles + nxcd - 1) / nxcd;
+  const int xcd = blockIdx.x % nxcd, slot = blockIdx.x / nxcd, nslot = gridDim.x / nxcd;
+  const int t_end = min(ntiles, (xcd + 1) * chunk);
 
-  stage_tile(A, lda_b, m0, p.M, 0, smem, wave, lane);
-  stage_tile(B, ldb_b, n0, p.N, 0, smem + TILE_BYTES, wave, lane);
+  auto tile_coords = [&](int t, int& bz, int& m0, int& n0) {
+    bz = t / per_batch;
+    const int r = t - bz * per_batch;
+    m0 = (r / ntn) * BM;
+    n0 = (r % ntn) * BN;
+  };
+  auto stage = [&](int bz, int m0, int n0, int kt, char* buf) {
+    const char* A = (const char*)p.A + (long)bz * p.sA * esz;
+    const char* B = (const char*)p.B + (long)bz * p.sB * esz;
+    stage_rows<BM, NW>(A, lda_b, m0, p.M, (long)kt * KBYTES, buf, wave, lane);
+    stage_rows<BN, NW>(B, ldb_b, n0, p.N, (long)kt * KBYTES, buf + A_BYTES, wave, lane);
+  };
 
-  const int lrow = lane & 31, hi = lane >> 5;
+  int t = xcd * chunk + slot;
+  int bz, m0, n0;
   int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) {
-      char* nxt = smem + (cur ^ 1) * STAGE_BYTES;
-      stage_tile(A, lda_b, m0, p.M, (long)(kt + 1) * KBYTES, nxt, wave, lane);
-      stage_tile(B, ldb_b, n0, p.N, (long)(kt + 1) * KBYTES, nxt + TILE_BYTES, wave, lane);
-    }
-    const char* At = smem + cur * STAGE_BYTES;
-    const char* Bt = At + TILE_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int chunk = 2 * kk + hi;
-      f32x4 a[2], b[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int ra = wm * 64 + t * 32 + lrow;
-        const int rb = wn * 64 + t * 32 + lrow;
-        a[t] = *(const f32x4*)(At + ra * KBYTES + ((chunk ^ ((ra >> 1) & 7)) << 4));
-        b[t] = *(const f32x4*)(Bt + rb * KBYTES + ((chunk ^ ((rb >> 1) & 7)) << 4));
-      }
-      if constexpr (BF16) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),
-                                                                __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
-      }
-    }
-    cur ^= 1;
+  if (t < t_end) {
+    tile_coords(t, bz, m0, n0);
+    stage(bz, m0, n0, 0, smem);
   }
+  for (; t < t_end; t += nslot) {
+    f32x16 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // ---- epilogue: acc reg r of lane (col = lane&31, hi) is row (r&3) + 8*(r>>2) + 4*hi ----
-  const float* bias = p.bias ? p.bias + (long)bz * p.sBias : nullptr;
-  const float* resid = p.resid ? p.resid + (long)bz * p.sR : nullptr;
-  const float* aux = p.aux ? p.aux + (long)bz * p.sAux : nullptr;
-  float* Cf = (float*)p.C + (long)bz * p.sC;
-  bf16_t* Ch = (bf16_t*)p.C + (long)bz * p.sC;
+    const int tn = t + nslot;
+    int bz2 = 0, m02 = 0, n02 = 0;
+    if (tn < t_end) tile_coords(tn, bz2, m02, n02);
+
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      char* nxt = smem + (cur ^ 1) * STAGE;
+      if (kt + 1 < nk) stage(bz, m0, n0, kt + 1, nxt);
+      else if (tn < t_end) stage(bz2, m02, n02, 0, nxt);   // next tile's first K-step lands under this tile's epilogue
+      const char* At = smem + cur * STAGE;
+      const char* Bt = At + A_BYTES;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + lrow;
-    if (n >= p.N) continue;
-    const float bv = bias ? bias[n] : 0.f;
-    const float gv = p.gamma ? p.gamma[n] : 1.f;
+      for (int kk = 0; kk < 4; ++kk) {
+        const int chunkk = 2 * kk + hi;
+        f32x4 xa[MT], wb[NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+        for (int j = 0; j < MT; ++j) {
+          const int ra = wm * (BM / WGM) + j * 32 + lrow;
+          xa[j] = *(const f32x4*)(At + ra * KBYTES + ((chunkk ^ ((ra >> 1) & 7)) << 4));
+        }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (m >= p.M) continue;
-        float v = acc[i][j][r] + bv;
-        if (p.table) v += p.table[(long)(m % p.period) * p.ldt + n];
-        if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-        else if (p.act == ACT_GELU) v = gelu_erf(v);
-        else if (p.act == ACT_TANHGATE) v = (tanhf(v) + 1.f) * aux[(long)m * p.ldaux + n];
-        v *= gv;
-        if (resid) v += resid[(long)m * p.ldr + n];
-        if (p.c_bf16) {
-          const bf16_t hv = f2bf(v);
-          Ch[(long)m * p.ldc + n] = hv;
-          if (TAG == 1 && p.vt && n >= p.vt_col0) {
-            const int bi = m / p.vt_T, t = m - bi * p.vt_T;
-            ((bf16_t*)p.vt)[((long)bi * (p.N - p.vt_col0) + (n - p.vt_col0)) * p.vt_ld + t] = hv;
-          }
+        for (int i = 0; i < NT; ++i) {
+          const int rb = wn * (BN / WGN) + i * 32 + lrow;
+          wb[i] = *(const f32x4*)(Bt + rb * KBYTES + ((chunkk ^ ((rb >> 1) & 7)) << 4));
+        }
+        if constexpr (BF16) {
+#pragma unroll
+          for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[i]),
+                                                                  __builtin_bit_cast(bf16x8, xa[j]), acc[i][j], 0, 0, 0);
         } else {
-          Cf[(long)m * p.ldc + n] = v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+              for (int j = 0; j < MT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[i][e], xa[j][e], acc[i][j], 0, 0, 0);
+        }
+      }
+      cur ^= 1;
+    }
+
+    // ---- epilogue.  acc[i][j][r], lane (m_local = lane & 31, hi): column n_local = (r&3) + 8*(r>>2) + 4*hi.
+    // Pair the register quads g = 2q, 2q+1 across the half-waves (v_permlane32_swap): afterwards lane hi=0 holds
+    // columns 16q..16q+7 and lane hi=1 columns 16q+8..16q+15 of its row -> 8 consecutive outputs per lane.
+    const float* bias = p.bias ? p.bias + (long)bz * p.sBias : nullptr;
+    const float* resid = p.resid ? p.resid + (long)bz * p.sR : nullptr;
+    const float* aux = p.aux ? p.aux + (long)bz * p.sAux : nullptr;
+    char* Cb = (char*)p.C + (long)bz * p.sC * (p.c_bf16 ? 2 : 4);
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int m = m0 + wm * (BM / WGM) + j * 32 + lrow;
+      const bool mok = m < p.M;
+      const int mt = mok && p.table ? m % p.period : 0;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float a = acc[i][j][8 * q + e], b = acc[i][j][8 * q + 4 + e];
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+            v[e] = __uint_as_float(sw[0]);
+            v[4 + e] = __uint_as_float(sw[1]);
+          }
+          const int n = n0 + wn * (BN / WGN) + i * 32 + 16 * q + 8 * hi;   // first of this lane's 8 columns
+          if (!mok || n >= p.N) continue;                                   // N is a multiple of 8 (checked on the host)
+          if (bias) {
+            const f32x4 b0 = *(const f32x4*)(bias + n), b1 = *(const f32x4*)(bias + n + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+          }
+          if (p.table) {
+            const float* tp = p.table + (long)mt * p.ldt + n;
+            const f32x4 t0 = *(const f32x4*)tp, t1 = *(const f32x4*)(tp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += t0[e]; v[4 + e] += t1[e]; }
+          }
+          if (p.act == ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          } else if (p.act == ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = p.c_bf16 ? gelu_fast(v[e]) : gelu_erf(v[e]);
+          } else if (p.act == ACT_TANHGATE) {
+            const float* ap = aux + (long)m * p.ldaux + n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (tanhf(v[e]) + 1.f) * ap[e];
+          }
+          if (p.gamma) {
+            const f32x4 g0 = *(const f32x4*)(p.gamma + n), g1 = *(const f32x4*)(p.gamma + n + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] *= g0[e]; v[4 + e] *= g1[e]; }
+          }
+          if (resid) {
+            const float* rp = resid + (long)m * p.ldr + n;
+            const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+          }
+          if (p.c_bf16) {
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (unsigned)f2bf(v[2 * e]) | ((unsigned)f2bf(v[2 * e + 1]) << 16);
+            *(u32x4*)(Cb + ((long)m * p.ldc + n) * 2) = o;
+          } else {
+            f32x4 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o0[e] = v[e]; o1[e] = v[4 + e]; }
+            float* cp = (float*)Cb + (long)m * p.ldc + n;
+            *(f32x4*)cp = o0;
+            *(f32x4*)(cp + 4) = o1;
+          }
         }
       }
     }
+    bz = bz2; m0 = m02; n0 = n02;
   }
 }
 
@@ -256,29 +332,64 @@ __global__ __launch_bounds__(256) void bgemm_small_kernel(BgemmP p) {
 
 }  // namespace
 
+namespace {
+struct Cfg { int bm, bn, threads, lds, per_cu; };
+template <bool BF16, int BM, int BN, int WGM, int WGN>
+int launch_cfg(const GemmP& p, hipStream_t st, int per_cu) {
+  typedef void (*kern_t)(GemmP);
+  static const kern_t table[5] = {gemm_nt_kernel<BF16, BM, BN, WGM, WGN, 0>, gemm_nt_kernel<BF16, BM, BN, WGM, WGN, 1>,
+                                  gemm_nt_kernel<BF16, BM, BN, WGM, WGN, 2>, gemm_nt_kernel<BF16, BM, BN, WGM, WGN, 3>,
+                                  gemm_nt_kernel<BF16, BM, BN, WGM, WGN, 4>};
+  constexpr int LDS = 2 * (BM + BN) * KBYTES;
+  static bool attr_done = false;
+  if (!attr_done) {
+    for (int t = 0; t < 5; ++t)
+      EC_HIP(hipFuncSetAttribute((const void*)table[t], hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_done = true;
+  }
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    EC_HIP(hipGetDevice(&dev));
+    EC_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  const long ntiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.batch;
+  long grid = (long)ncu * per_cu;
+  if (ntiles < grid) grid = ntiles;
+  hipLaunchKernelGGL(table[p.tag], dim3((unsigned)grid), dim3(WGM * WGN * 64), LDS, st, p);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace
+
 int gemm_nt(const GemmP& p, hipStream_t st) {
   const int esz = p.ab_bf16 ? 2 : 4;
   EC_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0 && p.batch > 0, -1, "gemm_nt: empty problem");
   EC_REQUIRE((p.K * esz) % KBYTES == 0, -1, "gemm_nt: K must be a multiple of 128 bytes");
   EC_REQUIRE((p.lda * esz) % 16 == 0 && (p.ldb * esz) % 16 == 0, -1, "gemm_nt: row strides must be 16-byte multiples");
   EC_REQUIRE(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0, -1, "gemm_nt: operands must be 16-byte aligned");
+  EC_REQUIRE(p.N % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C % 16) == 0, -1, "gemm_nt: N and ldc must be multiples of 8");
+  EC_REQUIRE(!p.resid || (p.ldr % 4 == 0), -1, "gemm_nt: residual stride must be a multiple of 4");
+  EC_REQUIRE(!p.table || (p.ldt % 4 == 0), -1, "gemm_nt: table stride must be a multiple of 4");
   EC_REQUIRE(p.act != ACT_TANHGATE || p.aux, -1, "gemm_nt: tanh-gate epilogue needs aux");
-  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.batch);
-  typedef void (*kern_t)(GemmP);
-  static const kern_t table[2][5] = {
-      {gemm_nt_kernel<false, 0>, gemm_nt_kernel<false, 1>, gemm_nt_kernel<false, 2>, gemm_nt_kernel<false, 3>, gemm_nt_kernel<false, 4>},
-      {gemm_nt_kernel<true, 0>, gemm_nt_kernel<true, 1>, gemm_nt_kernel<true, 2>, gemm_nt_kernel<true, 3>, gemm_nt_kernel<true, 4>}};
-  static bool attr_done = false;
-  if (!attr_done) {
-    for (int a = 0; a < 2; ++a)
-      for (int t = 0; t < 5; ++t)
-        EC_HIP(hipFuncSetAttribute((const void*)table[a][t], hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
-    attr_done = true;
-  }
   EC_REQUIRE(p.tag >= 0 && p.tag < 5, -1, "gemm_nt: bad tag");
-  hipLaunchKernelGGL(table[p.ab_bf16 ? 1 : 0][p.tag], grid, dim3(256), GEMM_LDS, st, p);
-  EC_LAUNCH_CHECK();
-  return 0;
+  // tile choice: 256x256 (8 waves, 1 workgroup/CU) for the big backbone GEMMs, 256x128 when N is not a multiple of
+  // 256, 128x128 (4 waves, 2 workgroups/CU) for the small head GEMMs.
+  static const int force = getenv("EC_GEMM_TILE") ? atoi(getenv("EC_GEMM_TILE")) : 0;
+  int sel;
+  const long work = (long)p.M * p.batch;
+  if (work >= 4096 && p.N >= 512 && p.N % 256 == 0) sel = 2;
+  else if (work >= 4096 && p.N >= 384) sel = 1;
+  else sel = 0;
+  if (force == 128) sel = 0; else if (force == 256128) sel = 1; else if (force == 256) sel = 2;
+  if (p.ab_bf16) {
+    if (sel == 2) return launch_cfg<true, 256, 256, 2, 4>(p, st, 1);
+    if (sel == 1) return launch_cfg<true, 256, 128, 4, 2>(p, st, 1);
+    return launch_cfg<true, 128, 128, 2, 2>(p, st, 2);
+  }
+  if (sel == 2) return launch_cfg<false, 256, 256, 2, 4>(p, st, 1);
+  if (sel == 1) return launch_cfg<false, 256, 128, 4, 2>(p, st, 1);
+  return launch_cfg<false, 128, 128, 2, 2>(p, st, 2);
 }
 
 int bgemm_small(const BgemmP& p, hipStream_t st) {

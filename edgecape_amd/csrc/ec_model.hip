@@ -92,7 +92,6 @@ struct ec_model {
 
   // workspace (device)
   int n_img_max = 0;
-  void* bb_vt = nullptr; int Tpad = 0;   // transposed V for the bf16 attention kernel: [n*C][Tpad] bf16
   float* bb_x = nullptr; void* bb_xn = nullptr; void* bb_qkv = nullptr; void* bb_att = nullptr; void* bb_h = nullptr;
   float* feat = nullptr;      // [n_img_max, HW, C] tokens; query first, then shot s at (1+s)*bs
   float* feat_nchw_tmp = nullptr;
@@ -358,7 +357,6 @@ static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_
       p.B = h16 ? (const void*)b.qkv.w16 : (const void*)b.qkv.w; p.ldb = C;
       p.C = m->bb_qkv; p.ldc = 3 * C; p.c_bf16 = h16; p.bias = b.qkv.b;
       p.M = (int)M; p.N = 3 * C; p.K = C;
-      if (h16) { p.vt = m->bb_vt; p.vt_col0 = 2 * C; p.vt_T = T; p.vt_ld = m->Tpad; }
       RUN(gemm_nt(p, st));
     }
     if (prof) EC_HIP(hipEventRecord(m->prof_ev[m->prof_used++], st));
@@ -367,7 +365,6 @@ static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_
     a.Q = m->bb_qkv; a.K = (const char*)m->bb_qkv + (size_t)C * es; a.V = (const char*)m->bb_qkv + (size_t)2 * C * es;
     a.O = m->bb_att;
     a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
-    if (h16) { a.V = m->bb_vt; a.ldv = m->Tpad; }
     a.sQ = a.sK = a.sV = (long)T * 3 * C; a.sO = (long)T * C;
     a.B = n; a.H = nh; a.Lq = T; a.Lk = T; a.hd = C / nh; a.bf16 = h16;
     RUN(attention(a, st));
@@ -813,11 +810,6 @@ int ec_finalize(ec_handle m) {
   if ((rc = dmalloc(m, &m->bb_xn, MT * C * es))) return rc;
   if ((rc = dmalloc(m, &m->bb_qkv, MT * 3 * C * es))) return rc;
   if ((rc = dmalloc(m, &m->bb_att, MT * C * es))) return rc;
-  m->Tpad = ((T + 63) / 64) * 64;
-  if (m->bb16) {
-    if ((rc = dmalloc(m, &m->bb_vt, (size_t)n * C * m->Tpad * 2))) return rc;
-    EC_HIP(hipMemset(m->bb_vt, 0, (size_t)n * C * m->Tpad * 2));   // the padded key tail must stay finite (P = 0 there)
-  }
   if ((rc = dmalloc(m, &m->bb_h, std::max(MT * 4 * C, (size_t)n * HW * m->Kp) * es))) return rc;
   if ((rc = dalloc(m, &m->feat, (size_t)n * HW * C))) return rc;
   if ((rc = dalloc(m, &m->feat_nchw_tmp, (size_t)n * HW * C))) return rc;
@@ -1000,19 +992,19 @@ int ec_op_attention(const float* q, const float* k, const float* v, const uint8_
     // test path: round q,k,v to bf16 on device, build V^T, run the bf16 kernel, widen the result
     EC_REQUIRE(hd == 64 && !kmask && !bias, EC_ERR_ARG, "ec_op_attention(bf16): hd = 64, no mask / bias");
     hipStream_t st = (hipStream_t)stream;
-    const int E = H * hd, Tp = ((Lk + 63) / 64) * 64;
-    bf16_t *q16 = nullptr, *k16 = nullptr, *vt16 = nullptr, *o16 = nullptr;
+    const int E = H * hd;
+    bf16_t *q16 = nullptr, *k16 = nullptr, *v16 = nullptr, *o16 = nullptr;
     EC_HIP(hipMalloc((void**)&q16, (size_t)B * Lq * E * 2));
     EC_HIP(hipMalloc((void**)&k16, (size_t)B * Lk * E * 2));
-    EC_HIP(hipMalloc((void**)&vt16, (size_t)B * E * Tp * 2));
+    EC_HIP(hipMalloc((void**)&v16, (size_t)B * Lk * E * 2));
     EC_HIP(hipMalloc((void**)&o16, (size_t)B * Lq * E * 2));
     int rc = f32_to_bf16(q, q16, (long)B * Lq * E, st);
     if (!rc) rc = f32_to_bf16(k, k16, (long)B * Lk * E, st);
-    if (!rc) rc = transpose_pad_bf16(v, vt16, B, Lk, E, Tp, st);   // [B][Lk][E] fp32 -> [B][E][Tp] bf16, zero tail
+    if (!rc) rc = f32_to_bf16(v, v16, (long)B * Lk * E, st);
     AttnP a;
-    a.Q = q16; a.K = k16; a.V = vt16; a.O = o16;
-    a.ldq = a.ldk = a.ldo = E; a.ldv = Tp;
-    a.sQ = a.sO = (long)Lq * E; a.sK = (long)Lk * E;
+    a.Q = q16; a.K = k16; a.V = v16; a.O = o16;
+    a.ldq = a.ldk = a.ldv = a.ldo = E;
+    a.sQ = a.sO = (long)Lq * E; a.sK = a.sV = (long)Lk * E;
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.hd = hd; a.bf16 = 1;
     if (!rc) rc = attention(a, st);
     (void)hipStreamSynchronize(st);
@@ -1023,7 +1015,7 @@ int ec_op_attention(const float* q, const float* k, const float* v, const uint8_
       for (size_t i = 0; i < ho.size(); ++i) hf[i] = bf2f(ho[i]);
       EC_HIP(hipMemcpy(o, hf.data(), hf.size() * 4, hipMemcpyHostToDevice));
     }
-    (void)hipFree(q16); (void)hipFree(k16); (void)hipFree(vt16); (void)hipFree(o16);
+    (void)hipFree(q16); (void)hipFree(k16); (void)hipFree(v16); (void)hipFree(o16);
     return rc;
   }
   AttnP a;

@@ -144,3 +144,26 @@ def test_attention_bf16(lib, B, H, L):
     # P and O are rounded to bf16 (8 mantissa bits): |O| <~ 1 -> a few 1e-3 absolute
     assert err < 2e-2, err
     assert (od.cpu() - ref).abs().mean().item() < 2e-3
+
+
+@pytest.mark.parametrize("M,N,K,prec", [(20800, 2304, 768, 1), (5000, 768, 3072, 1), (4100, 1152, 384, 1), (4500, 384, 384, 0),
+                                        (6000, 512, 256, 0), (300, 256, 256, 1)])
+def test_linear_tile_configs(lib, M, N, K, prec):
+    """Exercise every tile configuration of the persistent GEMM (256x256, 256x128, 128x128) incl. ragged M edges."""
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g)
+    if prec == 1:
+        ref = (A.bfloat16().double() @ W.bfloat16().double().T + b.double() + R.double()).float()
+        tol = 3e-4
+    else:
+        ref = (A.double() @ W.double().T + b.double() + R.double()).float()
+        tol = 3e-5
+    Ad, Wd, bd, Rd = A.cuda(), W.cuda(), b.cuda(), R.cuda()
+    Cd = torch.empty(M, N, device="cuda")
+    _chk(lib, lib.ec_op_linear(_p(Ad), _p(Wd), _p(bd), None, _p(Rd), _p(Cd), M, N, K, 0, prec, None))
+    torch.cuda.synchronize()
+    err = (Cd.cpu() - ref).abs().max().item()
+    assert err < tol * max(1.0, ref.abs().max().item()), err
