@@ -35,7 +35,9 @@ def shard_indices(n_total, rank, world_size):
     """DistributedSampler(shuffle=False) semantics: pad to equal length, rank r takes r, r+W, ..."""
     per = (n_total + world_size - 1) // world_size
     idx = list(range(n_total))
-    idx += idx[: per * world_size - n_total]
+    pad = per * world_size - n_total
+    if pad > 0 and n_total > 0:
+        idx += (idx * ((pad + n_total - 1) // n_total))[:pad]   # wraps more than once when n_total < world_size
     return idx[rank::world_size]
 
 
