@@ -99,8 +99,11 @@ struct GemmP {
   int c_bf16 = 0;   // store C as bf16
   int ab_bf16 = 0;  // A and B are bf16 (else fp32)
   int tag = 0;      // kernel-symbol tag (profiling only): 1 qkv, 2 proj, 3 fc1, 4 fc2
+  int dbg = 0;      // timing experiments (EC_G8_DBG): bit 0 = skip the C stores
 };
 int gemm_nt(const GemmP& p, hipStream_t st);
+// 256x256x64 8-phase bf16 kernel (ec_gemm8.hip): 1 = handled, 0 = shape not eligible (use gemm_nt's own kernels), < 0 error
+int gemm8_bf16(const GemmP& p, hipStream_t st);
 
 // Small batched fp32 GEMM on the vector ALU (ec_gemm.hip): C[b] = alpha * A[b] @ op(B[b]) + beta * C[b]
 // transB = 1: B is [N,K] (NT); transB = 0: B is [K,N] (NN).  Arbitrary sizes/strides.

@@ -373,6 +373,10 @@ int gemm_nt(const GemmP& p, hipStream_t st) {
   EC_REQUIRE(!p.table || (p.ldt % 4 == 0), -1, "gemm_nt: table stride must be a multiple of 4");
   EC_REQUIRE(p.act != ACT_TANHGATE || p.aux, -1, "gemm_nt: tanh-gate epilogue needs aux");
   EC_REQUIRE(p.tag >= 0 && p.tag < 5, -1, "gemm_nt: bad tag");
+  if (p.ab_bf16) {   // large bf16 problems: the 8-phase 256x256x64 kernel
+    const int rc = gemm8_bf16(p, st);
+    if (rc != 0) return rc < 0 ? rc : 0;
+  }
   // tile choice: 256x256 (8 waves, 1 workgroup/CU) for the big backbone GEMMs, 256x128 when N is not a multiple of
   // 256, 128x128 (4 waves, 2 workgroups/CU) for the small head GEMMs.
   static const int force = getenv("EC_GEMM_TILE") ? atoi(getenv("EC_GEMM_TILE")) : 0;

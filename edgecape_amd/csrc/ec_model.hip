@@ -92,7 +92,7 @@ struct ec_model {
 
   // workspace (device)
   int n_img_max = 0;
-  float* bb_x = nullptr; void* bb_xn = nullptr; void* bb_qkv = nullptr; void* bb_att = nullptr; void* bb_h = nullptr;
+  float* bb_x = nullptr; void* bb_xn = nullptr; void* bb_qkv = nullptr; void* bb_att = nullptr; void* bb_h = nullptr; void* bb_y = nullptr;
   float* feat = nullptr;      // [n_img_max, HW, C] tokens; query first, then shot s at (1+s)*bs
   float* feat_nchw_tmp = nullptr;
   int32_t *d_edges = nullptr, *d_off = nullptr; int edges_cap = 0;
@@ -311,10 +311,11 @@ static int linear(const void* A, long lda, bool a16, const Lin& W, void* C, long
 }
 
 static int ln(const float* x, long ldx, void* y, long ldy, bool y16, const Norm& n, int rows, int cols, float eps, hipStream_t st,
-              int drop_period = 0) {
+              int drop_period = 0, const void* add = nullptr, long ldadd = 0) {
   LnP p;
   p.x = x; p.ldx = ldx; p.y = y; p.ldy = ldy; p.y_bf16 = y16; p.w = n.w; p.b = n.b; p.rows = rows; p.cols = cols; p.eps = eps;
   p.drop_period = drop_period;
+  p.add = add; p.ldadd = ldadd; p.xsum = add ? const_cast<float*>(x) : nullptr;
   return layernorm(p, st);
 }
 
@@ -345,9 +346,14 @@ static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_
   }
   RUN(set_cls_rows(m->bb_x, C, m->cls, m->pos, n, T, C, st));
   if (!feat_out) m->taps["tokens0"] = {m->bb_x, M * C};
+  // bf16 mode: the branch GEMMs (proj, fc2) write y = gamma * (acc + bias) as bf16 and the residual add x += y is fused
+  // into the FOLLOWING LayerNorm (same HBM bytes, but the fp32 read-modify-write leaves the GEMM epilogue).
+  // fp32 mode: the residual is added in the GEMM epilogue (exact fp32 stream).
+  const void* pend = nullptr;   // branch output not yet added to x
   for (size_t i = 0; i < m->blocks.size(); ++i) {
     const BBlock& b = m->blocks[i];
-    RUN(ln(m->bb_x, C, m->bb_xn, C, h16, b.n1, (int)M, C, 1e-6f, st));
+    RUN(ln(m->bb_x, C, m->bb_xn, C, h16, b.n1, (int)M, C, 1e-6f, st, 0, pend, C));
+    pend = nullptr;
     const bool prof = m->prof_on && m->prof_used + 2 <= m->prof_ev.size();
     if (prof) EC_HIP(hipEventRecord(m->prof_ev[m->prof_used++], st));
     {
@@ -368,12 +374,20 @@ static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_
     a.sQ = a.sK = a.sV = (long)T * 3 * C; a.sO = (long)T * C;
     a.B = n; a.H = nh; a.Lq = T; a.Lk = T; a.hd = C / nh; a.bf16 = h16;
     RUN(attention(a, st));
-    RUN(linear(m->bb_att, C, h16, b.proj, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls1, m->bb_x, C, nullptr, 0, 1, nullptr, 0, 2));
-    RUN(ln(m->bb_x, C, m->bb_xn, C, h16, b.n2, (int)M, C, 1e-6f, st));
-    RUN(linear(m->bb_xn, C, h16, b.fc1, m->bb_h, 4 * C, h16, (int)M, ACT_GELU, st, nullptr, nullptr, 0, nullptr, 0, 1, nullptr, 0, 3));
-    RUN(linear(m->bb_h, 4 * C, h16, b.fc2, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls2, m->bb_x, C, nullptr, 0, 1, nullptr, 0, 4));
+    if (h16) {
+      RUN(linear(m->bb_att, C, true, b.proj, m->bb_y, C, true, (int)M, ACT_NONE, st, b.ls1, nullptr, 0, nullptr, 0, 1, nullptr, 0, 2));
+      RUN(ln(m->bb_x, C, m->bb_xn, C, true, b.n2, (int)M, C, 1e-6f, st, 0, m->bb_y, C));
+      RUN(linear(m->bb_xn, C, true, b.fc1, m->bb_h, 4 * C, true, (int)M, ACT_GELU, st, nullptr, nullptr, 0, nullptr, 0, 1, nullptr, 0, 3));
+      RUN(linear(m->bb_h, 4 * C, true, b.fc2, m->bb_y, C, true, (int)M, ACT_NONE, st, b.ls2, nullptr, 0, nullptr, 0, 1, nullptr, 0, 4));
+      pend = m->bb_y;
+    } else {
+      RUN(linear(m->bb_att, C, false, b.proj, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls1, m->bb_x, C, nullptr, 0, 1, nullptr, 0, 2));
+      RUN(ln(m->bb_x, C, m->bb_xn, C, false, b.n2, (int)M, C, 1e-6f, st));
+      RUN(linear(m->bb_xn, C, false, b.fc1, m->bb_h, 4 * C, false, (int)M, ACT_GELU, st, nullptr, nullptr, 0, nullptr, 0, 1, nullptr, 0, 3));
+      RUN(linear(m->bb_h, 4 * C, false, b.fc2, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls2, m->bb_x, C, nullptr, 0, 1, nullptr, 0, 4));
+    }
   }
-  RUN(ln(m->bb_x, C, feat_out ? feat_out : m->feat, C, false, m->bnorm, (int)M, C, 1e-6f, st, T));
+  RUN(ln(m->bb_x, C, feat_out ? feat_out : m->feat, C, false, m->bnorm, (int)M, C, 1e-6f, st, T, pend, C));
   return 0;
 }
 
@@ -810,6 +824,7 @@ int ec_finalize(ec_handle m) {
   if ((rc = dmalloc(m, &m->bb_xn, MT * C * es))) return rc;
   if ((rc = dmalloc(m, &m->bb_qkv, MT * 3 * C * es))) return rc;
   if ((rc = dmalloc(m, &m->bb_att, MT * C * es))) return rc;
+  if (m->bb16 && (rc = dmalloc(m, &m->bb_y, MT * C * 2))) return rc;
   if ((rc = dmalloc(m, &m->bb_h, std::max(MT * 4 * C, (size_t)n * HW * m->Kp) * es))) return rc;
   if ((rc = dalloc(m, &m->feat, (size_t)n * HW * C))) return rc;
   if ((rc = dalloc(m, &m->feat_nchw_tmp, (size_t)n * HW * C))) return rc;

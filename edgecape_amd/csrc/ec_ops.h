@@ -14,6 +14,10 @@ struct LnP {
   const float* w = nullptr; const float* b = nullptr;
   int rows = 0, cols = 0; float eps = 1e-5f;
   int drop_period = 0;
+  // optional fused residual add (bf16 backbone): x' = x + add (bf16 [rows, ldadd]); x' is written to xsum (may alias x,
+  // same stride) and normalised.  Replaces the fp32 residual read-modify-write in the GEMM epilogue.
+  const void* add = nullptr; long ldadd = 0;
+  float* xsum = nullptr;
 };
 int layernorm(const LnP& p, hipStream_t st);
 

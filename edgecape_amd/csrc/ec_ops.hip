@@ -9,7 +9,7 @@ namespace {
 // LayerNorm: one wave per row, float4 loads, values kept in registers (cols <= 1024).
 // Reference: DINOv2 norm1/norm2/norm (eps 1e-6), head LayerNorms (eps 1e-5, encoder_decoder.py:450-451,566-576).
 // ------------------------------------------------------------------------------------------------
-template <bool OUT_BF16>
+template <bool OUT_BF16, bool ADD>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnP p) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -28,6 +28,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnP p) {
     const int c = (i * 64 + lane) * 4;
     if (c < p.cols) {
       v[i] = *(const f32x4*)(x + c);
+      if (ADD) {   // residual add fused in front of the norm: x <- x + branch (bf16 branch output of the previous GEMM)
+        const bf16x4 a = *(const bf16x4*)((const bf16_t*)p.add + (long)row * p.ldadd + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] += bf2f((bf16_t)a[e]);
+        *(f32x4*)(p.xsum + (long)row * p.ldx + c) = v[i];
+      }
       s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
   }
@@ -476,8 +482,15 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 int layernorm(const LnP& p, hipStream_t st) {
   EC_REQUIRE(p.cols % 4 == 0 && p.cols <= 1024, -1, "layernorm: cols must be a multiple of 4 and <= 1024");
   EC_REQUIRE(p.ldx % 4 == 0 && p.ldy % 4 == 0, -1, "layernorm: strides must be multiples of 4");
-  if (p.y_bf16) hipLaunchKernelGGL(layernorm_kernel<true>, dim3(cdiv(p.rows, 4)), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(layernorm_kernel<false>, dim3(cdiv(p.rows, 4)), dim3(256), 0, st, p);
+  EC_REQUIRE(!p.add || (p.xsum && p.ldadd % 4 == 0), -1, "layernorm: fused residual add needs xsum and a 4-aligned stride");
+  const dim3 grid(cdiv(p.rows, 4));
+  if (p.add) {
+    if (p.y_bf16) hipLaunchKernelGGL((layernorm_kernel<true, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((layernorm_kernel<false, true>), grid, dim3(256), 0, st, p);
+  } else {
+    if (p.y_bf16) hipLaunchKernelGGL((layernorm_kernel<true, false>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((layernorm_kernel<false, false>), grid, dim3(256), 0, st, p);
+  }
   EC_LAUNCH_CHECK();
   return 0;
 }

@@ -54,7 +54,9 @@ def test_linear_identity_layout(lib):
     assert torch.equal(Cd, W.T)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (650, 1152, 384), (1000, 768, 3072)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (650, 1152, 384), (1000, 768, 3072),
+                                   # >= 1024 rows: the 8-phase 256x256x64 kernel (ragged M, N not a multiple of 256, long K)
+                                   (1300, 768, 768), (2600, 1152, 384), (4099, 2304, 768), (1024, 256, 3072), (5000, 1536, 128)])
 def test_linear_bf16(lib, M, N, K):
     g = torch.Generator().manual_seed(1)
     A = torch.randn(M, K, generator=g)
@@ -67,6 +69,38 @@ def test_linear_bf16(lib, M, N, K):
     torch.cuda.synchronize()
     err = (Cd.cpu() - ref).abs().max().item()
     assert err < 2e-4, err   # fp32 accumulation-order noise only
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear_bf16_epilogue(lib, act):
+    """bias + activation + LayerScale + residual epilogue of the 8-phase bf16 kernel (fp32 output)."""
+    M, N, K = 2500, 768, 256
+    g = torch.Generator().manual_seed(7 + act)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    gam = torch.rand(N, generator=g) + 0.5
+    R = torch.randn(M, N, generator=g)
+    ref = A.bfloat16().double() @ W.bfloat16().double().T + b.double()
+    ref = {0: ref, 1: ref.relu(), 2: torch.nn.functional.gelu(ref)}[act]
+    ref = (ref * gam.double() + R.double()).float()
+    Ad, Wd, bd, gd, Rd = (x.cuda() for x in (A, W, b, gam, R))
+    Cd = torch.empty(M, N, device="cuda")
+    _chk(lib, lib.ec_op_linear(_p(Ad), _p(Wd), _p(bd), _p(gd), _p(Rd), _p(Cd), M, N, K, act, 1, None))
+    torch.cuda.synchronize()
+    err = (Cd.cpu() - ref).abs().max().item()
+    assert err < 2e-4, err
+
+
+def test_linear_bf16_identity_layout(lib):
+    """A = [I; I; ...] with an asymmetric W through the 8-phase kernel: C rows must equal W^T rows exactly."""
+    N, K, reps = 512, 256, 5
+    A = torch.eye(K).repeat(reps, 1).cuda()                      # M = 1280
+    W = ((torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 127) - 63).cuda()   # exactly representable in bf16
+    Cd = torch.empty(reps * K, N, device="cuda")
+    _chk(lib, lib.ec_op_linear(_p(A), _p(W), None, None, None, _p(Cd), reps * K, N, K, 0, 1, None))
+    torch.cuda.synchronize()
+    assert torch.equal(Cd, W.T.repeat(reps, 1))
 
 
 @pytest.mark.parametrize("rows,cols,eps", [(100, 256, 1e-5), (650, 384, 1e-6), (37, 768, 1e-6), (9, 1024, 1e-6)])

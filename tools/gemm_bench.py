@@ -14,6 +14,8 @@ SHAPES = [("qkv", 20800, 2304, 768), ("proj", 20800, 768, 768), ("fc1", 20800, 3
 
 def main():
     lib = _lib.load()
+    if os.environ.get("SHAPES"):   # e.g. SHAPES="a:7168:2304:768,b:14336:2304:768"
+        SHAPES[:] = [(n, int(m), int(nn), int(k)) for n, m, nn, k in (x.split(":") for x in os.environ["SHAPES"].split(","))]
     prec = 1 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else 0
     iters = int(os.environ.get("ITERS", 20))
     only = os.environ.get("ONLY")
@@ -28,8 +30,10 @@ def main():
         ms = C.c_float()
         _lib.check(lib.ec_op_gemm_bench(A.data_ptr(), W.data_ptr(), b.data_ptr(), Cd.data_ptr(), M, N, K, prec, iters, None, C.byref(ms)))
         tf = 2.0 * M * N * K / (ms.value * 1e-3) / 1e12
-        ref = (A.float() @ W.float().T + b)
-        err = (Cd.float() - ref).abs().max().item()
+        err = float("nan")
+        if not os.environ.get("NOCHECK"):
+            ref = (A.float() @ W.float().T + b)
+            err = (Cd.float() - ref).abs().max().item()
         print(f"{name:8s} M={M} N={N} K={K} {'bf16' if prec else 'fp32'}: {ms.value * 1e3:8.1f} us  {tf:7.1f} TFLOP/s  max|err|={err:.3g}", flush=True)
 
 
