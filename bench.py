@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--arch", default="dinov2_vitb14")
     ap.add_argument("--precision", default=os.environ.get("EC_BENCH_PRECISION", "bf16"), choices=["bf16", "fp32"],
                     help="backbone MFMA operand type (fp32 accumulate); the head is fp32")
+    ap.add_argument("--head-precision", default=os.environ.get("EC_BENCH_HEAD_PRECISION", "bf16x3"), choices=["fp32", "bf16x3"],
+                    help="head GEMMs: exact fp32 MFMA, or split-bf16 (hi+lo, 3 MFMAs per product; fp32-class accuracy)")
     ap.add_argument("--cpu-sample", type=int, default=4, help="pairs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -72,7 +74,8 @@ def main():
     g = H // 14
     T = g * g + 1
     sd = synth.make_weights(arch, seed=0)
-    eng = HipEngine(sd, arch=arch, image_size=H, max_batch=bs, max_shots=S, backbone_precision=args.precision)
+    eng = HipEngine(sd, arch=arch, image_size=H, max_batch=bs, max_shots=S, backbone_precision=args.precision,
+                    head_precision=args.head_precision)
 
     # this rank's shard: global pair indices rank*bs .. rank*bs+bs-1 (fixed per-GPU work => weak scaling)
     batch = synth.make_pairs(bs, S, H, seed=1000, first_index=rank * bs, fixed_n_kp=False)
@@ -146,7 +149,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"{S}-shot split1-style synthetic pairs, batch={bs}/GPU, {H}x{H}, {arch}, K=100 padded keypoints, "
-                                   f"backbone {args.precision} MFMA / fp32 accumulate, head fp32",
+                                   f"backbone {args.precision} MFMA / fp32 accumulate, head {args.head_precision}",
                        "global_batch": world * bs, "parallelism": f"dp{world} (independent pair shards, one all-reduce of PCK counters)"},
             "roofline": {"bound": "mfma", "kernel": f"backbone QKV GEMM M={Mq} K={Kq} N={Nq} ({args.precision})",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),

@@ -13,7 +13,7 @@ from . import build as _build
 
 _LIB = None
 
-EC_F32, EC_BF16 = 0, 1
+EC_F32, EC_BF16, EC_BF16X3 = 0, 1, 2
 EC_DT_F32, EC_DT_F16, EC_DT_BF16, EC_DT_F64 = 0, 1, 2, 3
 EC_LAYOUT_TOKENS, EC_LAYOUT_NCHW = 0, 1
 

@@ -98,10 +98,13 @@ struct GemmP {
   int act = ACT_NONE;
   int c_bf16 = 0;   // store C as bf16
   int ab_bf16 = 0;  // A and B are bf16 (else fp32)
+  int split = 0;    // bf16x3: A fp32, B pre-split into [32 hi | 32 lo] bf16 per 32-k block (split_pack_weights)
   int tag = 0;      // kernel-symbol tag (profiling only): 1 qkv, 2 proj, 3 fc1, 4 fc2
   int dbg = 0;      // timing experiments (EC_G8_DBG): bit 0 = skip the C stores
 };
 int gemm_nt(const GemmP& p, hipStream_t st);
+// host: W [N,K] fp32 -> bf16x3 packing of the same byte size: per row, per 32-k block, 32 hi bf16 then 32 lo bf16
+void split_pack_weights(const float* W, long n_rows, long K, float* out);
 // 256x256x64 8-phase bf16 kernel (ec_gemm8.hip): 1 = handled, 0 = shape not eligible (use gemm_nt's own kernels), < 0 error
 int gemm8_bf16(const GemmP& p, hipStream_t st);
 

@@ -66,8 +66,32 @@ __device__ inline float gelu_fast(float x) {
 // accumulator lane holds ONE output row m and 4 consecutive columns n per register quad: the epilogue
 // then writes 16-byte row segments (after a v_permlane32_swap pairing of the two half-waves) instead of
 // scalar elements.  TAG only separates kernel symbols for rocprof (1 qkv, 2 proj, 3 fc1, 4 fc2).
-template <bool BF16, int BM, int BN, int WGM, int WGN, int TAG>
+// MODE 0: fp32 operands, exact (v_mfma_f32_32x32x2_f32).  MODE 1: bf16 operands.  MODE 2 ("bf16x3"): A is fp32 in memory and
+// is split in registers into hi + lo bf16 (hi = RNE(a), lo = RNE(a - hi), a - hi exact), B is the weight matrix PRE-SPLIT on
+// the host into the same 128-byte K-blocks ([32 hi | 32 lo] bf16 per 32 k) so staging and addressing are those of fp32;
+// acc += hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate): ~2^-17 relative operand error at 16/3 of the
+// fp32 MFMA rate — the head's throughput mode (the head is 6 % of the FLOPs; keeping it fp32-class keeps the 1e-3 gate).
+enum { GM_F32 = 0, GM_BF16 = 1, GM_SPLIT = 2 };
+
+__device__ __forceinline__ void split8(const f32x4 x0, const f32x4 x1, bf16x8& hi, bf16x8& lo) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16v2;
+  unsigned h[4], l[4];
+  const float f[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    h[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{f[2 * q], f[2 * q + 1]}, bf16v2));
+    const float r0 = f[2 * q] - __uint_as_float(h[q] << 16);
+    const float r1 = f[2 * q + 1] - __uint_as_float(h[q] & 0xffff0000u);
+    l[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16v2));
+  }
+  hi = __builtin_bit_cast(bf16x8, u32x4{h[0], h[1], h[2], h[3]});
+  lo = __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], l[2], l[3]});
+}
+
+template <int MODE, int BM, int BN, int WGM, int WGN, int TAG>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_nt_kernel(GemmP p) {
+  constexpr bool BF16 = MODE == GM_BF16;
   constexpr int NW = WGM * WGN;
   constexpr int MT = BM / WGM / 32, NT = BN / WGN / 32;
   constexpr int A_BYTES = BM * KBYTES, B_BYTES = BN * KBYTES, STAGE = A_BYTES + B_BYTES;
@@ -133,6 +157,35 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_nt_kernel(GemmP p) {
       else if (tn < t_end) stage(bz2, m02, n02, 0, nxt);   // next tile's first K-step lands under this tile's epilogue
       const char* At = smem + cur * STAGE;
       const char* Bt = At + A_BYTES;
+      if constexpr (MODE == GM_SPLIT) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {   // two 16-k MFMA steps per 32-k stage
+          bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+          for (int j = 0; j < MT; ++j) {
+            const int ra = wm * (BM / WGM) + j * 32 + lrow;
+            const int sw = (ra >> 1) & 7, c0 = ks * 4 + hi * 2;
+            const f32x4 x0 = *(const f32x4*)(At + ra * KBYTES + ((c0 ^ sw) << 4));
+            const f32x4 x1 = *(const f32x4*)(At + ra * KBYTES + (((c0 + 1) ^ sw) << 4));
+            split8(x0, x1, ah[j], al[j]);
+          }
+#pragma unroll
+          for (int i = 0; i < NT; ++i) {
+            const int rb = wn * (BN / WGN) + i * 32 + lrow;
+            const int sw = (rb >> 1) & 7, c0 = ks * 2 + hi;
+            bh[i] = *(const bf16x8*)(Bt + rb * KBYTES + ((c0 ^ sw) << 4));
+            bl[i] = *(const bf16x8*)(Bt + rb * KBYTES + (((4 + c0) ^ sw) << 4));
+          }
+#pragma unroll
+          for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[i], ah[j], acc[i][j], 0, 0, 0);   // small terms first
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[i], al[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[i], ah[j], acc[i][j], 0, 0, 0);
+            }
+        }
+      } else
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int chunkk = 2 * kk + hi;
@@ -334,12 +387,12 @@ __global__ __launch_bounds__(256) void bgemm_small_kernel(BgemmP p) {
 
 namespace {
 struct Cfg { int bm, bn, threads, lds, per_cu; };
-template <bool BF16, int BM, int BN, int WGM, int WGN>
+template <int MODE, int BM, int BN, int WGM, int WGN>
 int launch_cfg(const GemmP& p, hipStream_t st, int per_cu) {
   typedef void (*kern_t)(GemmP);
-  static const kern_t table[5] = {gemm_nt_kernel<BF16, BM, BN, WGM, WGN, 0>, gemm_nt_kernel<BF16, BM, BN, WGM, WGN, 1>,
-                                  gemm_nt_kernel<BF16, BM, BN, WGM, WGN, 2>, gemm_nt_kernel<BF16, BM, BN, WGM, WGN, 3>,
-                                  gemm_nt_kernel<BF16, BM, BN, WGM, WGN, 4>};
+  static const kern_t table[5] = {gemm_nt_kernel<MODE, BM, BN, WGM, WGN, 0>, gemm_nt_kernel<MODE, BM, BN, WGM, WGN, MODE == GM_SPLIT ? 0 : 1>,
+                                  gemm_nt_kernel<MODE, BM, BN, WGM, WGN, MODE == GM_SPLIT ? 0 : 2>, gemm_nt_kernel<MODE, BM, BN, WGM, WGN, MODE == GM_SPLIT ? 0 : 3>,
+                                  gemm_nt_kernel<MODE, BM, BN, WGM, WGN, MODE == GM_SPLIT ? 0 : 4>};
   constexpr int LDS = 2 * (BM + BN) * KBYTES;
   static bool attr_done = false;
   if (!attr_done) {
@@ -373,27 +426,71 @@ int gemm_nt(const GemmP& p, hipStream_t st) {
   EC_REQUIRE(!p.table || (p.ldt % 4 == 0), -1, "gemm_nt: table stride must be a multiple of 4");
   EC_REQUIRE(p.act != ACT_TANHGATE || p.aux, -1, "gemm_nt: tanh-gate epilogue needs aux");
   EC_REQUIRE(p.tag >= 0 && p.tag < 5, -1, "gemm_nt: bad tag");
+  EC_REQUIRE(!(p.split && p.ab_bf16), -1, "gemm_nt: split (bf16x3) mode takes fp32 A and a pre-split B");
   if (p.ab_bf16) {   // large bf16 problems: the 8-phase 256x256x64 kernel
     const int rc = gemm8_bf16(p, st);
     if (rc != 0) return rc < 0 ? rc : 0;
   }
-  // tile choice: 256x256 (8 waves, 1 workgroup/CU) for the big backbone GEMMs, 256x128 when N is not a multiple of
-  // 256, 128x128 (4 waves, 2 workgroups/CU) for the small head GEMMs.
+  // Tile choice.  The fp32 MFMA rate (64 FLOP/clk/SIMD = 614 GFLOP/s per CU) is reached by any of these tiles, so what
+  // matters for the head's small problems (M = bs*K = 3200 rows, N = 256) is how evenly the tiles spread over the 256
+  // CUs: pick the tile minimising  ceil(tiles / CUs) * tile_area / efficiency.  256x256 only pays for the big backbone
+  // GEMMs (fp32 parity mode) where operand re-reads dominate.
   static const int force = getenv("EC_GEMM_TILE") ? atoi(getenv("EC_GEMM_TILE")) : 0;
-  int sel;
-  const long work = (long)p.M * p.batch;
-  if (work >= 4096 && p.N >= 512 && p.N % 256 == 0) sel = 2;
-  else if (work >= 4096 && p.N >= 384) sel = 1;
-  else sel = 0;
-  if (force == 128) sel = 0; else if (force == 256128) sel = 1; else if (force == 256) sel = 2;
-  if (p.ab_bf16) {
-    if (sel == 2) return launch_cfg<true, 256, 256, 2, 4>(p, st, 1);
-    if (sel == 1) return launch_cfg<true, 256, 128, 4, 2>(p, st, 1);
-    return launch_cfg<true, 128, 128, 2, 2>(p, st, 2);
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    EC_HIP(hipGetDevice(&dev));
+    EC_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
   }
-  if (sel == 2) return launch_cfg<false, 256, 256, 2, 4>(p, st, 1);
-  if (sel == 1) return launch_cfg<false, 256, 128, 4, 2>(p, st, 1);
-  return launch_cfg<false, 128, 128, 2, 2>(p, st, 2);
+  struct Opt { int bm, bn; float eff; };
+  static const Opt opts[5] = {{256, 256, 1.00f}, {256, 128, 1.00f}, {128, 128, 0.95f}, {128, 64, 0.85f}, {64, 64, 0.75f}};
+  int sel = 2;
+  float best = 1e30f;
+  for (int i = 0; i < 5; ++i) {
+    const long nt = (long)((p.M + opts[i].bm - 1) / opts[i].bm) * ((p.N + opts[i].bn - 1) / opts[i].bn) * p.batch;
+    const float cost = (float)((nt + ncu - 1) / ncu) * (float)(opts[i].bm * opts[i].bn) / opts[i].eff;
+    if (cost < best) { best = cost; sel = i; }
+  }
+  if (force == 256) sel = 0; else if (force == 256128) sel = 1; else if (force == 128) sel = 2; else if (force == 12864) sel = 3;
+  else if (force == 64) sel = 4;
+  if (p.ab_bf16) {
+    switch (sel) {
+      case 0: return launch_cfg<GM_BF16, 256, 256, 2, 4>(p, st, 1);
+      case 1: return launch_cfg<GM_BF16, 256, 128, 4, 2>(p, st, 1);
+      case 2: return launch_cfg<GM_BF16, 128, 128, 2, 2>(p, st, 2);
+      case 3: return launch_cfg<GM_BF16, 128, 64, 2, 2>(p, st, 3);
+      default: return launch_cfg<GM_BF16, 64, 64, 2, 2>(p, st, 4);
+    }
+  }
+  if (p.split) {
+    switch (sel) {
+      case 0: return launch_cfg<GM_SPLIT, 256, 256, 2, 4>(p, st, 1);
+      case 1: return launch_cfg<GM_SPLIT, 256, 128, 4, 2>(p, st, 1);
+      case 2: return launch_cfg<GM_SPLIT, 128, 128, 2, 2>(p, st, 2);
+      case 3: return launch_cfg<GM_SPLIT, 128, 64, 2, 2>(p, st, 3);
+      default: return launch_cfg<GM_SPLIT, 64, 64, 2, 2>(p, st, 4);
+    }
+  }
+  switch (sel) {
+    case 0: return launch_cfg<GM_F32, 256, 256, 2, 4>(p, st, 1);
+    case 1: return launch_cfg<GM_F32, 256, 128, 4, 2>(p, st, 1);
+    case 2: return launch_cfg<GM_F32, 128, 128, 2, 2>(p, st, 2);
+    case 3: return launch_cfg<GM_F32, 128, 64, 2, 2>(p, st, 3);
+    default: return launch_cfg<GM_F32, 64, 64, 2, 2>(p, st, 4);
+  }
+}
+
+void split_pack_weights(const float* W, long n_rows, long K, float* out) {
+  for (long r = 0; r < n_rows; ++r)
+    for (long kb = 0; kb < K / 32; ++kb) {
+      const float* src = W + r * K + kb * 32;
+      bf16_t* dst = (bf16_t*)(out + r * K + kb * 32);
+      for (int j = 0; j < 32; ++j) {
+        const bf16_t h = f2bf(src[j]);
+        dst[j] = h;
+        dst[32 + j] = f2bf(src[j] - bf2f(h));
+      }
+    }
 }
 
 int bgemm_small(const BgemmP& p, hipStream_t st) {

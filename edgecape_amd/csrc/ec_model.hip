@@ -38,14 +38,17 @@ struct Tensor {
 struct Lin {  // a Linear layer view: W [N,K] (+ optional bf16 copy), bias [N]
   const float* w = nullptr;
   const bf16_t* w16 = nullptr;
+  const float* ws = nullptr;   // bf16x3 split-packed copy (head_precision = EC_BF16X3), same byte size as w
   const float* b = nullptr;
   int N = 0, K = 0;
+  const void* wsel(bool split) const { return split ? (const void*)ws : (const void*)w; }
 };
 struct Norm { const float* w = nullptr; const float* b = nullptr; };
 
 struct BBlock { Norm n1, n2; Lin qkv, proj, fc1, fc2; const float* ls1 = nullptr; const float* ls2 = nullptr; };
 
 struct DecLayer {
+  std::vector<float> h_kv_w, h_kv_table;   // host copies of ca_kv weights / positional table (stacked across layers at finalize)
   Lin sa_in, sa_out;                 // self-attention in/out projections (fused [3d, d])
   const float *m_w1 = nullptr, *m_b1 = nullptr, *m_w2 = nullptr, *m_b2 = nullptr;  // markov_structural_mlp
   Lin ca_q, ca_kv, ca_fold;          // cross-attention: Q proj, fused K|V proj of image tokens, out_proj∘choker
@@ -68,6 +71,7 @@ struct ec_model {
   int Kp = 640;  // padded im2col width (588 -> 640: multiple of 128 bytes for fp32 and bf16)
   bool finalized = false;
   bool bb16 = false;
+  bool head_split = false;   // head GEMMs in bf16x3 (ec_gemm.hip GM_SPLIT)
   std::unordered_map<std::string, Tensor> tensors;
   std::vector<void*> owned;  // every hipMalloc'd pointer
   std::unordered_map<std::string, std::pair<const float*, long>> taps;
@@ -88,6 +92,7 @@ struct ec_model {
   std::vector<EncLayer> enc;
   Norm dec_norm;
   Lin rp0, rp1, pg_support, pg_query, pg_dyn0, pg_dyn2;
+  Lin dec_kv_all; const float* dec_kv_table = nullptr;   // decoder cross-attention K|V projections of all layers, stacked
   std::vector<KptBranch> kpt;
 
   // workspace (device)
@@ -134,6 +139,13 @@ static int upload16(ec_model* m, const std::vector<float>& h, const bf16_t** out
   return 0;
 }
 
+static int upload_split(ec_model* m, const float* W, long rows, long K, const float** out) {
+  EC_REQUIRE(K % 32 == 0, EC_ERR_ARG, "bf16x3 packing needs K % 32 == 0");
+  std::vector<float> packed((size_t)rows * K);
+  split_pack_weights(W, rows, K, packed.data());
+  return upload(m, packed, out);
+}
+
 static const Tensor* find(ec_model* m, const std::string& name) {
   auto it = m->tensors.find(name);
   return it == m->tensors.end() ? nullptr : &it->second;
@@ -143,6 +155,7 @@ static const Tensor* find(ec_model* m, const std::string& name) {
   const Tensor* var = find(m, name);                                             \
   if (!var) { set_error(std::string("missing tensor: ") + (name)); return EC_ERR_STATE; }
 
+static bool name_is_head(const std::string& n) { return n.compare(0, 21, "keypoint_head_module.") == 0; }
 static int make_lin(ec_model* m, const std::string& wname, const std::string& bname, Lin* out, bool want16) {
   GET(w, wname);
   out->w = w->dev;
@@ -155,6 +168,9 @@ static int make_lin(ec_model* m, const std::string& wname, const std::string& bn
   if (want16) {
     int rc = upload16(m, w->host, &out->w16);
     if (rc) return rc;
+  } else if (m->head_split && name_is_head(wname)) {
+    int rc = upload_split(m, w->host.data(), out->N, out->K, &out->ws);
+    if (rc) return rc;
   }
   return 0;
 }
@@ -162,6 +178,7 @@ static int make_lin_host(ec_model* m, const std::vector<float>& W, const std::ve
   out->N = N; out->K = K;
   int rc = upload(m, W, &out->w);
   if (rc) return rc;
+  if (m->head_split && (rc = upload_split(m, W.data(), N, K, &out->ws))) return rc;   // make_lin_host is only used by the head
   if (!b.empty()) rc = upload(m, b, &out->b);
   return rc;
 }
@@ -264,6 +281,7 @@ static int build_dec_layer(ec_model* m, const std::string& P, bool biased, bool 
         for (int n = 0; n < E; ++n) tb[(size_t)t * 2 * E + E + n] = bv[n];
       }
       if ((r = upload(m, tb, kv_table))) return r;
+      L->h_kv_w = Wkv; L->h_kv_table = tb;
     }
     // ---- out_proj followed by choker, no non-linearity in between (encoder_decoder.py:624-631): fold
     std::vector<float> Wf((size_t)d * E), bf(d);
@@ -301,7 +319,8 @@ static int linear(const void* A, long lda, bool a16, const Lin& W, void* C, long
   GemmP p;
   p.tag = tag;
   p.A = A; p.lda = lda; p.ab_bf16 = a16 ? 1 : 0;
-  p.B = a16 ? (const void*)W.w16 : (const void*)W.w; p.ldb = W.K;
+  p.split = (!a16 && W.ws) ? 1 : 0;     // head in bf16x3 mode: every head Lin carries a split-packed copy
+  p.B = a16 ? (const void*)W.w16 : W.wsel(p.split); p.ldb = W.K;
   EC_REQUIRE(p.B != nullptr, EC_ERR_STATE, "linear: weight copy for this precision was not built");
   p.C = C; p.ldc = ldc; p.c_bf16 = c16 ? 1 : 0;
   p.bias = W.b; p.gamma = gamma; p.resid = resid; p.ldr = ldr; p.table = table; p.ldt = ldt; p.period = period;
@@ -402,6 +421,8 @@ struct LayerIO {
   const float* bias;   // [nb, nhead, K, K] or null
   int nb, bs;
   bool update_mem;
+  const float* kv_pre = nullptr;   // if set: K|V of the image tokens were projected beforehand ([nb, HW, ld_kv_pre], K at +0, V at +E)
+  long ld_kv_pre = 0;
 };
 
 static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool biased, bool two_way, float* qkv, float* att,
@@ -426,17 +447,22 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
   // ---- cross attention tokens -> image (hd = E/nh = 64); Q input is [x | init_pos] (K = 2d) in the main decoder
   RUN(linear(io.x, io.ldx, false, L.ca_q, qc, E, false, Mk, ACT_NONE, st));
   {
-    GemmP p;  // K|V of the image tokens, one batch entry per sample (mem may be a strided view)
-    p.A = io.mem; p.lda = d; p.sA = io.s_mem;
-    p.B = L.ca_kv.w; p.ldb = d;
-    p.C = kv; p.ldc = 2 * E; p.sC = (long)HW * 2 * E;
-    p.table = L.ca_kv_table; p.ldt = 2 * E; p.period = HW;
-    p.M = HW; p.N = 2 * E; p.K = d; p.batch = io.nb;
-    RUN(gemm_nt(p, st));
+    const float* kvp = io.kv_pre;
+    long ldkv = io.ld_kv_pre;
+    if (!kvp) {
+      GemmP p;  // K|V of the image tokens, one batch entry per sample (mem may be a strided view)
+      p.A = io.mem; p.lda = d; p.sA = io.s_mem;
+      p.split = L.ca_kv.ws ? 1 : 0; p.B = L.ca_kv.wsel(p.split); p.ldb = d;
+      p.C = kv; p.ldc = 2 * E; p.sC = (long)HW * 2 * E;
+      p.table = L.ca_kv_table; p.ldt = 2 * E; p.period = HW;
+      p.M = HW; p.N = 2 * E; p.K = d; p.batch = io.nb;
+      RUN(gemm_nt(p, st));
+      kvp = kv; ldkv = 2 * E;
+    }
     AttnP a;
-    a.Q = qc; a.K = kv; a.V = kv + E; a.O = att;
-    a.ldq = E; a.ldk = a.ldv = 2 * E; a.ldo = E;
-    a.sQ = (long)K * E; a.sK = a.sV = (long)HW * 2 * E; a.sO = (long)K * E;
+    a.Q = qc; a.K = kvp; a.V = kvp + E; a.O = att;
+    a.ldq = E; a.ldk = a.ldv = ldkv; a.ldo = E;
+    a.sQ = (long)K * E; a.sK = a.sV = (long)HW * ldkv; a.sO = (long)K * E;
     a.B = io.nb; a.H = nh; a.Lq = K; a.Lk = HW; a.hd = E / nh;
     RUN(attention(a, st));
   }
@@ -499,7 +525,7 @@ static int run_head(ec_model* m, const float* fq, const float* const* fs, const 
   {
     GemmP p;
     p.A = fq; p.lda = C; p.sA = (long)HW * C;
-    p.B = m->input_proj.w; p.ldb = C; p.bias = m->input_proj.b;
+    p.split = m->input_proj.ws ? 1 : 0; p.B = m->input_proj.wsel(p.split); p.ldb = C; p.bias = m->input_proj.b;
     p.C = m->e_x; p.ldc = d; p.sC = (long)L * d;
     p.M = HW; p.N = d; p.K = C; p.batch = bs;
     RUN(gemm_nt(p, st));
@@ -589,11 +615,11 @@ static int run_head(ec_model* m, const float* fq, const float* const* fs, const 
   // (5) proposal generator (encoder_decoder.py:49-112)
   {
     GemmP p;
-    p.A = kp; p.lda = d; p.sA = s_tok; p.B = m->pg_support.w; p.ldb = d; p.bias = m->pg_support.b;
+    p.A = kp; p.lda = d; p.sA = s_tok; p.split = m->pg_support.ws ? 1 : 0; p.B = m->pg_support.wsel(p.split); p.ldb = d; p.bias = m->pg_support.b;
     p.C = m->p_fs; p.ldc = d; p.sC = (long)K * d; p.M = K; p.N = d; p.K = d; p.batch = bs;
     RUN(gemm_nt(p, st));
     GemmP q;
-    q.A = mem; q.lda = d; q.sA = s_tok; q.B = m->pg_query.w; q.ldb = d; q.bias = m->pg_query.b;
+    q.A = mem; q.lda = d; q.sA = s_tok; q.split = m->pg_query.ws ? 1 : 0; q.B = m->pg_query.wsel(q.split); q.ldb = d; q.bias = m->pg_query.b;
     q.C = m->p_fq; q.ldc = d; q.sC = (long)HW * d; q.M = HW; q.N = d; q.K = d; q.batch = bs;
     RUN(gemm_nt(q, st));
   }
@@ -611,6 +637,17 @@ static int run_head(ec_model* m, const float* fq, const float* const* fs, const 
 
   // (6) decoder (encoder_decoder.py:330-425): x lives as the left half of d_qin = [x | qpe]
   RUN(copy3d(m->d_qin, 2 * d, (long)K * 2 * d, kp, d, s_tok, bs, K, d, st));
+  const int nL = (int)m->dec.size();
+  {  // the decoder never updates the image memory (two_way_attn=False, encoder_decoder.py:638): project K|V of the image
+     // tokens for ALL decoder layers in one GEMM (stacked weights [nL*2E, d], stacked positional tables [HW, nL*2E])
+    GemmP p;
+    p.A = mem; p.lda = d; p.sA = s_tok;
+    p.split = m->dec_kv_all.ws ? 1 : 0; p.B = m->dec_kv_all.wsel(p.split); p.ldb = d;
+    p.C = m->d_kv; p.ldc = (long)nL * 2 * E; p.sC = (long)HW * nL * 2 * E;
+    p.table = m->dec_kv_table; p.ldt = (long)nL * 2 * E; p.period = HW;
+    p.M = HW; p.N = nL * 2 * E; p.K = d; p.batch = bs;
+    RUN(gemm_nt(p, st));
+  }
   for (size_t li = 0; li < m->dec.size(); ++li) {
     const DecLayer& Ld = m->dec[li];
     float* bi = pts + (long)li * Mk * 2;
@@ -622,6 +659,7 @@ static int run_head(ec_model* m, const float* fq, const float* const* fs, const 
     io.x = m->d_qin; io.ldx = 2 * d; io.mem = mem; io.s_mem = s_tok;
     io.adj1 = m->adj1; io.valid = m->valid; io.kmask_fixed = m->kmask_fixed; io.bias = m->d_bias;
     io.nb = bs; io.bs = bs; io.update_mem = false;
+    io.kv_pre = m->d_kv + (long)li * 2 * E; io.ld_kv_pre = (long)nL * 2 * E;
     RUN(run_dec_layer(m, Ld, io, true, false, m->d_qkv, m->d_att, m->d_tmp, m->d_qc, m->d_kv, m->d_y, m->d_z, nullptr, nullptr,
                       nullptr, nullptr, Fd, st));
     RUN(ln(m->d_qin, 2 * d, m->d_hs + (long)li * Mk * d, d, false, m->dec_norm, Mk, d, 1e-5f, st));
@@ -674,7 +712,8 @@ int ec_create(const ec_config* cfg, ec_handle* out) {
   EC_REQUIRE(cfg->d_model == 256 && cfg->nhead == 8, EC_ERR_ARG, "head d_model/nhead must be 256/8");
   EC_REQUIRE(cfg->num_kpts > 0 && cfg->num_kpts <= 128 && cfg->num_kpts % 4 == 0, EC_ERR_ARG, "num_kpts must be a multiple of 4, <= 128");
   EC_REQUIRE(cfg->max_hops == 4, EC_ERR_ARG, "max_hops must be 4");
-  EC_REQUIRE(cfg->head_precision == EC_F32, EC_ERR_ARG, "head_precision: only EC_F32 is built");
+  EC_REQUIRE(cfg->head_precision == EC_F32 || cfg->head_precision == EC_BF16X3, EC_ERR_ARG,
+             "head_precision: EC_F32 (exact) or EC_BF16X3 (split-bf16 MFMA, fp32-class accuracy)");
   EC_REQUIRE(cfg->max_batch > 0 && cfg->max_shots > 0, EC_ERR_ARG, "max_batch / max_shots must be positive");
   ec_model* m = new ec_model();
   m->cfg = *cfg;
@@ -682,6 +721,7 @@ int ec_create(const ec_config* cfg, ec_handle* out) {
   m->HW = m->g * m->g; m->T = m->HW + 1; m->C = cfg->embed_dim; m->K = cfg->num_kpts; m->d = cfg->d_model;
   m->L = m->HW + m->K; m->E = 2 * m->d;
   m->bb16 = cfg->backbone_precision == EC_BF16;
+  m->head_split = cfg->head_precision == EC_BF16X3;
   EC_REQUIRE(m->g >= 2 && m->g <= 32, EC_ERR_ARG, "token grid must be within 2..32");
   *out = m;
   return EC_OK;
@@ -781,6 +821,19 @@ int ec_finalize(ec_handle m) {
   for (int i = 0; i < m->cfg.dec_layers; ++i)
     if ((rc = build_dec_layer(m, hp + "transformer.decoder.layers." + std::to_string(i) + ".", true, false, pos_img, &m->dec[i])))
       return rc;
+  {  // stack the decoder layers' K|V projections: W [nL*2E, d], table [HW, nL*2E]
+    const int nL = m->cfg.dec_layers;
+    std::vector<float> W((size_t)nL * 2 * E * d), tb((size_t)HW * nL * 2 * E);
+    for (int l = 0; l < nL; ++l) {
+      memcpy(&W[(size_t)l * 2 * E * d], m->dec[l].h_kv_w.data(), (size_t)2 * E * d * sizeof(float));
+      for (int t = 0; t < HW; ++t)
+        memcpy(&tb[((size_t)t * nL + l) * 2 * E], &m->dec[l].h_kv_table[(size_t)t * 2 * E], (size_t)2 * E * sizeof(float));
+    }
+    if ((rc = make_lin_host(m, W, {}, nL * 2 * E, d, &m->dec_kv_all))) return rc;
+    if ((rc = upload(m, tb, &m->dec_kv_table))) return rc;
+    for (auto& l : m->dec) { std::vector<float>().swap(l.h_kv_w); std::vector<float>().swap(l.h_kv_table); }
+    for (auto& l : m->skel) { std::vector<float>().swap(l.h_kv_w); std::vector<float>().swap(l.h_kv_table); }
+  }
   for (auto& l : m->skel) EC_REQUIRE(l.ffn1.N == 2 * m->cfg.skel_ffn_dim, EC_ERR_ARG, "skeleton GCN width mismatch");
   for (auto& l : m->dec) EC_REQUIRE(l.ffn1.N == 2 * m->cfg.ffn_dim, EC_ERR_ARG, "decoder GCN width mismatch");
   m->enc.resize(m->cfg.enc_layers);
@@ -842,7 +895,7 @@ int ec_finalize(ec_handle m) {
   WS(e_x, Me * d); WS(e_qkv, Me * 3 * d); WS(e_att, Me * d); WS(e_tmp, Me * d); WS(e_h, Me * Fd);
   WS(p_fs, Mk * d); WS(p_fq, Mi * d); WS(p_g1, Mk * 128); WS(p_fs2, Mk * d);
   WS(d_qin, Mk * 2 * d); WS(d_sc, Mk * d); WS(d_rp, Mk * d); WS(d_bias, (size_t)bs * m->cfg.nhead * KK); WS(d_qkv, Mk * 3 * d);
-  WS(d_att, Mk * E); WS(d_tmp, Mk * d); WS(d_qc, Mk * E); WS(d_kv, Mi * 2 * E); WS(d_y, Mk * 2 * Fd); WS(d_z, Mk * Fd);
+  WS(d_att, Mk * E); WS(d_tmp, Mk * d); WS(d_qc, Mk * E); WS(d_kv, Mi * 2 * E * m->cfg.dec_layers); WS(d_y, Mk * 2 * Fd); WS(d_z, Mk * Fd);
   WS(d_hs, 3 * Mk * d); WS(d_pts, 4 * Mk * 2); WS(d_k1, Mk * d); WS(d_k2, Mk * d);
 #undef WS
   EC_REQUIRE(m->pg_dyn0.N <= 128, EC_ERR_ARG, "dynamic_proj_dim must be <= 128");
@@ -968,6 +1021,21 @@ int ec_op_linear(const float* A, const float* W, const float* bias, const float*
     (void)hipFree(a16); (void)hipFree(w16);
     return rc;
   }
+  if (precision == EC_BF16X3) {   // W is split-packed on the host (as ec_finalize does for the head weights), A stays fp32
+    EC_REQUIRE(K % 32 == 0, EC_ERR_ARG, "bf16x3 needs K % 32 == 0");
+    std::vector<float> hw((size_t)N * K), packed((size_t)N * K);
+    EC_HIP(hipStreamSynchronize(st));
+    EC_HIP(hipMemcpy(hw.data(), W, hw.size() * 4, hipMemcpyDeviceToHost));
+    split_pack_weights(hw.data(), N, K, packed.data());
+    float* ws = nullptr;
+    EC_HIP(hipMalloc((void**)&ws, packed.size() * 4));
+    EC_HIP(hipMemcpy(ws, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+    p.A = A; p.B = ws; p.split = 1;
+    int rc = gemm_nt(p, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(ws);
+    return rc;
+  }
   p.A = A; p.B = W;
   return gemm_nt(p, st);
 }
@@ -979,6 +1047,7 @@ int ec_op_gemm_bench(const void* A, const void* W, const float* bias, void* C, i
   GemmP p;
   p.A = A; p.B = W; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N;
   p.ab_bf16 = precision == EC_BF16; p.c_bf16 = p.ab_bf16;
+  p.split = precision == EC_BF16X3;   // timing only: W is interpreted as an already split-packed buffer
   hipEvent_t e0, e1;
   EC_HIP(hipEventCreate(&e0));
   EC_HIP(hipEventCreate(&e1));

@@ -46,7 +46,11 @@ enum ec_status {
   EC_ERR_NODEVICE = -5   /* no gfx950 device visible */
 };
 
-enum ec_precision { EC_F32 = 0, EC_BF16 = 1 };
+enum ec_precision {
+  EC_F32 = 0,     /* fp32 operands, exact products (v_mfma_f32_32x32x2_f32) */
+  EC_BF16 = 1,    /* bf16 operands, fp32 accumulate */
+  EC_BF16X3 = 2   /* fp32 data, each operand split into hi+lo bf16, 3 bf16 MFMAs per product: ~2^-17 relative (head only) */
+};
 enum ec_dtype { EC_DT_F32 = 0, EC_DT_F16 = 1, EC_DT_BF16 = 2, EC_DT_F64 = 3 };
 enum ec_layout { EC_LAYOUT_TOKENS = 0, EC_LAYOUT_NCHW = 1 };
 
@@ -69,7 +73,7 @@ typedef struct ec_config {
   int32_t max_shots;          /* S_max */
   int32_t max_batch;          /* bs_max (pairs per call) */
   int32_t backbone_precision; /* ec_precision: operand type of the backbone MFMA GEMMs/attention (fp32 accumulate always) */
-  int32_t head_precision;     /* ec_precision for the head */
+  int32_t head_precision;     /* EC_F32 or EC_BF16X3: GEMM operand handling in the head (attention/LayerNorm/softmax stay fp32) */
 } ec_config;
 
 typedef struct ec_outputs {

@@ -154,6 +154,51 @@ def test_forward_vs_oracle_vitb_256():
     assert np.abs(o["adj"].cpu().numpy() - out_ref["adj"].numpy()).max() < 1e-4
 
 
+@pytest.mark.parametrize("name", ["head_s1_c384_g16_kp17", "head_s5_c768_g18_kp17"])
+def test_head_bf16x3_vs_reference_golden(name):
+    """Head throughput mode (split-bf16 GEMMs, everything else fp32) still meets the fp32 parity gate against the
+    REAL reference's outputs: 1e-3 abs on output keypoints (observed ~1e-5), no argmax flips."""
+    gold, meta = load_golden(name)
+    C, g = meta["C"], meta["g"]
+    arch = ARCH_OF_C[C]
+    sd = synth.make_backbone_weights(arch, seed=3)
+    sd.update(synth.make_head_weights(C=C, seed=meta["weight_seed"]))
+    inp = synth.make_head_inputs(len(meta["n_kps"]), meta["shots"], C, g, meta["input_seed"], meta["n_kps"], meta["skeletons"])
+    eng = _engine(sd, arch, g * 14, len(meta["n_kps"]), meta["shots"], head_precision="bf16x3")
+    o = eng.head(inp["feature_q"], inp["feature_s"], inp["target_s"], inp["mask_s"], inp["skeleton"])
+    torch.cuda.synchronize()
+    got = {k: v.cpu().numpy() for k, v in o.items()}
+    v = _valid_mask(meta["n_kps"])
+    bsz = len(meta["n_kps"])
+    flips = (got["similarity_map"].reshape(bsz, 100, -1).argmax(-1) != gold["similarity_map"].reshape(bsz, 100, -1).argmax(-1))[v].sum()
+    e_valid = np.abs(got["output_kpts"] - gold["output_kpts"])[:, v].max()
+    e_adj = np.abs(got["adj"] - gold["adj"]).max()
+    e_sim = np.abs(got["similarity_map"] - gold["similarity_map"]).max()
+    print(name, "bf16x3 head: kpt err", e_valid, "adj err", e_adj, "sim err", e_sim, "flips", flips)
+    assert flips == 0
+    assert e_valid < 1e-3
+    assert e_adj < 1e-3
+
+
+def test_forward_bf16x3_head_vs_oracle_vitb_256():
+    """fp32 backbone + bf16x3 head end to end at the BASELINE config-2 shape: inside the 1e-3 coordinate gate."""
+    from oracle import edgecape_oracle as orc
+    arch, H, bs = "dinov2_vitb14", 256, 2
+    sd = synth.make_weights(arch, seed=31)
+    batch = synth.make_pairs(bs, 1, H, seed=77, fixed_n_kp=False)
+    res_ref, out_ref = orc.forward_test(sd, batch, synth.ARCHS[arch]["heads"])
+    eng = _engine(sd, arch, H, bs, 1, head_precision="bf16x3")
+    mask = batch["target_weight_s"][0]
+    o = eng.forward(batch["img_q"], batch["img_s"], batch["target_s"], mask, [m["sample_skeleton"][0] for m in batch["img_metas"]])
+    torch.cuda.synchronize()
+    valid = mask[:, :, 0] > 0
+    err = np.abs(o["output_kpts"].cpu().numpy() - out_ref["output_kpts"].numpy())[:, valid].max()
+    flips = (o["similarity_map"].cpu().numpy().reshape(bs, 100, -1).argmax(-1) !=
+             out_ref["similarity_map"].numpy().reshape(bs, 100, -1).argmax(-1))[valid].sum()
+    print("vitb256 fp32 backbone + bf16x3 head: kpt err", err, "flips", flips)
+    assert flips == 0 and err < 1e-3
+
+
 def test_bf16_backbone_mode_vitb_256():
     """Throughput mode: backbone GEMMs/attention on bf16 MFMA (fp32 accumulate), head fp32.  bf16 cannot
     meet the 1e-3 coordinate bound; it is judged on feature error and PCK agreement."""

@@ -43,6 +43,27 @@ def test_linear_fp32(lib, M, N, K, act):
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 256, 256), (3200, 256, 768), (10368, 1024, 256), (650, 1152, 384), (77, 128, 128)])
+@pytest.mark.parametrize("act", [0, 2])
+def test_linear_bf16x3(lib, M, N, K, act):
+    """Split-bf16 (hi+lo) GEMM of the head's throughput mode: fp32-class accuracy (~2^-17 relative per operand)."""
+    g = torch.Generator().manual_seed(M + N + K + act)
+    A = torch.randn(M, K, generator=g) * 3
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    gam = torch.rand(N, generator=g) + 0.5
+    R = torch.randn(M, N, generator=g)
+    ref = A.double() @ W.double().T + b.double()
+    ref = {0: ref, 2: torch.nn.functional.gelu(ref)}[act]
+    ref = (ref * gam.double() + R.double()).float()
+    Ad, Wd, bd, gd, Rd = (x.cuda() for x in (A, W, b, gam, R))
+    Cd = torch.empty(M, N, device="cuda")
+    _chk(lib, lib.ec_op_linear(_p(Ad), _p(Wd), _p(bd), _p(gd), _p(Rd), _p(Cd), M, N, K, act, 2, None))
+    torch.cuda.synchronize()
+    err = (Cd.cpu() - ref).abs().max().item()
+    assert err < 1e-4 * max(1.0, ref.abs().max().item()), err      # bf16 alone would be ~1e-2 here
+
+
 def test_linear_identity_layout(lib):
     """A = I with an asymmetric W: C must equal W^T exactly (transpose-detecting)."""
     N = K = 128

@@ -16,13 +16,13 @@ def main():
     lib = _lib.load()
     if os.environ.get("SHAPES"):   # e.g. SHAPES="a:7168:2304:768,b:14336:2304:768"
         SHAPES[:] = [(n, int(m), int(nn), int(k)) for n, m, nn, k in (x.split(":") for x in os.environ["SHAPES"].split(","))]
-    prec = 1 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else 0
+    prec = {"bf16": 1, "fp32": 0, "bf16x3": 2}[sys.argv[1] if len(sys.argv) > 1 else "bf16"]
     iters = int(os.environ.get("ITERS", 20))
     only = os.environ.get("ONLY")
     for name, M, N, K in SHAPES:
         if only and name not in only.split(","):
             continue
-        dt = torch.bfloat16 if prec else torch.float32
+        dt = torch.bfloat16 if prec == 1 else torch.float32
         A = torch.randn(M, K, device="cuda").to(dt)
         W = (torch.randn(N, K, device="cuda") / K ** 0.5).to(dt)
         b = torch.randn(N, device="cuda")
@@ -34,7 +34,7 @@ def main():
         if not os.environ.get("NOCHECK"):
             ref = (A.float() @ W.float().T + b)
             err = (Cd.float() - ref).abs().max().item()
-        print(f"{name:8s} M={M} N={N} K={K} {'bf16' if prec else 'fp32'}: {ms.value * 1e3:8.1f} us  {tf:7.1f} TFLOP/s  max|err|={err:.3g}", flush=True)
+        print(f"{name:8s} M={M} N={N} K={K} {['fp32', 'bf16', 'bf16x3'][prec]}: {ms.value * 1e3:8.1f} us  {tf:7.1f} TFLOP/s  max|err|={err:.3g}", flush=True)
 
 
 if __name__ == "__main__":
