@@ -14,6 +14,8 @@
 // exactly a valid k-slot assignment for the B operand of the second MFMA, so P never moves.
 //
 //   fp32 path : v_mfma_f32_32x32x2_f32 (exact fp32 products) — parity mode.
+#include <stdlib.h>
+
 #include "ec_common.h"
 
 namespace ec {
@@ -24,8 +26,8 @@ constexpr int KT = 64;  // keys per LDS tile
 // acc register r (0..15) of half `hi` holds row (r&3) + 8*(r>>2) + 4*hi of the 32x32 tile
 __device__ inline int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-template <int HD>
-__global__ __launch_bounds__(256) void attn_f32_kernel(AttnP p) {
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_f32_kernel(AttnP p) {
   constexpr int KS = HD + 1;  // K tile row stride (floats): odd -> conflict-free column reads
   constexpr int NM = HD / 2;  // MFMAs per 32x32 S^T tile
   constexpr int DT = HD / 32; // 32-wide d tiles of O^T
@@ -34,11 +36,13 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, hi = lane >> 5;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (NW * 32) + wave * 32;
   const float* Q = (const float*)p.Q + (long)b * p.sQ + h * HD;
   const float* K = (const float*)p.K + (long)b * p.sK + h * HD;
   const float* V = (const float*)p.V + (long)b * p.sV + h * HD;
-  const float scale = rsqrtf((float)HD);
+  // softmax in the exp2 domain: logits are scaled by hd^-1/2 * log2(e) up front (v_exp_f32 is exact to ~1 ulp)
+  constexpr float LOG2E = 1.44269504088896340736f;
+  const float scale = rsqrtf((float)HD) * LOG2E;
 
   // Q fragment: lane (j, hi) holds Q[q0+j][hi*NM + m], m = 0..NM-1 (contiguous), pre-scaled.
   float qf[NM];
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnP p) {
   for (int k0 = 0; k0 < p.Lk; k0 += KT) {
     __syncthreads();  // previous tile fully consumed
     // stage K,V tile: KT x HD floats each; 256 threads x float4
-    for (int idx = tid; idx < KT * HD / 4; idx += 256) {
+    for (int idx = tid; idx < KT * HD / 4; idx += NW * 64) {
       const int r = idx / (HD / 4), c = (idx % (HD / 4)) * 4;
       int kr = k0 + r;
       kr = kr < p.Lk ? kr : p.Lk - 1;
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnP p) {
       for (int r = 0; r < 16; ++r) {
         const int kg = k0 + t * 32 + acc_row(r, hi);
         float v = s[t][r];
-        if (bias && kg < p.Lk) v += bias[(long)qrow * p.Lk + kg];
+        if (bias && kg < p.Lk) v = fmaf(bias[(long)qrow * p.Lk + kg], LOG2E, v);
         bool masked = kg >= p.Lk;
         if (km && !masked && kg >= p.mask_start) masked = km[kg - p.mask_start] != 0;
         v = masked ? -INFINITY : v;
@@ -105,14 +109,14 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnP p) {
       }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float mnew = fmaxf(mrun, tmax);
-    const float alpha = expf(mrun - mnew);
+    const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
     mrun = mnew;
     float psum = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = expf(s[t][r] - mnew);
+        const float e = __builtin_amdgcn_exp2f(s[t][r] - mnew);
         s[t][r] = e;
         psum += e;
       }
@@ -308,6 +312,23 @@ int attention(const AttnP& p, hipStream_t st) {
   EC_REQUIRE(p.B > 0 && p.H > 0 && p.Lq > 0 && p.Lk > 0, -1, "attention: empty problem");
   EC_REQUIRE(p.hd == 32 || p.hd == 64, -1, "attention: head dim must be 32 or 64");
   dim3 grid((p.Lq + 127) / 128, p.H, p.B);
+  if (!p.bf16) {
+    EC_REQUIRE(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldv % 4 == 0 && p.ldo % 4 == 0, -1, "attention: strides must be multiples of 4");
+    // few workgroups (Lq = 100 keypoint queries: one 128-query block per (batch, head) = 1 workgroup per CU): use 2-wave
+    // workgroups of 64 queries so two of them share a CU and one computes while the other stages its K/V tile
+    static const bool allow_narrow = getenv("EC_ATTN_NARROW") != nullptr;   // measured slower on MI355X (80 vs 65 us at Lq=100, Lk=324)
+    const bool narrow = allow_narrow && (long)grid.x * grid.y * grid.z < 1024 && p.Lq > 32;
+    if (narrow) {
+      grid.x = (p.Lq + 63) / 64;
+      if (p.hd == 64) hipLaunchKernelGGL((attn_f32_kernel<64, 2>), grid, dim3(128), 0, st, p);
+      else hipLaunchKernelGGL((attn_f32_kernel<32, 2>), grid, dim3(128), 0, st, p);
+    } else {
+      if (p.hd == 64) hipLaunchKernelGGL((attn_f32_kernel<64, 4>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((attn_f32_kernel<32, 4>), grid, dim3(256), 0, st, p);
+    }
+    EC_LAUNCH_CHECK();
+    return 0;
+  }
   if (p.bf16) {
     EC_REQUIRE(p.hd == 64 && !p.kmask && !p.bias, -1, "attention(bf16): hd = 64, no mask / bias (backbone only)");
     EC_REQUIRE(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0, -1, "attention(bf16): stride alignment");
@@ -315,11 +336,7 @@ int attention(const AttnP& p, hipStream_t st) {
     EC_LAUNCH_CHECK();
     return 0;
   }
-  EC_REQUIRE(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldv % 4 == 0 && p.ldo % 4 == 0, -1, "attention: strides must be multiples of 4");
-  if (p.hd == 64) hipLaunchKernelGGL(attn_f32_kernel<64>, grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(attn_f32_kernel<32>, grid, dim3(256), 0, st, p);
-  EC_LAUNCH_CHECK();
-  return 0;
+  return -1;
 }
 
 }  // namespace ec

@@ -110,6 +110,8 @@ struct ec_model {
   float *o_sim, *o_adj, *o_init, *o_out;
 };
 
+struct ec_support;
+
 namespace ec {
 
 static int dmalloc(ec_model* m, void** p, size_t bytes) {
@@ -511,25 +513,27 @@ static int kpt_mlp(ec_model* m, const KptBranch& kb, const float* x, long ldx, i
 // ---------------------------------------------------------------------------------------------
 // Head: TwoStageHead.forward (head.py:161-222).  fq: [bs,HW,C] tokens, fs: S pointers [bs,HW,C].
 // ---------------------------------------------------------------------------------------------
-static int run_head(ec_model* m, const float* fq, const float* const* fs, const float* const* target_s, const float* mask_s,
-                    int bs, int S, hipStream_t st, const ec_outputs* out) {
-  const int C = m->C, d = m->d, E = m->E, K = m->K, HW = m->HW, L = m->L, g = m->g, nh = m->cfg.nhead;
-  const int Fd = m->cfg.ffn_dim, Fs = m->cfg.skel_ffn_dim, hops1 = m->cfg.max_hops + 1;
-  const int Mk = bs * K, Mi = bs * HW;
-  float* sim = out->similarity_map_dev;
-  float* adj_out = out->adj_dev;
-  float* attn_adj = out->attn_adj_dev ? out->attn_adj_dev : m->attn_adj;
-  float* pts = out->out_points_dev ? out->out_points_dev : m->d_pts;
+// Support-side state of one batch (or of a set of cached episodes): everything the query side of the head needs from the
+// support images / heatmaps / skeleton.  SkeletonPredictor.forward takes no query input (head.py:196-200).
+struct SupportState {
+  float* sk = nullptr;           // [n, K, d]   support keypoint tokens after query_proj        head.py:186-188
+  float* valid = nullptr;        // [n, K]
+  uint8_t* kmask = nullptr;      // [n, K]      1 = padded keypoint                             head.py:189
+  uint8_t* kmask_fixed = nullptr;  // [n, K]    with column 0 un-masked for all-padded samples  encoder_decoder.py:359-360
+  float* adj1 = nullptr;         // [n, K, K]   predicted, soft-normalised adjacency            skeleton.py:142-150
+  float* adj_out = nullptr;      // [n, 2, K, K]
+  float* attn_adj = nullptr;     // [hops+1, n, K, K]                                            skeleton.py:152-161
+};
 
-  // (1) input_proj on the query features, written straight into the encoder token buffer [bs, L, d] (rows 0..HW-1)
-  {
-    GemmP p;
-    p.A = fq; p.lda = C; p.sA = (long)HW * C;
-    p.split = m->input_proj.ws ? 1 : 0; p.B = m->input_proj.wsel(p.split); p.ldb = C; p.bias = m->input_proj.b;
-    p.C = m->e_x; p.ldc = d; p.sC = (long)L * d;
-    p.M = HW; p.N = d; p.K = C; p.batch = bs;
-    RUN(gemm_nt(p, st));
-  }
+// Support half of TwoStageHead.forward (head.py:175-200): pooling + query_proj + SkeletonPredictor.
+static int run_head_support(ec_model* m, const float* const* fs, const float* const* target_s, const float* mask_s, int bs, int S,
+                            hipStream_t st, const SupportState& ss) {
+  const int C = m->C, d = m->d, K = m->K, HW = m->HW, g = m->g;
+  const int Fs = m->cfg.skel_ffn_dim, hops1 = m->cfg.max_hops + 1;
+  const int Mk = bs * K, Mi = bs * HW;
+  float* adj_out = ss.adj_out;
+  float* attn_adj = ss.attn_adj;
+
   // (2) support keypoint pooling + query_proj (head.py:175-188)
   for (int s = 0; s < S; ++s) {
     RUN(pool_weights(target_s[s], mask_s, 1.f / (float)S, m->Wp, bs, K, m->cfg.heatmap_size, g, st));
@@ -541,21 +545,20 @@ static int run_head(ec_model* m, const float* fq, const float* const* fs, const 
     p.beta = s == 0 ? 0.f : 1.f;
     RUN(bgemm_small(p, st));
   }
-  RUN(linear(m->pooled, C, false, m->query_proj, m->sk, d, false, Mk, ACT_NONE, st));
-  m->taps["support_keypoints"] = {m->sk, (long)Mk * d};
-  RUN(copy3d(m->e_x + (long)HW * d, d, (long)L * d, m->sk, d, (long)K * d, bs, K, d, st));
+  RUN(linear(m->pooled, C, false, m->query_proj, ss.sk, d, false, Mk, ACT_NONE, st));
+  m->taps["support_keypoints"] = {ss.sk, (long)Mk * d};
 
   // (3) skeleton head (skeleton.py:58-161)
-  RUN(adj_build(m->d_edges, m->d_off, mask_s, m->valid, m->kmask, m->kmask_fixed, m->binary, m->adj_r1, bs, K, st));
+  RUN(adj_build(m->d_edges, m->d_off, mask_s, ss.valid, ss.kmask, ss.kmask_fixed, m->binary, m->adj_r1, bs, K, st));
   const int nb = S * bs;
   for (int s = 0; s < S; ++s) {
     RUN(linear(fs[s], C, false, m->image_project, m->s_mem + (long)s * Mi * d, d, false, Mi, ACT_NONE, st));
-    RUN(copy2d(m->s_x + (long)s * Mk * d, d, m->sk, d, Mk, d, st));
+    RUN(copy2d(m->s_x + (long)s * Mk * d, d, ss.sk, d, Mk, d, st));
   }
   for (size_t i = 0; i < m->skel.size(); ++i) {
     LayerIO io;
     io.x = m->s_x; io.ldx = d; io.mem = m->s_mem; io.s_mem = (long)HW * d;
-    io.adj1 = m->adj_r1; io.valid = m->valid; io.kmask_fixed = m->kmask_fixed; io.bias = nullptr;
+    io.adj1 = m->adj_r1; io.valid = ss.valid; io.kmask_fixed = ss.kmask_fixed; io.bias = nullptr;
     io.nb = nb; io.bs = bs;
     io.update_mem = (i + 1 < m->skel.size());  // the last layer's image update is never read (skeleton.py:104-112)
     RUN(run_dec_layer(m, m->skel[i], io, false, true, m->s_qkv, m->s_att, m->s_tmp, m->s_qc, m->s_kv, m->s_y, m->s_z, m->s_qimg,
@@ -572,7 +575,7 @@ static int run_head(ec_model* m, const float* fq, const float* const* fs, const 
     p.M = K; p.N = K; p.K = d; p.batch = bs;
     RUN(bgemm_small(p, st));
   }
-  RUN(adj_combine(m->P, m->binary, m->valid, m->zc_w, m->zc_b, adj_out, m->adj1, attn_adj, bs, K, st));
+  RUN(adj_combine(m->P, m->binary, ss.valid, m->zc_w, m->zc_b, adj_out, ss.adj1, attn_adj, bs, K, st));
   {  // Markov powers: A^2 = A A, A^3 = A^2 A, A^4 = A^2 A^2 (torch.matrix_power's association)
     const long KK = (long)K * K, hop = (long)bs * KK;
     auto mm = [&](const float* a, const float* b, float* c) {
@@ -588,6 +591,29 @@ static int run_head(ec_model* m, const float* fq, const float* const* fs, const 
     EC_REQUIRE(hops1 <= 5, EC_ERR_ARG, "max_hops > 4 not supported");
   }
 
+  return 0;
+}
+
+// Query half of TwoStageHead.forward (head.py:169-173, 202-222): input_proj, encoder, proposal generator, decoder, kpt branches.
+static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, const ec_outputs* out, const SupportState& ss) {
+  const int C = m->C, d = m->d, E = m->E, K = m->K, HW = m->HW, L = m->L, g = m->g, nh = m->cfg.nhead;
+  const int Fd = m->cfg.ffn_dim, hops1 = m->cfg.max_hops + 1;
+  const int Mk = bs * K;
+  float* sim = out->similarity_map_dev;
+  float* attn_adj = ss.attn_adj;
+  float* pts = out->out_points_dev ? out->out_points_dev : m->d_pts;
+
+  // (1) input_proj on the query features, written straight into the encoder token buffer [bs, L, d] (rows 0..HW-1)
+  {
+    GemmP p;
+    p.A = fq; p.lda = C; p.sA = (long)HW * C;
+    p.split = m->input_proj.ws ? 1 : 0; p.B = m->input_proj.wsel(p.split); p.ldb = C; p.bias = m->input_proj.b;
+    p.C = m->e_x; p.ldc = d; p.sC = (long)L * d;
+    p.M = HW; p.N = d; p.K = C; p.batch = bs;
+    RUN(gemm_nt(p, st));
+  }
+  RUN(copy3d(m->e_x + (long)HW * d, d, (long)L * d, ss.sk, d, (long)K * d, bs, K, d, st));
+
   // (4) encoder (encoder_decoder.py:276-310, 461-483) over [bs, L = HW + K, d]
   const int Me = bs * L;
   for (size_t i = 0; i < m->enc.size(); ++i) {
@@ -598,7 +624,7 @@ static int run_head(ec_model* m, const float* fq, const float* const* fs, const 
     a.Q = m->e_qkv; a.K = m->e_qkv + d; a.V = m->e_qkv + 2 * d; a.O = m->e_att;
     a.ldq = a.ldk = a.ldv = 3 * d; a.ldo = d;
     a.sQ = a.sK = a.sV = (long)L * 3 * d; a.sO = (long)L * d;
-    a.kmask = m->kmask; a.mask_start = HW; a.mask_len = K; a.mask_mod = 0;
+    a.kmask = ss.kmask; a.mask_start = HW; a.mask_len = K; a.mask_mod = 0;
     a.B = bs; a.H = nh; a.Lq = L; a.Lk = L; a.hd = d / nh;
     RUN(attention(a, st));
     RUN(linear(m->e_att, d, false, e.out, m->e_tmp, d, false, Me, ACT_NONE, st, nullptr, m->e_x, d));
@@ -657,7 +683,7 @@ static int run_head(ec_model* m, const float* fq, const float* const* fs, const 
     RUN(bias_mlp(attn_adj, Ld.m_w1, Ld.m_b1, Ld.m_w2, Ld.m_b2, m->d_bias, hops1, m->cfg.max_hops + nh, nh, bs, K, st));
     LayerIO io;
     io.x = m->d_qin; io.ldx = 2 * d; io.mem = mem; io.s_mem = s_tok;
-    io.adj1 = m->adj1; io.valid = m->valid; io.kmask_fixed = m->kmask_fixed; io.bias = m->d_bias;
+    io.adj1 = ss.adj1; io.valid = ss.valid; io.kmask_fixed = ss.kmask_fixed; io.bias = m->d_bias;
     io.nb = bs; io.bs = bs; io.update_mem = false;
     io.kv_pre = m->d_kv + (long)li * 2 * E; io.ld_kv_pre = (long)nL * 2 * E;
     RUN(run_dec_layer(m, Ld, io, true, false, m->d_qkv, m->d_att, m->d_tmp, m->d_qc, m->d_kv, m->d_y, m->d_z, nullptr, nullptr,
@@ -672,6 +698,32 @@ static int run_head(ec_model* m, const float* fq, const float* const* fs, const 
     RUN(kpt_mlp(m, m->kpt[li], m->d_hs + (long)li * Mk * d, d, Mk, pts + (long)li * Mk * 2,
                 out->output_kpts_dev + (long)li * Mk * 2, st));
   return 0;
+}
+
+}  // namespace ec
+struct ec_support {
+  ec_model* m = nullptr;
+  int cap = 0, n = 0, S = 0;
+  ec::SupportState ss;
+  int32_t* d_idx = nullptr;
+  std::vector<void*> owned;
+};
+namespace ec {
+
+static SupportState workspace_support(ec_model* m, const ec_outputs* out) {
+  SupportState ss;
+  ss.sk = m->sk; ss.valid = m->valid; ss.kmask = m->kmask; ss.kmask_fixed = m->kmask_fixed; ss.adj1 = m->adj1;
+  ss.adj_out = out->adj_dev;
+  ss.attn_adj = out->attn_adj_dev ? out->attn_adj_dev : m->attn_adj;
+  return ss;
+}
+
+// TwoStageHead.forward (head.py:161-222).  fq: [bs,HW,C] tokens, fs: S pointers [bs,HW,C].
+static int run_head(ec_model* m, const float* fq, const float* const* fs, const float* const* target_s, const float* mask_s,
+                    int bs, int S, hipStream_t st, const ec_outputs* out) {
+  const SupportState ss = workspace_support(m, out);
+  RUN(run_head_support(m, fs, target_s, mask_s, bs, S, st, ss));
+  return run_head_query(m, fq, bs, st, out, ss);
 }
 
 static int upload_edges(ec_model* m, const int32_t* edges, const int32_t* off, int bs, hipStream_t st) {
@@ -960,6 +1012,78 @@ int ec_forward(ec_handle m, const float* img_q, const float* const* img_s, const
   RUN(run_backbone(m, srcs.data(), 1 + S, bs, m->feat, st));
   m->taps["feature_q"] = {m->feat, (long)per};
   return run_head(m, m->feat, fsp.data(), target_s, mask_s, bs, S, st, out);
+}
+
+// ---- support-side episode cache -------------------------------------------------------------
+// The reference evaluates one support set against 15 queries (test_dataset.py:93-97) and recomputes the support backbone
+// features, pooled support tokens and the whole SkeletonPredictor for every pair; none of that depends on the query
+// (head.py:196-200).  ec_support_encode runs it once per episode, ec_forward_cached runs only the query side.
+int ec_support_create(ec_handle m, int max_episodes, ec_support_t* out) {
+  EC_REQUIRE(m && m->finalized && out, EC_ERR_STATE, "model not finalized");
+  EC_REQUIRE(max_episodes > 0 && max_episodes <= m->cfg.max_batch, EC_ERR_ARG, "max_episodes must be within 1..max_batch");
+  ec_support* c = new ec_support();
+  c->m = m; c->cap = max_episodes;
+  const size_t n = max_episodes, K = m->K, d = m->d, KK = K * K;
+  auto al = [&](void** p, size_t bytes) -> int {
+    EC_HIP(hipMalloc(p, bytes));
+    c->owned.push_back(*p);
+    return 0;
+  };
+  int rc = 0;
+  if ((rc = al((void**)&c->ss.sk, n * K * d * 4)) || (rc = al((void**)&c->ss.valid, n * K * 4)) || (rc = al((void**)&c->ss.kmask, n * K)) ||
+      (rc = al((void**)&c->ss.kmask_fixed, n * K)) || (rc = al((void**)&c->ss.adj1, n * KK * 4)) ||
+      (rc = al((void**)&c->ss.adj_out, n * 2 * KK * 4)) || (rc = al((void**)&c->ss.attn_adj, (m->cfg.max_hops + 1) * n * KK * 4)) ||
+      (rc = al((void**)&c->d_idx, (size_t)m->cfg.max_batch * 4))) {
+    for (void* p : c->owned) (void)hipFree(p);
+    delete c;
+    return rc;
+  }
+  *out = c;
+  return EC_OK;
+}
+
+int ec_support_destroy(ec_support_t c) {
+  if (!c) return EC_OK;
+  for (void* p : c->owned) (void)hipFree(p);
+  delete c;
+  return EC_OK;
+}
+
+int ec_support_encode(ec_handle m, ec_support_t c, const float* const* img_s, const float* const* target_s, const float* mask_s,
+                      const int32_t* edges, const int32_t* off, int n_episodes, int S, void* stream) {
+  EC_REQUIRE(m && m->finalized && c && c->m == m, EC_ERR_STATE, "bad handle");
+  EC_REQUIRE(img_s && target_s && mask_s, EC_ERR_ARG, "null input");
+  EC_REQUIRE(n_episodes > 0 && n_episodes <= c->cap && S > 0 && S <= m->cfg.max_shots, EC_ERR_ARG, "n_episodes / S exceed the configured maxima");
+  hipStream_t st = (hipStream_t)stream;
+  RUN(upload_edges(m, edges, off, n_episodes, st));
+  const size_t per = (size_t)n_episodes * m->HW * m->C;
+  std::vector<const float*> fsp(S);
+  for (int s = 0; s < S; ++s) fsp[s] = m->feat + s * per;
+  RUN(run_backbone(m, img_s, S, n_episodes, m->feat, st));
+  c->n = n_episodes; c->S = S;
+  return run_head_support(m, fsp.data(), target_s, mask_s, n_episodes, S, st, c->ss);
+}
+
+int ec_forward_cached(ec_handle m, ec_support_t c, const float* img_q, const int32_t* episode_of_query, int bs, void* stream,
+                      const ec_outputs* out) {
+  RUN(check_head_args(m, bs, 1, out));
+  EC_REQUIRE(c && c->m == m && c->n > 0, EC_ERR_STATE, "support cache is empty: call ec_support_encode first");
+  EC_REQUIRE(img_q && episode_of_query, EC_ERR_ARG, "null input");
+  for (int b = 0; b < bs; ++b)
+    EC_REQUIRE(episode_of_query[b] >= 0 && episode_of_query[b] < c->n, EC_ERR_ARG, "episode index out of range");
+  hipStream_t st = (hipStream_t)stream;
+  EC_HIP(hipMemcpyAsync(c->d_idx, episode_of_query, (size_t)bs * 4, hipMemcpyHostToDevice, st));
+  RUN(run_backbone(m, &img_q, 1, bs, m->feat, st));
+  const SupportState ws = workspace_support(m, out);
+  const long K = m->K, KK = K * K;
+  RUN(gather_rows(ws.sk, c->ss.sk, c->d_idx, K * m->d, bs, 1, 0, 0, st));
+  RUN(gather_rows(ws.valid, c->ss.valid, c->d_idx, K, bs, 1, 0, 0, st));
+  RUN(gather_rows((float*)ws.kmask, (const float*)c->ss.kmask, c->d_idx, K / 4, bs, 1, 0, 0, st));            // K % 4 == 0
+  RUN(gather_rows((float*)ws.kmask_fixed, (const float*)c->ss.kmask_fixed, c->d_idx, K / 4, bs, 1, 0, 0, st));
+  RUN(gather_rows(ws.adj1, c->ss.adj1, c->d_idx, KK, bs, 1, 0, 0, st));
+  RUN(gather_rows(ws.adj_out, c->ss.adj_out, c->d_idx, 2 * KK, bs, 1, 0, 0, st));
+  RUN(gather_rows(ws.attn_adj, c->ss.attn_adj, c->d_idx, KK, bs, m->cfg.max_hops + 1, (long)c->n * KK, (long)bs * KK, st));
+  return run_head_query(m, m->feat, bs, st, out, ws);
 }
 
 int ec_profile(ec_handle m, int enable, int max_launches) {

@@ -26,6 +26,9 @@ int copy2d(float* dst, long ldd, const float* src, long lds, int rows, int cols,
 // dst[b][r][c] = src[b][r][c] for b < batch with batch strides
 int copy3d(float* dst, long ldd, long sd, const float* src, long lds, long ss, int batch, int rows, int cols, hipStream_t st);
 int mean_over(float* dst, const float* src, long stride, int n, long count, hipStream_t st);
+// dst[o][b][0..row) = src[o][idx[b]][0..row) for b < n_rows, o < n_outer (outer strides in floats)
+int gather_rows(float* dst, const float* src, const int32_t* idx_dev, long row, int n_rows, int n_outer, long src_os, long dst_os,
+                hipStream_t st);
 int f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t st);
 // src [B][L][E] fp32 -> dst [B][E][Lp] bf16 (columns >= L zeroed); test helper for the bf16 attention kernel
 int transpose_pad_bf16(const float* src, bf16_t* dst, int B, int L, int E, int Lp, hipStream_t st);

@@ -91,6 +91,14 @@ __global__ void copy3d_kernel(float* dst, long ldd, long sd, const float* src, l
   *(f32x4*)(dst + b * sd + (long)r * ldd + c) = *(const f32x4*)(src + b * ss + (long)r * lds + c);
 }
 
+// dst[o][b][i] = src[o][idx[b]][i]  (support-side episode cache -> per-query workspace)
+__global__ void gather_rows_kernel(float* dst, const float* src, const int32_t* idx, long row, long src_os, long dst_os) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= row) return;
+  const int b = blockIdx.y, o = blockIdx.z;
+  dst[o * dst_os + (long)b * row + i] = src[o * src_os + (long)idx[b] * row + i];
+}
+
 __global__ void mean_over_kernel(float* dst, const float* src, long stride, int n, long count) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
@@ -513,6 +521,14 @@ int copy3d(float* dst, long ldd, long sd, const float* src, long lds, long ss, i
 
 int copy2d(float* dst, long ldd, const float* src, long lds, int rows, int cols, hipStream_t st) {
   return copy3d(dst, ldd, 0, src, lds, 0, 1, rows, cols, st);
+}
+
+int gather_rows(float* dst, const float* src, const int32_t* idx_dev, long row, int n_rows, int n_outer, long src_os, long dst_os,
+                hipStream_t st) {
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(row, 256), n_rows, n_outer), dim3(256), 0, st, dst, src, idx_dev, row, src_os,
+                     dst_os);
+  EC_LAUNCH_CHECK();
+  return 0;
 }
 
 int mean_over(float* dst, const float* src, long stride, int n, long count, hipStream_t st) {

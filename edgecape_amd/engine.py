@@ -59,6 +59,24 @@ def normalize_state_dict(sd):
     return out
 
 
+class SupportCache:
+    """Owner of an ec_support_t (cached support-side state of up to `max_episodes` episodes of one engine)."""
+
+    def __init__(self, engine, max_episodes):
+        self.engine, self.n_episodes = engine, 0
+        h = C.c_void_p()
+        _lib.check(engine.lib.ec_support_create(engine.h, max_episodes, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.engine.lib.ec_support_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 class HipEngine:
     def __init__(self, state_dict, arch="dinov2_vits14", image_size=224, max_batch=2, max_shots=1, num_kpts=100,
                  ffn_dim=384, skel_ffn_dim=None, backbone_precision="fp32", head_precision="fp32", heatmap_size=64,
@@ -187,6 +205,33 @@ class HipEngine:
         _lib.check(self.lib.ec_forward(self.h, iq.data_ptr(), self._ptr_array(is_), self._ptr_array(ts), ms.data_ptr(),
                                        edges.ctypes.data, off.ctypes.data, iq.shape[0], len(is_), _lib.current_stream(),
                                        C.byref(eo)))
+        return o
+
+    # ---- support-side episode cache (include/edgecape_hip.h: ec_support_*) ---------------------------
+    def support_encode(self, img_s, target_s, mask_s, skeletons, cache=None):
+        """Run the support side once per episode: support backbone features, pooled support tokens, SkeletonPredictor.
+        img_s / target_s: lists over shots of [n_episodes, ...]; returns an opaque cache for forward_cached()."""
+        is_ = [self._dev(x) for x in img_s]
+        ts = [self._dev(t) for t in target_s]
+        n, S = is_[0].shape[0], len(is_)
+        ms = self._dev(mask_s).reshape(n, self.K)
+        edges, off = self._edges(skeletons, n)
+        if cache is None:
+            cache = SupportCache(self, self.max_batch)
+        _lib.check(self.lib.ec_support_encode(self.h, cache.h, self._ptr_array(is_), self._ptr_array(ts), ms.data_ptr(),
+                                              edges.ctypes.data, off.ctypes.data, n, S, _lib.current_stream()))
+        cache.n_episodes = n
+        cache._keep = (is_, ts, ms)
+        return cache
+
+    def forward_cached(self, img_q, cache, episode_of_query):
+        """Query side only: query b is matched against cached episode episode_of_query[b]."""
+        iq = self._dev(img_q)
+        bs = iq.shape[0]
+        ep = np.ascontiguousarray(np.asarray(episode_of_query, np.int32).reshape(bs))
+        o, eo = self._outputs(bs)
+        _lib.check(self.lib.ec_forward_cached(self.h, cache.h, iq.data_ptr(), ep.ctypes.data, bs, _lib.current_stream(), C.byref(eo)))
+        o["_keep"] = (iq,)
         return o
 
     def debug(self, name):

@@ -113,6 +113,22 @@ int ec_forward(ec_handle h, const float* img_q_dev, const float* const* img_s_de
                const float* const* target_s_dev, const float* mask_s_dev, const int32_t* edges,
                const int32_t* edge_offsets, int bs, int S, void* stream, const ec_outputs* out);
 
+/* ---- support-side episode cache --------------------------------------------------------
+ * The reference pairs ONE support set with 15 queries (EdgeCape/datasets/datasets/mp100/test_dataset.py:93-97) and
+ * recomputes the support backbone features, the pooled support tokens (head.py:175-188) and the whole SkeletonPredictor
+ * (skeleton.py:58-161; it has no query input, head.py:196-200) for every pair.  ec_support_encode does that work once
+ * per episode; ec_forward_cached then runs the query side only (query backbone, input_proj, encoder, proposal generator,
+ * decoder, kpt branches) for a batch of queries, query b using episode episode_of_query[b].  Results are identical to
+ * ec_forward on the expanded (support, query) pairs. */
+typedef struct ec_support* ec_support_t;
+int ec_support_create(ec_handle h, int max_episodes, ec_support_t* out);   /* max_episodes <= max_batch */
+int ec_support_destroy(ec_support_t s);
+int ec_support_encode(ec_handle h, ec_support_t s, const float* const* img_s_dev, const float* const* target_s_dev,
+                      const float* mask_s_dev, const int32_t* edges, const int32_t* edge_offsets, int n_episodes, int S,
+                      void* stream);
+int ec_forward_cached(ec_handle h, ec_support_t s, const float* img_q_dev, const int32_t* episode_of_query, int bs,
+                      void* stream, const ec_outputs* out);
+
 /* Copy a named intermediate of the LAST forward/head call to a host fp32 buffer (tests only; synchronises). */
 int ec_debug_read(ec_handle h, const char* name, float* host_out, int64_t max_elems, int64_t* n_elems);
 

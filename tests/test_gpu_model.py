@@ -226,3 +226,109 @@ def test_bf16_backbone_mode_vitb_256():
     print(f"bf16 mode: median |d| {np.median(d):.3f}px p90 {np.percentile(d, 90):.3f}px max {d.max():.2f}px; PCK@0.2 {pck_g:.4f} vs {pck_r:.4f}")
     assert abs(pck_g - pck_r) <= 0.1          # north star: PCK@0.2 within +-0.1
     assert np.median(d) < 1.0
+
+
+def _fwd(eng, batch):
+    mask = batch["target_weight_s"][0].copy()
+    for tw in batch["target_weight_s"]:
+        mask = mask * tw
+    o = eng.forward(batch["img_q"], batch["img_s"], batch["target_s"], mask, [m["sample_skeleton"][0] for m in batch["img_metas"]])
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in o.items() if isinstance(v, torch.Tensor)}, mask[:, :, 0] > 0
+
+
+def test_forward_vs_oracle_5shot_vitb_256():
+    """BASELINE config 4 shape (5 support images per query, ViT-B/14 @256) at a batch the CPU oracle finishes in seconds:
+    support-stack pooling (mean over shots), per-shot skeleton refinement, mask = product of the shots' weights."""
+    from oracle import edgecape_oracle as orc
+    arch, H, bs, S = "dinov2_vitb14", 256, 2, 5
+    sd = synth.make_weights(arch, seed=41)
+    batch = synth.make_pairs(bs, S, H, seed=91, fixed_n_kp=False)
+    res_ref, out_ref = orc.forward_test(sd, batch, synth.ARCHS[arch]["heads"])
+    got, valid = _fwd(_engine(sd, arch, H, bs, S), batch)
+    err = np.abs(got["output_kpts"] - out_ref["output_kpts"].numpy())[:, valid].max()
+    flips = (got["similarity_map"].reshape(bs, 100, -1).argmax(-1) !=
+             out_ref["similarity_map"].numpy().reshape(bs, 100, -1).argmax(-1))[valid].sum()
+    print("5-shot vitb256: kpt err", err, "flips", flips)
+    assert flips == 0 and err < 1e-3
+    assert np.abs(got["adj"] - out_ref["adj"].numpy()).max() < 1e-4
+
+
+def test_forward_vs_oracle_vitl_384():
+    """BASELINE config 5 shape: ViT-L/14 (24 blocks, C = 1024, 16 heads) at 384x384 -> 27x27 grid, 730 tokens (floor
+    semantics); skeleton-head GCN width follows the backbone width (F4)."""
+    from oracle import edgecape_oracle as orc
+    arch, H, bs = "dinov2_vitl14", 384, 1
+    sd = synth.make_weights(arch, seed=51)
+    batch = synth.make_pairs(bs, 1, H, seed=17, fixed_n_kp=False)
+    res_ref, out_ref = orc.forward_test(sd, batch, synth.ARCHS[arch]["heads"])
+    eng = _engine(sd, arch, H, bs, 1)
+    feat = eng.backbone(batch["img_q"], nchw=True).cpu().numpy()
+    ferr = np.abs(feat - out_ref["feature_q"].numpy()).max()
+    got, valid = _fwd(eng, batch)
+    err = np.abs(got["output_kpts"] - out_ref["output_kpts"].numpy())[:, valid].max()
+    flips = (got["similarity_map"].reshape(bs, 100, -1).argmax(-1) !=
+             out_ref["similarity_map"].numpy().reshape(bs, 100, -1).argmax(-1))[valid].sum()
+    print("vitl384: feature err", ferr, "kpt err", err, "flips", flips)
+    assert ferr < 5e-4
+    assert flips == 0 and err < 1e-3
+
+
+def test_full_size_properties_cfg2_bf16():
+    """BASELINE config 2 at FULL size (32 pairs, ViT-B/14 @256, throughput precisions): size-independent properties.
+      * shard invariance: the first 2 pairs of the 32-pair batch equal a 2-pair batch of the same pairs (pairs are independent,
+        SURVEY §8e) — this is what makes data-parallel sharding exact;
+      * structural invariants of the reference: adj[:,0] = diag(valid), adj[:,1] rows sum to 1 on valid rows and are
+        zero on padded rows/columns, attn_adj[0] = I, all padded keypoint slots of a sample produce identical outputs,
+        coordinates inside [0,1]."""
+    arch, H, bs = "dinov2_vitb14", 256, 32
+    sd = synth.make_weights(arch, seed=0)
+    batch = synth.make_pairs(bs, 1, H, seed=1000, fixed_n_kp=False)
+    eng = _engine(sd, arch, H, bs, 1, backbone_precision="bf16", head_precision="bf16x3")
+    got, valid = _fwd(eng, batch)
+    small = synth.make_pairs(2, 1, H, seed=1000, fixed_n_kp=False)
+    got2, valid2 = _fwd(eng, small)
+    for k in ("output_kpts", "similarity_map", "adj", "initial_proposals"):
+        a = got[k][:, :2] if k == "output_kpts" else got[k][:2]
+        d = np.abs(a - got2[k]).max()
+        print("shard invariance", k, d)
+        assert d < 1e-5, (k, d)
+    adj, attn = got["adj"], got["attn_adj"]
+    K = adj.shape[-1]
+    for b in range(bs):
+        v = valid[b]
+        assert np.array_equal(adj[b, 0], np.diag(v.astype(np.float32)))
+        rs = adj[b, 1].sum(-1)
+        assert np.allclose(rs[v], 1.0, atol=1e-5) and np.all(adj[b, 1][~v] == 0) and np.all(adj[b, 1][:, ~v] == 0)
+        assert np.array_equal(attn[0, b], np.eye(K, dtype=np.float32))
+        pad = got["output_kpts"][:, b, ~v]                     # [layers, n_pad, 2]
+        if pad.shape[1] > 1:
+            assert np.abs(pad - pad[:, :1]).max() == 0.0       # padded slots are indistinguishable tokens
+    assert np.all(np.isfinite(got["output_kpts"])) and got["output_kpts"].min() >= 0 and got["output_kpts"].max() <= 1
+
+
+@pytest.mark.parametrize("shots", [1, 5])
+def test_support_cache_matches_pairwise_forward(shots):
+    """encode 3 support sets once, run 8 queries against them (episode map with repeats) and compare
+    with the plain pairwise ec_forward on the expanded (support, query) batch — identical by construction."""
+    arch, H = "dinov2_vits14", 224
+    sd = synth.make_weights(arch, seed=61)
+    sup = synth.make_pairs(3, shots, H, seed=300, fixed_n_kp=False)          # 3 episodes (their queries are not used)
+    qry = synth.make_pairs(8, 1, H, seed=400)
+    ep = np.array([0, 0, 1, 2, 2, 2, 1, 0], np.int32)
+    eng = _engine(sd, arch, H, 8, shots)
+    mask = sup["target_weight_s"][0].copy()
+    for tw in sup["target_weight_s"]:
+        mask = mask * tw
+    skels = [m["sample_skeleton"][0] for m in sup["img_metas"]]
+    cache = eng.support_encode(sup["img_s"], sup["target_s"], mask, skels)
+    got = eng.forward_cached(qry["img_q"], cache, ep)
+    torch.cuda.synchronize()
+    ref = eng.forward(qry["img_q"], [x[ep] for x in sup["img_s"]], [x[ep] for x in sup["target_s"]], mask[ep], [skels[e] for e in ep])
+    torch.cuda.synchronize()
+    for k in ("output_kpts", "initial_proposals", "similarity_map", "adj", "attn_adj", "out_points"):
+        d = (got[k] - ref[k]).abs().max().item()
+        print("cache vs pairwise", k, d)
+        assert d < 1e-6, (k, d)
+    with pytest.raises(Exception):
+        eng.forward_cached(qry["img_q"], cache, np.full(8, 3, np.int32))     # episode index out of range
