@@ -1086,6 +1086,37 @@ int ec_forward_cached(ec_handle m, ec_support_t c, const float* img_q, const int
   return run_head_query(m, m->feat, bs, st, out, ws);
 }
 
+// ---- on-device input pipeline ---------------------------------------------------------------
+int ec_preprocess_images(const uint8_t* const* src_dev, const int32_t* src_hw, const int64_t* src_pitch, const float* inv_affine,
+                         int n, int out_size, const float* mean, const float* stdv, float* out_dev, void* stream) {
+  EC_REQUIRE(src_dev && src_hw && inv_affine && mean && stdv && out_dev && n > 0 && out_size > 0, EC_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  for (int i0 = 0; i0 < n; i0 += 16) {
+    PreprocBatch pb;
+    const int nb = std::min(16, n - i0);
+    for (int i = 0; i < nb; ++i) {
+      EC_REQUIRE(src_dev[i0 + i] && src_hw[2 * (i0 + i)] > 0 && src_hw[2 * (i0 + i) + 1] > 0, EC_ERR_ARG, "bad source image");
+      pb.src[i] = src_dev[i0 + i];
+      pb.hs[i] = src_hw[2 * (i0 + i)]; pb.ws[i] = src_hw[2 * (i0 + i) + 1];
+      pb.pitch[i] = src_pitch ? src_pitch[i0 + i] : (long)pb.ws[i] * 3;
+      memcpy(pb.inv[i], inv_affine + 6 * (size_t)(i0 + i), 6 * sizeof(float));
+    }
+    for (int c = 0; c < 3; ++c) { pb.mean[c] = mean[c]; pb.stdv[c] = stdv[c]; }
+    RUN(preprocess_affine(pb, nb, out_dev + (size_t)i0 * 3 * out_size * out_size, out_size, st));
+  }
+  return EC_OK;
+}
+
+int ec_msra_targets(const float* joints_dev, const float* visible_dev, int n, int K, int image_size, int heatmap_size, int sigma,
+                    const float* gauss_host, float* target_dev, float* weight_dev, void* stream) {
+  EC_REQUIRE(joints_dev && visible_dev && gauss_host && target_dev && weight_dev && n > 0 && K > 0, EC_ERR_ARG, "bad argument");
+  EC_REQUIRE(sigma == 1, EC_ERR_ARG, "sigma must be 1 (configs/test/*.py; 7x7 gaussian)");
+  MsraP mp;
+  mp.hm = heatmap_size; mp.tmp = 3 * sigma; mp.stride = (double)image_size / (double)heatmap_size;
+  memcpy(mp.g, gauss_host, 49 * sizeof(float));
+  return msra_targets(joints_dev, visible_dev, target_dev, weight_dev, n * K, mp, (hipStream_t)stream);
+}
+
 int ec_profile(ec_handle m, int enable, int max_launches) {
   EC_REQUIRE(m, EC_ERR_ARG, "null handle");
   m->prof_on = enable != 0;

@@ -37,6 +37,23 @@ int set_cls_rows(float* x, long ldx, const float* cls, const float* pos0, int n_
 int nchw_to_tokens(const float* src, float* dst, int n, int C, int HW, hipStream_t st);
 int tokens_to_nchw(const float* src, float* dst, int n, int C, int HW, hipStream_t st);
 
+// on-device input pipeline (ec_preprocess_images / ec_msra_targets); batches of up to 16 images per launch
+struct PreprocBatch {
+  const unsigned char* src[16];   // RGB uint8 HWC source images (device)
+  long pitch[16];                 // bytes per source row
+  int hs[16], ws[16];
+  float inv[16][6];               // dst -> src affine (row-major 2x3)
+  float mean[3], stdv[3];
+};
+int preprocess_affine(const PreprocBatch& pb, int n, float* out, int H, hipStream_t st);
+struct MsraP {
+  int hm, tmp;        // heatmap side, 3 * sigma
+  double stride;      // image_size / heatmap_size (float64 in the reference)
+  float g[49];        // (2*tmp+1)^2 gaussian, float32 values computed on the host exactly as the reference does
+};
+int msra_targets(const float* joints, const float* visible, float* target, float* weight, int n_kpts_total, const MsraP& mp,
+                 hipStream_t st);
+
 // head.py:175-184 — bilinear(g->hm) + normalised-heatmap pooling expressed as weights over the g*g cells
 int pool_weights(const float* target, const float* mask_s, float inv_shots, float* Wp, int bs, int K, int hm, int g,
                  hipStream_t st);

@@ -523,10 +523,82 @@ int copy2d(float* dst, long ldd, const float* src, long lds, int rows, int cols,
   return copy3d(dst, ldd, 0, src, lds, 0, 1, rows, cols, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// On-device input pipeline: TopDownAffineFewShot + ToTensor + NormalizeTensor
+// (EdgeCape/datasets/pipelines/top_down_transform.py:35-58, configs/test/1shot_split1.py:117-125) and
+// TopDownGenerateTargetFewShot._msra_generate_target (top_down_transform.py:165-194).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_affine_kernel(PreprocBatch pb, float* out, int H) {
+  // one thread per destination pixel; dst -> src through the inverse 2x3 matrix (what warpAffine does without
+  // WARP_INVERSE_MAP), bilinear, constant-0 border, then x/255, (x - mean) / std, HWC -> CHW.
+  const int img = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= H * H) return;
+  const int y = i / H, x = i - y * H;
+  const float* M = pb.inv[img];
+  const float sx = M[0] * (float)x + M[1] * (float)y + M[2];
+  const float sy = M[3] * (float)x + M[4] * (float)y + M[5];
+  const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
+  const float fx = sx - (float)x0, fy = sy - (float)y0;
+  const int Hs = pb.hs[img], Ws = pb.ws[img];
+  const unsigned char* src = pb.src[img];
+  const long pitch = pb.pitch[img];
+  float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int xx = x0 + dx, yy = y0 + dy;
+      const float w = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy);
+      if (xx >= 0 && xx < Ws && yy >= 0 && yy < Hs) {
+        const unsigned char* px = src + (long)yy * pitch + (long)xx * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = fmaf(w, (float)px[c], acc[c]);
+      }
+    }
+  float* o = out + (long)img * 3 * H * H + (long)y * H + x;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) o[(long)c * H * H] = (acc[c] * (1.f / 255.f) - pb.mean[c]) / pb.stdv[c];
+}
+
+__global__ __launch_bounds__(256) void msra_target_kernel(const float* joints, const float* visible, float* target, float* weight,
+                                                          MsraP mp) {
+  // one workgroup per (sample, keypoint): zero the hm x hm map, then paste the in-bounds part of the (2*3*sigma+1)^2 gaussian
+  const int jk = blockIdx.x;
+  const int hm = mp.hm, tmp = mp.tmp, size = 2 * mp.tmp + 1;
+  // reference arithmetic: float32 joint / float64 stride + 0.5, int() truncation (top_down_transform.py:170-172)
+  const int mu_x = (int)((double)joints[2 * (long)jk] / mp.stride + 0.5);
+  const int mu_y = (int)((double)joints[2 * (long)jk + 1] / mp.stride + 0.5);
+  const int ulx = mu_x - tmp, uly = mu_y - tmp, brx = mu_x + tmp + 1, bry = mu_y + tmp + 1;
+  float w = visible[jk];
+  if (ulx >= hm || uly >= hm || brx < 0 || bry < 0) w = 0.f;
+  float* t = target + (long)jk * hm * hm;
+  for (int i = threadIdx.x; i < hm * hm; i += blockDim.x) {
+    const int y = i / hm, x = i - y * hm;
+    float v = 0.f;
+    if (w > 0.5f && x >= ulx && x < brx && y >= uly && y < bry) v = mp.g[(y - uly) * size + (x - ulx)];
+    t[i] = v;
+  }
+  if (threadIdx.x == 0) weight[jk] = w;
+}
+
 int gather_rows(float* dst, const float* src, const int32_t* idx_dev, long row, int n_rows, int n_outer, long src_os, long dst_os,
                 hipStream_t st) {
   hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(row, 256), n_rows, n_outer), dim3(256), 0, st, dst, src, idx_dev, row, src_os,
                      dst_os);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int preprocess_affine(const PreprocBatch& pb, int n, float* out, int H, hipStream_t st) {
+  hipLaunchKernelGGL(preprocess_affine_kernel, dim3(cdiv((long)H * H, 256), n), dim3(256), 0, st, pb, out, H);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int msra_targets(const float* joints, const float* visible, float* target, float* weight, int n_kpts_total, const MsraP& mp,
+                 hipStream_t st) {
+  hipLaunchKernelGGL(msra_target_kernel, dim3(n_kpts_total), dim3(256), 0, st, joints, visible, target, weight, mp);
   EC_LAUNCH_CHECK();
   return 0;
 }

@@ -171,11 +171,7 @@ class EdgeCape:
         return dict(preds=all_preds, boxes=all_boxes, image_paths=image_paths, bbox_ids=bbox_ids)
 
 
-def load_checkpoint(model, filename, map_location="cpu", strict=True):
-    """mmcv.runner.load_checkpoint stand-in (test.py:124): torch-pickled {'state_dict': ..., 'meta': ...}."""
-    ckpt = torch.load(filename, map_location=map_location, weights_only=False)
-    model.load_state_dict(ckpt, strict=strict)
-    return ckpt
+from .checkpoint import load_checkpoint  # noqa: E402,F401  (mmcv.runner.load_checkpoint stand-in, test.py:124)
 
 
 def hip_library_loaded():

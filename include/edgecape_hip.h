@@ -129,6 +129,23 @@ int ec_support_encode(ec_handle h, ec_support_t s, const float* const* img_s_dev
 int ec_forward_cached(ec_handle h, ec_support_t s, const float* img_q_dev, const int32_t* episode_of_query, int bs,
                       void* stream, const ec_outputs* out);
 
+/* ---- on-device input pipeline (no model handle needed) -----------------------------------
+ * ec_preprocess_images = TopDownAffineFewShot (cv2.warpAffine INTER_LINEAR, constant-0 border;
+ *   EdgeCape/datasets/pipelines/top_down_transform.py:35-58) + ToTensor + NormalizeTensor (configs/test/1shot_split1.py:
+ *   119-125) for n RGB uint8 HWC images already on the device: src_dev = host array of n device pointers, src_hw = host
+ *   [n,2] (rows, cols), src_pitch = host [n] row pitches in bytes or NULL (= cols*3), inv_affine = host [n,6] dst->src 2x3
+ *   matrices (get_affine_transform(center, scale, rot, size, inv=True)), out_dev [n,3,out_size,out_size] fp32.
+ *   Interpolation is exact float bilinear; cv2 quantises the source coordinate to 1/32 px (third-party, absent here:
+ *   parity unpinned).
+ * ec_msra_targets = TopDownGenerateTargetFewShot._msra_generate_target, biased branch (top_down_transform.py:165-194):
+ *   joints_dev [n,K,2] model-input pixels, visible_dev [n,K] -> target_dev [n,K,hm,hm], weight_dev [n,K]; gauss_host = the
+ *   7x7 float32 gaussian computed on the host as the reference does (np.exp on float32), so the result is bit-exact. */
+int ec_preprocess_images(const uint8_t* const* src_dev, const int32_t* src_hw, const int64_t* src_pitch,
+                         const float* inv_affine, int n, int out_size, const float* mean, const float* stdv,
+                         float* out_dev, void* stream);
+int ec_msra_targets(const float* joints_dev, const float* visible_dev, int n, int K, int image_size, int heatmap_size,
+                    int sigma, const float* gauss_host, float* target_dev, float* weight_dev, void* stream);
+
 /* Copy a named intermediate of the LAST forward/head call to a host fp32 buffer (tests only; synchronises). */
 int ec_debug_read(ec_handle h, const char* name, float* host_out, int64_t max_elems, int64_t* n_elems);
 
