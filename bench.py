@@ -47,6 +47,7 @@ def parse():
                     help="head GEMMs: exact fp32 MFMA, or split-bf16 (hi+lo, 3 MFMAs per product; fp32-class accuracy)")
     ap.add_argument("--cpu-sample", type=int, default=4, help="pairs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-episode", action="store_true", help="skip the auxiliary episode-cached measurement")
     return ap.parse_args()
 
 
@@ -154,15 +155,59 @@ def main():
             "roofline": {"bound": "mfma", "kernel": f"backbone QKV GEMM M={Mq} K={Kq} N={Nq} ({args.precision})",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "flops_per_launch": qkv_flops, "avg_launch_ms": round(qkv_ms, 5), "launches_timed": nl.value,
-                         "traffic": None},
+                         **pmc_traffic(args, bs, S, H, arch)},
             "pck_vs_synthetic_gt": {k: round(v, 4) for k, v in pck.items()},
         }
+        if world == 1 and not args.no_episode:
+            result["episode_cached"] = episode_mode(args, eng, synth, batch, bs, S, H)
         if not args.no_cpu_baseline and args.cpu_sample > 0 and world == 1:
             result["cpu_baseline"], result["parity_sample"] = cpu_baseline(args, sd, eng, synth)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
     return result
+
+
+def pmc_traffic(args, bs, S, H, arch):
+    """`traffic` cannot be measured from inside the process: it comes from the committed rocprofv3 --pmc summary of THIS
+    command (profiles/r01_qkv_gemm_pmc.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction,
+    MI355X_MICROARCH.md §HBM) and is only reported for the workload that summary was collected on."""
+    path = os.path.join(ROOT, "profiles", "r01_qkv_gemm_pmc.json")
+    if not (os.path.exists(path) and args.precision == "bf16" and (bs, S, H, arch) == (32, 1, 256, "dinov2_vitb14")):
+        return {"traffic": None}
+    d = json.load(open(path))
+    return {"traffic": d["traffic_bytes_per_launch"], "traffic_unit": "bytes/launch (L2 miss traffic incl. Infinity-Cache hits)",
+            "algorithmic_bytes": d["algorithmic_bytes_per_launch"], "mfma_util_pmc": d["mfma_util"], "traffic_source": "profiles/r01_qkv_gemm_pmc.json"}
+
+
+def episode_mode(args, eng, synth, batch, bs, S, H, steps=5):
+    """Auxiliary number (not `value`): the reference's real evaluation pairs one support set with 15 queries
+    (test_dataset.py:93-97); with the support-side cache (ec_support_encode / ec_forward_cached) a step is: encode
+    ceil(bs/15) support sets, then run bs queries against them."""
+    import torch
+    qpe = 15
+    n_ep = (bs + qpe - 1) // qpe
+    ep = np.arange(bs, dtype=np.int32) // qpe
+    mask = batch["target_weight_s"][0].copy()
+    for tw in batch["target_weight_s"]:
+        mask = mask * tw
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    img_s = [dev(x[:n_ep]) for x in batch["img_s"]]
+    tgt_s = [dev(x[:n_ep]) for x in batch["target_s"]]
+    msk = dev(mask[:n_ep])
+    skel = [m["sample_skeleton"][0] for m in batch["img_metas"][:n_ep]]
+    iq = dev(batch["img_q"])
+    cache = None
+    for i in range(steps + 2):
+        if i == 2:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        cache = eng.support_encode(img_s, tgt_s, msk, skel, cache)
+        eng.forward_cached(iq, cache, ep)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(bs / dt, 2), "unit": "images/s", "queries_per_episode": qpe, "episodes_per_step": n_ep,
+            "ms_per_step": round(dt * 1e3, 3), "note": "support side encoded once per episode (SURVEY §8f rank 1); not the headline metric"}
 
 
 def cpu_baseline(args, sd, eng, synth):

@@ -306,12 +306,221 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// bf16x3 ("split") path for the HEAD's attentions in throughput mode (head_precision = EC_BF16X3): fp32 Q/K/V/O in memory,
+// every MFMA operand is split in registers / at staging time into hi + lo bf16 (hi = RNE(x), lo = RNE(x - hi)) and each
+// product is three v_mfma_f32_32x32x16_bf16 (lo*hi, hi*lo, hi*hi; fp32 accumulate): ~2^-17 relative operand error at
+// 16/3 of the fp32 MFMA rate.  Same transposed formulation as above; softmax statistics, masks (key padding,
+// encoder_decoder.py:301-304,359-360) and the additive Markov bias (bias_attn.py:188-191) in fp32.
+//   * K and V tiles (64 keys) are loaded to registers one tile ahead (global latency under the previous tile's MFMAs),
+//     split, and written as four bf16 LDS images (K hi/lo, V hi/lo), 16-byte chunks XOR-swizzled by row.
+//   * V^T fragments come from the hi and lo images with ds_read_b64_tr_b16 exactly as in the bf16 kernel.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16v2;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+__device__ __forceinline__ void split4(const f32x4 x, u32x2& hi, u32x2& lo) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x[2 * q], x[2 * q + 1]}, bf16v2));
+    const float r0 = x[2 * q] - __uint_as_float(h << 16);
+    const float r1 = x[2 * q + 1] - __uint_as_float(h & 0xffff0000u);
+    hi[q] = h;
+    lo[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16v2));
+  }
+}
+__device__ __forceinline__ void split8v(const f32x4 x0, const f32x4 x1, bf16x8& hi, bf16x8& lo) {
+  u32x2 h0, l0, h1, l1;
+  split4(x0, h0, l0);
+  split4(x1, h1, l1);
+  hi = __builtin_bit_cast(bf16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
+  lo = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_split_kernel(AttnP p) {
+  constexpr int ROWB = HD * 2;             // bytes per bf16 row of an LDS image
+  constexpr int IMG = 64 * ROWB;           // one image: 64 keys
+  constexpr int KS16 = HD / 16;            // k16 MFMA steps of S^T
+  constexpr int DT = HD / 32;              // 32-wide d tiles of O^T
+  constexpr int PIECES = 64 * HD / 4 / 256;   // float4 pieces per thread per tile (K and V each)
+  __shared__ __attribute__((aligned(16))) char lds[4 * IMG];   // K hi | K lo | V hi | V lo
+  char* const Khi = lds; char* const Klo = lds + IMG; char* const Vhi = lds + 2 * IMG; char* const Vlo = lds + 3 * IMG;
+  auto swz = [](int row) { return HD == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hi = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const float* Q = (const float*)p.Q + (long)b * p.sQ + h * HD;
+  const float* K = (const float*)p.K + (long)b * p.sK + h * HD;
+  const float* V = (const float*)p.V + (long)b * p.sV + h * HD;
+  constexpr float LOG2E = 1.44269504088896340736f;
+  const float scale = rsqrtf((float)HD) * LOG2E;
+
+  // Q fragments (B operand of S^T): lane (query j, k-half hi) holds k = 16 m + 8 hi .. +7, pre-scaled, split once
+  bf16x8 qh[KS16], ql[KS16];
+  {
+    int qr = q0 + j;
+    qr = qr < p.Lq ? qr : p.Lq - 1;
+    const float* src = Q + (long)qr * p.ldq + hi * 8;
+#pragma unroll
+    for (int m = 0; m < KS16; ++m) {
+      f32x4 x0 = *(const f32x4*)(src + m * 16), x1 = *(const f32x4*)(src + m * 16 + 4);
+      x0 *= scale; x1 *= scale;
+      split8v(x0, x1, qh[m], ql[m]);
+    }
+  }
+  f32x16 ot[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
+  float mrun = -1e30f, lrun = 0.f;
+  const uint8_t* km = p.kmask ? p.kmask + (long)(p.mask_mod > 0 ? b % p.mask_mod : b) * p.mask_len : nullptr;
+  const float* bias = p.bias ? p.bias + ((long)(b * p.H + h) * p.Lq) * p.Lk : nullptr;
+  const int qrow = (q0 + j) < p.Lq ? (q0 + j) : p.Lq - 1;
+
+  // register-staged tile: piece it of this thread = row r, float4 column c4 (d = 4 c4 .. +3)
+  f32x4 kreg[PIECES], vreg[PIECES];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < PIECES; ++it) {
+      const int idx = tid + it * 256;
+      const int r = idx / (HD / 4), c4 = idx % (HD / 4);
+      int kr = k0 + r;
+      kr = kr < p.Lk ? kr : p.Lk - 1;
+      kreg[it] = *(const f32x4*)(K + (long)kr * p.ldk + c4 * 4);
+      vreg[it] = *(const f32x4*)(V + (long)kr * p.ldv + c4 * 4);
+    }
+  };
+  auto write_tile = [&]() {
+#pragma unroll
+    for (int it = 0; it < PIECES; ++it) {
+      const int idx = tid + it * 256;
+      const int r = idx / (HD / 4), c4 = idx % (HD / 4);
+      const int off = r * ROWB + (((c4 >> 1) ^ swz(r)) << 4) + (c4 & 1) * 8;
+      u32x2 a, c;
+      split4(kreg[it], a, c);
+      *(u32x2*)(Khi + off) = a; *(u32x2*)(Klo + off) = c;
+      split4(vreg[it], a, c);
+      *(u32x2*)(Vhi + off) = a; *(u32x2*)(Vlo + off) = c;
+    }
+  };
+
+  load_tile(0);
+  for (int k0 = 0; k0 < p.Lk; k0 += 64) {
+    __syncthreads();            // every wave is done reading the previous tile
+    write_tile();
+    __syncthreads();
+    if (k0 + 64 < p.Lk) load_tile(k0 + 64);   // next tile's global loads fly under this tile's MFMAs
+
+    f32x16 s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+      const int row = t * 32 + j;
+#pragma unroll
+      for (int m = 0; m < KS16; ++m) {
+        const int off = row * ROWB + (((2 * m + hi) ^ swz(row)) << 4);
+        const bf16x8 ah = *(const bf16x8*)(Khi + off), al = *(const bf16x8*)(Klo + off);
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[m], s[t], 0, 0, 0);
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[m], s[t], 0, 0, 0);
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[m], s[t], 0, 0, 0);
+      }
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kg = k0 + t * 32 + acc_row(r, hi);
+        float v = s[t][r];
+        if (bias && kg < p.Lk) v = fmaf(bias[(long)qrow * p.Lk + kg], LOG2E, v);
+        bool masked = kg >= p.Lk;
+        if (km && !masked && kg >= p.mask_start) masked = km[kg - p.mask_start] != 0;
+        v = masked ? -INFINITY : v;
+        s[t][r] = v;
+        tmax = fmaxf(tmax, v);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mnew = fmaxf(mrun, tmax);
+    const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+    mrun = mnew;
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[t][r] - mnew);
+        s[t][r] = e;
+        psum += e;
+      }
+    lrun = lrun * alpha + psum;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+    // O^T += V^T P^T.  Accumulator registers 8 uu .. 8 uu + 7 of sub-tile t are exactly the eight k-slots this lane feeds.
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) {
+        bf16x8 ph, pl;
+        split8v(f32x4{s[t][8 * uu], s[t][8 * uu + 1], s[t][8 * uu + 2], s[t][8 * uu + 3]},
+                f32x4{s[t][8 * uu + 4], s[t][8 * uu + 5], s[t][8 * uu + 6], s[t][8 * uu + 7]}, ph, pl);
+        const int i16 = lane & 15, G = (lane >> 4) & 1;
+        const int krow = 32 * t + 16 * uu + 4 * hi + (i16 >> 2);   // second 4-key block: + 8
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          const int chunk = 4 * d + 2 * G + ((i16 >> 1) & 1);
+          const int o0 = krow * ROWB + ((chunk ^ swz(krow)) << 4) + (i16 & 1) * 8;
+          const int o1 = (krow + 8) * ROWB + ((chunk ^ swz(krow + 8)) << 4) + (i16 & 1) * 8;
+          const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(Vhi + o0));
+          const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(Vhi + o1));
+          const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(Vlo + o0));
+          const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(Vlo + o1));
+          bf16x8 vh, vl;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { vh[e] = h0[e]; vh[4 + e] = h1[e]; vl[e] = l0[e]; vl[4 + e] = l1[e]; }
+          ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, ot[d], 0, 0, 0);
+          ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, ot[d], 0, 0, 0);
+          ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, ot[d], 0, 0, 0);
+        }
+      }
+  }
+  lrun += __shfl_xor(lrun, 32, 64);
+  const float inv = 1.f / lrun;
+  if (q0 + j < p.Lq) {
+    float* O = (float*)p.O + (long)b * p.sO + (long)(q0 + j) * p.ldo + h * HD;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+        v[0] = ot[d][4 * g] * inv; v[1] = ot[d][4 * g + 1] * inv; v[2] = ot[d][4 * g + 2] * inv; v[3] = ot[d][4 * g + 3] * inv;
+        *(f32x4*)(O + d * 32 + 8 * g + 4 * hi) = v;
+      }
+  }
+}
+
 }  // namespace
 
 int attention(const AttnP& p, hipStream_t st) {
   EC_REQUIRE(p.B > 0 && p.H > 0 && p.Lq > 0 && p.Lk > 0, -1, "attention: empty problem");
   EC_REQUIRE(p.hd == 32 || p.hd == 64, -1, "attention: head dim must be 32 or 64");
   dim3 grid((p.Lq + 127) / 128, p.H, p.B);
+  if (!p.bf16 && p.split) {
+    EC_REQUIRE(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldv % 4 == 0 && p.ldo % 4 == 0, -1, "attention: strides must be multiples of 4");
+    if (p.hd == 64) hipLaunchKernelGGL(attn_split_kernel<64>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(attn_split_kernel<32>, grid, dim3(256), 0, st, p);
+    EC_LAUNCH_CHECK();
+    return 0;
+  }
   if (!p.bf16) {
     EC_REQUIRE(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldv % 4 == 0 && p.ldo % 4 == 0, -1, "attention: strides must be multiples of 4");
     // few workgroups (Lq = 100 keypoint queries: one 128-query block per (batch, head) = 1 workgroup per CU): use 2-wave

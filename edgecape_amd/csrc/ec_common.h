@@ -142,6 +142,7 @@ struct AttnP {
   const float* bias = nullptr;                  // [B, H, Lq, Lk]
   int B = 0, H = 0, Lq = 0, Lk = 0, hd = 0;
   int bf16 = 0;                                 // Q/K/V/O are bf16
+  int split = 0;                                // fp32 data, bf16x3 MFMAs (head throughput mode)
 };
 int attention(const AttnP& p, hipStream_t st);
 

@@ -6,6 +6,7 @@
 // (bf16 for GEMM operands in bf16 mode), batch-first — unlike the reference's seq-first [L, bs, c] —
 // so every Linear is one NT GEMM over M = batch*tokens rows and attention reads heads as column slices.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -72,6 +73,11 @@ struct ec_model {
   bool finalized = false;
   bool bb16 = false;
   bool head_split = false;   // head GEMMs in bf16x3 (ec_gemm.hip GM_SPLIT)
+  // the support half of the head (pooling + SkeletonPredictor) has no query input: it runs on a side stream, concurrently
+  // with input_proj / encoder / proposal generator on the caller's stream (both are small-grid, latency-bound kernels)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_sk = nullptr, ev_join = nullptr;
+  bool overlap = false;
   std::unordered_map<std::string, Tensor> tensors;
   std::vector<void*> owned;  // every hipMalloc'd pointer
   std::unordered_map<std::string, std::pair<const float*, long>> taps;
@@ -442,6 +448,7 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
     a.kmask = io.kmask_fixed; a.mask_start = 0; a.mask_len = K; a.mask_mod = io.bs;
     a.bias = io.bias;
     a.B = io.nb; a.H = nh; a.Lq = K; a.Lk = K; a.hd = d / nh;
+    a.split = m->head_split ? 1 : 0;   // head throughput mode: bf16x3 MFMAs
     RUN(attention(a, st));
   }
   RUN(linear(att, d, false, L.sa_out, tmp, d, false, Mk, ACT_NONE, st, nullptr, io.x, io.ldx));
@@ -466,6 +473,7 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
     a.ldq = E; a.ldk = a.ldv = ldkv; a.ldo = E;
     a.sQ = (long)K * E; a.sK = a.sV = (long)HW * ldkv; a.sO = (long)K * E;
     a.B = io.nb; a.H = nh; a.Lq = K; a.Lk = HW; a.hd = E / nh;
+    a.split = m->head_split ? 1 : 0;   // head throughput mode: bf16x3 MFMAs
     RUN(attention(a, st));
   }
   RUN(linear(att, E, false, L.ca_fold, tmp, d, false, Mk, ACT_NONE, st, nullptr, io.x, io.ldx));
@@ -494,6 +502,7 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
     a.ldq = E; a.ldk = a.ldv = 2 * E; a.ldo = E;
     a.sQ = (long)HW * E; a.sK = a.sV = (long)K * 2 * E; a.sO = (long)HW * E;
     a.B = io.nb; a.H = nh; a.Lq = HW; a.Lk = K; a.hd = E / nh;
+    a.split = m->head_split ? 1 : 0;   // head throughput mode: bf16x3 MFMAs
     RUN(attention(a, st));
     RUN(linear(attimg, E, false, L.i2t_fold, tmpimg, d, false, Mi, ACT_NONE, st, nullptr, io.mem, d));
     RUN(ln(tmpimg, d, io.mem, d, false, L.n4, Mi, d, 1e-5f, st));
@@ -527,7 +536,7 @@ struct SupportState {
 
 // Support half of TwoStageHead.forward (head.py:175-200): pooling + query_proj + SkeletonPredictor.
 static int run_head_support(ec_model* m, const float* const* fs, const float* const* target_s, const float* mask_s, int bs, int S,
-                            hipStream_t st, const SupportState& ss) {
+                            hipStream_t st, const SupportState& ss, hipEvent_t ev_sk = nullptr) {
   const int C = m->C, d = m->d, K = m->K, HW = m->HW, g = m->g;
   const int Fs = m->cfg.skel_ffn_dim, hops1 = m->cfg.max_hops + 1;
   const int Mk = bs * K, Mi = bs * HW;
@@ -550,6 +559,7 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
 
   // (3) skeleton head (skeleton.py:58-161)
   RUN(adj_build(m->d_edges, m->d_off, mask_s, ss.valid, ss.kmask, ss.kmask_fixed, m->binary, m->adj_r1, bs, K, st));
+  if (ev_sk) EC_HIP(hipEventRecord(ev_sk, st));   // support tokens + key masks are ready: the encoder may start
   const int nb = S * bs;
   for (int s = 0; s < S; ++s) {
     RUN(linear(fs[s], C, false, m->image_project, m->s_mem + (long)s * Mi * d, d, false, Mi, ACT_NONE, st));
@@ -595,7 +605,8 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
 }
 
 // Query half of TwoStageHead.forward (head.py:169-173, 202-222): input_proj, encoder, proposal generator, decoder, kpt branches.
-static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, const ec_outputs* out, const SupportState& ss) {
+static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, const ec_outputs* out, const SupportState& ss,
+                          hipEvent_t wait_sk = nullptr, hipEvent_t wait_adj = nullptr) {
   const int C = m->C, d = m->d, E = m->E, K = m->K, HW = m->HW, L = m->L, g = m->g, nh = m->cfg.nhead;
   const int Fd = m->cfg.ffn_dim, hops1 = m->cfg.max_hops + 1;
   const int Mk = bs * K;
@@ -612,6 +623,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     p.M = HW; p.N = d; p.K = C; p.batch = bs;
     RUN(gemm_nt(p, st));
   }
+  if (wait_sk) EC_HIP(hipStreamWaitEvent(st, wait_sk, 0));
   RUN(copy3d(m->e_x + (long)HW * d, d, (long)L * d, ss.sk, d, (long)K * d, bs, K, d, st));
 
   // (4) encoder (encoder_decoder.py:276-310, 461-483) over [bs, L = HW + K, d]
@@ -626,6 +638,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     a.sQ = a.sK = a.sV = (long)L * 3 * d; a.sO = (long)L * d;
     a.kmask = ss.kmask; a.mask_start = HW; a.mask_len = K; a.mask_mod = 0;
     a.B = bs; a.H = nh; a.Lq = L; a.Lk = L; a.hd = d / nh;
+    a.split = m->head_split ? 1 : 0;   // head throughput mode: bf16x3 MFMAs
     RUN(attention(a, st));
     RUN(linear(m->e_att, d, false, e.out, m->e_tmp, d, false, Me, ACT_NONE, st, nullptr, m->e_x, d));
     RUN(ln(m->e_tmp, d, m->e_x, d, false, e.n1, Me, d, 1e-5f, st));
@@ -674,6 +687,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     p.M = HW; p.N = nL * 2 * E; p.K = d; p.batch = bs;
     RUN(gemm_nt(p, st));
   }
+  if (wait_adj) EC_HIP(hipStreamWaitEvent(st, wait_adj, 0));   // adjacency / Markov stack from the support side
   for (size_t li = 0; li < m->dec.size(); ++li) {
     const DecLayer& Ld = m->dec[li];
     float* bi = pts + (long)li * Mk * 2;
@@ -722,6 +736,13 @@ static SupportState workspace_support(ec_model* m, const ec_outputs* out) {
 static int run_head(ec_model* m, const float* fq, const float* const* fs, const float* const* target_s, const float* mask_s,
                     int bs, int S, hipStream_t st, const ec_outputs* out) {
   const SupportState ss = workspace_support(m, out);
+  if (m->overlap) {
+    EC_HIP(hipEventRecord(m->ev_fork, st));
+    EC_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+    RUN(run_head_support(m, fs, target_s, mask_s, bs, S, m->side, ss, m->ev_sk));
+    EC_HIP(hipEventRecord(m->ev_join, m->side));
+    return run_head_query(m, fq, bs, st, out, ss, m->ev_sk, m->ev_join);   // st joins the side stream before the decoder
+  }
   RUN(run_head_support(m, fs, target_s, mask_s, bs, S, st, ss));
   return run_head_query(m, fq, bs, st, out, ss);
 }
@@ -783,6 +804,8 @@ int ec_destroy(ec_handle m) {
   if (!m) return EC_OK;
   for (void* p : m->owned) (void)hipFree(p);
   for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
+  if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
+  for (hipEvent_t e : {m->ev_fork, m->ev_sk, m->ev_join}) if (e) (void)hipEventDestroy(e);
   delete m;
   return EC_OK;
 }
@@ -951,6 +974,16 @@ int ec_finalize(ec_handle m) {
   WS(d_hs, 3 * Mk * d); WS(d_pts, 4 * Mk * 2); WS(d_k1, Mk * d); WS(d_k2, Mk * d);
 #undef WS
   EC_REQUIRE(m->pg_dyn0.N <= 128, EC_ERR_ARG, "dynamic_proj_dim must be <= 128");
+  {
+    const char* ov = getenv("EC_OVERLAP");
+    m->overlap = !(ov && atoi(ov) == 0);
+    if (m->overlap) {
+      EC_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+      EC_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+      EC_HIP(hipEventCreateWithFlags(&m->ev_sk, hipEventDisableTiming));
+      EC_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    }
+  }
   EC_HIP(hipDeviceSynchronize());
   m->finalized = true;
   return EC_OK;
@@ -1264,6 +1297,7 @@ int ec_op_attention(const float* q, const float* k, const float* v, const uint8_
   a.kmask = kmask; a.mask_start = 0; a.mask_len = Lk; a.mask_mod = 0;
   a.bias = bias;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.hd = hd;
+  a.split = precision == EC_BF16X3;
   return attention(a, (hipStream_t)stream);
 }
 

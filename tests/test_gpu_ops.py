@@ -181,6 +181,32 @@ def test_attention_fp32(lib, B, H, Lq, Lk, hd, masked, biased):
     assert err < 2e-5, err
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,hd,masked,biased", [
+    (2, 8, 100, 100, 32, True, False), (2, 8, 100, 100, 32, True, True), (2, 8, 424, 424, 32, True, False),
+    (2, 8, 100, 324, 64, False, False), (2, 8, 324, 100, 64, False, False), (1, 12, 130, 70, 64, True, False),
+    (1, 8, 37, 53, 32, False, True), (3, 8, 829, 829, 32, True, False)])
+def test_attention_bf16x3(lib, B, H, Lq, Lk, hd, masked, biased):
+    """Split-bf16 attention of the head's throughput mode vs fp64 math: fp32-class accuracy."""
+    g = torch.Generator().manual_seed(B * 1000 + Lq + Lk + hd)
+    q = torch.randn(B, Lq, H * hd, generator=g) * 1.5
+    k = torch.randn(B, Lk, H * hd, generator=g) * 1.5
+    v = torch.randn(B, Lk, H * hd, generator=g)
+    kmask = None
+    if masked:
+        kmask = (torch.rand(B, Lk, generator=g) < 0.4).to(torch.uint8)
+        kmask[:, 0] = 0
+    bias = torch.randn(B, H, Lq, Lk, generator=g) if biased else None
+    ref = _attn_ref(q, k, v, H, hd, kmask, bias)
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    md = kmask.cuda() if masked else None
+    bd = bias.cuda() if biased else None
+    od = torch.empty(B, Lq, H * hd, device="cuda")
+    _chk(lib, lib.ec_op_attention(_p(qd), _p(kd), _p(vd), _p(md), _p(bd), _p(od), B, H, Lq, Lk, hd, 2, None))
+    torch.cuda.synchronize()
+    err = (od.cpu() - ref).abs().max().item()
+    assert err < 1e-4, err          # plain bf16 operands give ~1e-2 here
+
+
 @pytest.mark.parametrize("B,H,L", [(2, 6, 257), (2, 12, 325), (1, 16, 730), (1, 6, 64)])
 def test_attention_bf16(lib, B, H, L):
     """bf16 MFMA attention (backbone shape) vs fp64 math on the bf16-rounded operands."""
