@@ -173,7 +173,9 @@ constexpr int A16_TILE = 64 * 128;           // 8 KiB per tile
 constexpr int A16_STAGE = 2 * A16_TILE;      // K + V^T
 constexpr int A16_LDS = 2 * A16_STAGE;       // double buffered: 32 KiB
 
-__global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
+// __launch_bounds__(256, 2): with a 256-register budget hipcc keeps the MFMA accumulators in VGPRs (no v_accvgpr_read/write
+// copies around the softmax: -90 of ~410 VALU instructions per key tile; the kernel is VALU-bound at 16 MFMAs per tile).
+__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -216,54 +218,66 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
 
   stage(0, smem);
   int cur = 0;
+  const bool active = q0 < p.Lq;   // a wave whose 32 queries are all past Lq only helps staging (wave-uniform)
   for (int k0 = 0; k0 < p.Lk; k0 += 64) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (k0 + 64 < p.Lk) stage(k0 + 64, smem + (cur ^ 1) * A16_STAGE);
     const char* Kt = smem + cur * A16_STAGE;
     const char* Vtt = Kt + A16_TILE;
+    cur ^= 1;
+    if (!active) continue;
+    const bool edge = k0 + 64 > p.Lk;    // only the last tile needs the key-range mask
     f32x16 s[2];
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
       const int row = t * 32 + j;
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const bf16x8 a = *(const bf16x8*)(Kt + row * 128 + (((2 * m + hi) ^ ((row >> 1) & 7)) << 4));
-        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[m], s[t], 0, 0, 0);
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[m], m == 0 ? zero16 : s[t], 0, 0, 0);   // C = inline 0 on the first step
       }
     }
+    if (edge) {   // last key tile only (a real branch: the empty asm keeps the compiler from if-converting it into 64 selects)
+      asm volatile("" ::: "memory");
+      const int lim = p.Lk - k0 - 4 * hi;          // key (t, r) is out of range  <=>  32 t + (r&3) + 8 (r>>2) >= lim
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (32 * t + (r & 3) + 8 * (r >> 2) >= lim) s[t][r] = -INFINITY;
+    }
+    // raw-score maximum (the scale c > 0 is folded into the exponent below)
     float tmax = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kg = k0 + t * 32 + acc_row(r, hi);
-        const float v = kg < p.Lk ? s[t][r] * c : -INFINITY;
-        s[t][r] = v;
-        tmax = fmaxf(tmax, v);
-      }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float mnew = fmaxf(mrun, tmax);
-    const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-    mrun = mnew;
+      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[t][r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * c;
+    // running maximum: rescale O^T only when some query's maximum actually grew (exact: alpha == 1 otherwise)
+    if (!__all(tmax <= mrun)) {
+      const float mnew = fmaxf(mrun, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+      mrun = mnew;
+      lrun *= alpha;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+    }
     float psum = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(s[t][r] - mnew);
+        const float e = __builtin_amdgcn_exp2f(fmaf(s[t][r], c, -mrun));
         s[t][r] = e;
         psum += e;
       }
-    lrun = lrun * alpha + psum;
+    lrun += psum;
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
 #pragma unroll
       for (int uu = 0; uu < 2; ++uu) {
         f32x8 pv;
@@ -288,7 +302,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
           ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pb, ot[d], 0, 0, 0);
         }
       }
-    cur ^= 1;
+    }
   }
   lrun += __shfl_xor(lrun, 32, 64);
   const float inv = 1.f / lrun;
@@ -341,7 +355,7 @@ __device__ __forceinline__ void split8v(const f32x4 x0, const f32x4 x1, bf16x8& 
 }
 
 template <int HD>
-__global__ __launch_bounds__(256) void attn_split_kernel(AttnP p) {
+__global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
   constexpr int ROWB = HD * 2;             // bytes per bf16 row of an LDS image
   constexpr int IMG = 64 * ROWB;           // one image: 64 keys
   constexpr int KS16 = HD / 16;            // k16 MFMA steps of S^T

@@ -81,6 +81,7 @@ __device__ __forceinline__ void g8_epilogue(const GemmP& p, f32x4 (&acc)[8][4], 
       bias4[ni] = (p.bias && nok) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
       gam4[ni] = (p.gamma && nok) ? *(const f32x4*)(p.gamma + n) : f32x4{1.f, 1.f, 1.f, 1.f};
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile-seam drain (see the kernel), after the bias loads were issued
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
       const int m = mrow + (mi >> 2) * 64 + (mi & 3) * 16;
@@ -119,6 +120,8 @@ __device__ __forceinline__ void g8_epilogue(const GemmP& p, f32x4 (&acc)[8][4], 
       bias4[ni] = nok ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
       if constexpr (KIND == G8_SCALE_BF16) gam4[ni] = nok ? *(const f32x4*)(p.gamma + n) : f32x4{1.f, 1.f, 1.f, 1.f};
     }
+    // tile-seam drain: one wait covers the bias loads just issued AND every LDS-DMA half-tile still in flight
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // Stores go through a per-wave 4 KiB LDS staging slot: a piece = 32 rows x 64 columns of bf16 (two m-fragments) is
     // written fragment-wise (8 x ds_write_b64, 16-byte chunks XOR-swizzled by row) and read back row-wise
     // (4 x ds_read_b128), so every global store instruction writes 8 full 128-byte lines (16 B per lane) instead of 16
@@ -322,12 +325,11 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
     }
 
     // ---- epilogue.  Both groups run it concurrently: group 0 passes the tile's last barrier first, group 1 after.
-    // Tile seam: every half-tile issued so far (stream indices up to 4 of the NEXT tile) is drained here, before any
-    // store is issued, so the first three phases of the next tile need no wait; from its phase 3 on, vmcnt(6) covers
+    // Tile seam: every half-tile issued so far (stream indices up to 4 of the NEXT tile) is drained at the top of the
+    // epilogue (g8_epilogue, right after its bias loads are issued), before any store is issued, so the first three phases of the next tile need no wait; from its phase 3 on, vmcnt(6) covers
     // loads issued after this point (loads retire in order among themselves; the epilogue's stores, also counted by
     // vmcnt, can only make that wait stricter) while the stores drain in the background under the next tile's MFMAs.
     if (wr == 0) G8_BAR();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     {
       const int m0 = (t / ntn) << 8, n0 = (t % ntn) << 8;
       if (KIND != G8_GENERIC && m0 + 256 <= p.M && n0 + 256 <= p.N) g8_epilogue<KIND, true>(p, acc, smem, m0, n0, wr, wc, lane);
