@@ -783,7 +783,8 @@ int ec_create(const ec_config* cfg, ec_handle* out) {
   EC_REQUIRE(cfg->patch == 14, EC_ERR_ARG, "patch size must be 14");
   EC_REQUIRE(cfg->embed_dim % 64 == 0 && cfg->embed_dim / cfg->num_heads == 64, EC_ERR_ARG, "backbone head dim must be 64");
   EC_REQUIRE(cfg->d_model == 256 && cfg->nhead == 8, EC_ERR_ARG, "head d_model/nhead must be 256/8");
-  EC_REQUIRE(cfg->num_kpts > 0 && cfg->num_kpts <= 128 && cfg->num_kpts % 4 == 0, EC_ERR_ARG, "num_kpts must be a multiple of 4, <= 128");
+  // K is dynamic in the reference (target_s[0].shape[1]; 100 in the test configs, the number of clicked points in the demos)
+  EC_REQUIRE(cfg->num_kpts > 0 && cfg->num_kpts <= 128, EC_ERR_ARG, "num_kpts must be within 1..128");
   EC_REQUIRE(cfg->max_hops == 4, EC_ERR_ARG, "max_hops must be 4");
   EC_REQUIRE(cfg->head_precision == EC_F32 || cfg->head_precision == EC_BF16X3, EC_ERR_ARG,
              "head_precision: EC_F32 (exact) or EC_BF16X3 (split-bf16 MFMA, fp32-class accuracy)");
@@ -1111,8 +1112,8 @@ int ec_forward_cached(ec_handle m, ec_support_t c, const float* img_q, const int
   const long K = m->K, KK = K * K;
   RUN(gather_rows(ws.sk, c->ss.sk, c->d_idx, K * m->d, bs, 1, 0, 0, st));
   RUN(gather_rows(ws.valid, c->ss.valid, c->d_idx, K, bs, 1, 0, 0, st));
-  RUN(gather_rows((float*)ws.kmask, (const float*)c->ss.kmask, c->d_idx, K / 4, bs, 1, 0, 0, st));            // K % 4 == 0
-  RUN(gather_rows((float*)ws.kmask_fixed, (const float*)c->ss.kmask_fixed, c->d_idx, K / 4, bs, 1, 0, 0, st));
+  RUN(gather_bytes(ws.kmask, c->ss.kmask, c->d_idx, K, bs, st));
+  RUN(gather_bytes(ws.kmask_fixed, c->ss.kmask_fixed, c->d_idx, K, bs, st));
   RUN(gather_rows(ws.adj1, c->ss.adj1, c->d_idx, KK, bs, 1, 0, 0, st));
   RUN(gather_rows(ws.adj_out, c->ss.adj_out, c->d_idx, 2 * KK, bs, 1, 0, 0, st));
   RUN(gather_rows(ws.attn_adj, c->ss.attn_adj, c->d_idx, KK, bs, m->cfg.max_hops + 1, (long)c->n * KK, (long)bs * KK, st));

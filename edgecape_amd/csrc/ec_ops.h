@@ -25,6 +25,7 @@ int add_table(float* x, long ldx, const float* table, long ldt, int period, int 
 int copy2d(float* dst, long ldd, const float* src, long lds, int rows, int cols, hipStream_t st);
 // dst[b][r][c] = src[b][r][c] for b < batch with batch strides
 int copy3d(float* dst, long ldd, long sd, const float* src, long lds, long ss, int batch, int rows, int cols, hipStream_t st);
+int gather_bytes(uint8_t* dst, const uint8_t* src, const int32_t* idx_dev, int row, int n_rows, hipStream_t st);
 int mean_over(float* dst, const float* src, long stride, int n, long count, hipStream_t st);
 // dst[o][b][0..row) = src[o][idx[b]][0..row) for b < n_rows, o < n_outer (outer strides in floats)
 int gather_rows(float* dst, const float* src, const int32_t* idx_dev, long row, int n_rows, int n_outer, long src_os, long dst_os,

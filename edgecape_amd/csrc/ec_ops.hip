@@ -99,6 +99,11 @@ __global__ void gather_rows_kernel(float* dst, const float* src, const int32_t* 
   dst[o * dst_os + (long)b * row + i] = src[o * src_os + (long)idx[b] * row + i];
 }
 
+__global__ void gather_bytes_kernel(uint8_t* dst, const uint8_t* src, const int32_t* idx, int row) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < row) dst[(long)blockIdx.y * row + i] = src[(long)idx[blockIdx.y] * row + i];
+}
+
 __global__ void mean_over_kernel(float* dst, const float* src, long stride, int n, long count) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
@@ -599,6 +604,12 @@ int preprocess_affine(const PreprocBatch& pb, int n, float* out, int H, hipStrea
 int msra_targets(const float* joints, const float* visible, float* target, float* weight, int n_kpts_total, const MsraP& mp,
                  hipStream_t st) {
   hipLaunchKernelGGL(msra_target_kernel, dim3(n_kpts_total), dim3(256), 0, st, joints, visible, target, weight, mp);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int gather_bytes(uint8_t* dst, const uint8_t* src, const int32_t* idx_dev, int row, int n_rows, hipStream_t st) {
+  hipLaunchKernelGGL(gather_bytes_kernel, dim3(cdiv(row, 128), n_rows), dim3(128), 0, st, dst, src, idx_dev, row);
   EC_LAUNCH_CHECK();
   return 0;
 }

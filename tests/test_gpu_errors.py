@@ -50,7 +50,7 @@ def test_missing_weight_and_call_order():
     y = torch.zeros(1, 256, 384, device="cuda")
     assert lib.ec_backbone(h, x.data_ptr(), 1, y.data_ptr(), 0, None) == -3 and b"finalized" in lib.ec_last_error()      # EC_ERR_STATE
     assert lib.ec_finalize(h) == -3 and b"missing tensor" in lib.ec_last_error()
-    bad = _lib.EcConfig(**{**{f[0]: getattr(cfg, f[0]) for f in cfg._fields_}, "num_kpts": 17})
+    bad = _lib.EcConfig(**{**{f[0]: getattr(cfg, f[0]) for f in cfg._fields_}, "num_kpts": 129})
     h2 = C.c_void_p()
     assert lib.ec_create(C.byref(bad), C.byref(h2)) == -1 and b"num_kpts" in lib.ec_last_error()                           # EC_ERR_ARG
     assert lib.ec_destroy(h) == 0
@@ -91,3 +91,23 @@ def test_detector_rejects_what_the_reference_rejects():
                  pretrained="dinov2_vits14")
     with pytest.raises(KeyError):
         EdgeCape(keypoint_head=head, pretrained="resnet50")
+
+
+@pytest.mark.parametrize("K", [17, 5, 1])
+def test_dynamic_keypoint_count_like_the_demo(K):
+    """The demos call the model with K = number of clicked points and all weights 1 (gradio_utils/utils.py:142-148) — K is
+    whatever target_s[0].shape[1] says.  Checked against the oracle (the golden fixtures are K = 100)."""
+    from oracle import edgecape_oracle as orc
+    from edgecape_amd.engine import HipEngine
+    arch, H, bs = "dinov2_vits14", 224, 2
+    sd = synth.make_weights(arch, seed=8)
+    b = synth.make_pairs(bs, 1, H, seed=21, n_kp=K, K=K)
+    res_ref, out_ref = orc.forward_test(sd, b, synth.ARCHS[arch]["heads"])
+    e = HipEngine(sd, arch=arch, image_size=H, max_batch=bs, max_shots=1, num_kpts=K)
+    mask = b["target_weight_s"][0]
+    o = e.forward(b["img_q"], b["img_s"], b["target_s"], mask, [m["sample_skeleton"][0] for m in b["img_metas"]])
+    torch.cuda.synchronize()
+    err = np.abs(o["output_kpts"].cpu().numpy() - out_ref["output_kpts"].numpy()).max()
+    eadj = np.abs(o["adj"].cpu().numpy() - out_ref["adj"].numpy()).max()
+    print("K", K, "kpt err", err, "adj err", eadj)
+    assert o["output_kpts"].shape == (3, bs, K, 2) and err < 1e-3 and eadj < 1e-4
