@@ -248,3 +248,30 @@ def test_linear_tile_configs(lib, M, N, K, prec):
     torch.cuda.synchronize()
     err = (Cd.cpu() - ref).abs().max().item()
     assert err < tol * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("M,N,K", [(20800, 2304, 768), (4099, 768, 3072), (2600, 1152, 384)])
+def test_gemm8_race_screen(lib, M, N, K):
+    """The 8-phase kernel orders LDS-DMA writes and ds_reads only by counted vmcnt + barriers (ec_gemm8.hip header): an
+    early read shows up as rare wrong tiles that depend on timing.  Run the same problem repeatedly, alone and beside a
+    bandwidth-heavy kernel on another stream, and require bit-identical results that also match the reference."""
+    g = torch.Generator().manual_seed(M)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
+    ref = (Ad.bfloat16().double() @ Wd.bfloat16().double().T + bd.double()).float()
+    outs = []
+    noise = torch.empty(64 * 1024 * 1024, device="cuda")
+    side = torch.cuda.Stream()
+    for it in range(12):
+        Cd = torch.empty(M, N, device="cuda")
+        if it >= 4:                                   # perturb timing: stream 256 MB through HBM concurrently
+            with torch.cuda.stream(side):
+                noise.add_(1.0)
+        _chk(lib, lib.ec_op_linear(_p(Ad), _p(Wd), _p(bd), None, None, _p(Cd), M, N, K, 0, 1, None))
+        torch.cuda.synchronize()
+        outs.append(Cd)
+    assert (outs[0] - ref).abs().max().item() < 3e-4
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
