@@ -89,9 +89,14 @@ __device__ __forceinline__ void split8(const f32x4 x0, const f32x4 x1, bf16x8& h
   lo = __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], l[2], l[3]});
 }
 
-template <int MODE, int BM, int BN, int WGM, int WGN, int TAG>
+// NS = depth of the LDS stage ring.  The load stream (LDS-DMA) runs NS-1 stages ahead of the compute position and crosses
+// tile boundaries; each K-step waits with a COUNTED vmcnt for its own stage only, so NS-2 stages stay in flight across
+// the barrier.  The head's GEMMs are short (K = 256 = 8 stages) and small: with NS = 2 every K-step pays a full load
+// latency; with NS = 4 the latencies overlap (cdna_hip_programming.md §5 "Pipelining across barriers").
+template <int MODE, int BM, int BN, int WGM, int WGN, int NS, int TAG>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_nt_kernel(GemmP p) {
   constexpr bool BF16 = MODE == GM_BF16;
+  constexpr int LPS = BM / 8 / (WGM * WGN) + BN / 8 / (WGM * WGN);   // LDS-DMA instructions per thread per stage
   constexpr int NW = WGM * WGN;
   constexpr int MT = BM / WGM / 32, NT = BN / WGN / 32;
   constexpr int A_BYTES = BM * KBYTES, B_BYTES = BN * KBYTES, STAGE = A_BYTES + B_BYTES;
@@ -130,12 +135,26 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_nt_kernel(GemmP p) {
   };
 
   int t = xcd * chunk + slot;
+  if (t >= t_end) return;
   int bz, m0, n0;
+  tile_coords(t, bz, m0, n0);
+  // ---- load stream: (ls_t, ls_kt) = next stage to issue, into ring slot ls_slot.  Past the last stage of the workgroup's
+  // last tile the stream stops advancing and re-issues that stage into its own slot (identical bytes), which keeps the
+  // per-step load count - and therefore the counted waits - uniform without a dummy buffer.
+  int ls_t = t, ls_kt = 0, ls_slot = 0, lbz = bz, lm0 = m0, ln0 = n0;
+  auto issue_next = [&]() {
+    stage(lbz, lm0, ln0, ls_kt, smem + ls_slot * STAGE);
+    const int nslot_ = (ls_slot + 1 == NS) ? 0 : ls_slot + 1;
+    if (ls_kt + 1 < nk) {
+      ++ls_kt; ls_slot = nslot_;
+    } else if (ls_t + nslot < t_end) {
+      ls_t += nslot; ls_kt = 0; ls_slot = nslot_;
+      tile_coords(ls_t, lbz, lm0, ln0);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i) issue_next();
   int cur = 0;
-  if (t < t_end) {
-    tile_coords(t, bz, m0, n0);
-    stage(bz, m0, n0, 0, smem);
-  }
   for (; t < t_end; t += nslot) {
     f32x16 acc[NT][MT];
 #pragma unroll
@@ -144,17 +163,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_nt_kernel(GemmP p) {
       for (int j = 0; j < MT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int tn = t + nslot;
-    int bz2 = 0, m02 = 0, n02 = 0;
-    if (tn < t_end) tile_coords(tn, bz2, m02, n02);
+    tile_coords(t, bz, m0, n0);
 
     for (int kt = 0; kt < nk; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      char* nxt = smem + (cur ^ 1) * STAGE;
-      if (kt + 1 < nk) stage(bz, m0, n0, kt + 1, nxt);
-      else if (tn < t_end) stage(bz2, m02, n02, 0, nxt);   // next tile's first K-step lands under this tile's epilogue
+      // this wave's part of the stage about to be computed has landed; NS-2 younger stages stay in flight
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();      // raw barrier: __syncthreads() would drain the LDS-DMA queue (vmcnt(0))
+      __builtin_amdgcn_sched_barrier(0);
+      issue_next();                      // into the slot computed in the previous step (all waves are past it)
       const char* At = smem + cur * STAGE;
       const char* Bt = At + A_BYTES;
       if constexpr (MODE == GM_SPLIT) {
@@ -217,7 +234,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_nt_kernel(GemmP p) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[i][e], xa[j][e], acc[i][j], 0, 0, 0);
         }
       }
-      cur ^= 1;
+      cur = (cur + 1 == NS) ? 0 : cur + 1;
     }
 
     // ---- epilogue.  acc[i][j][r], lane (m_local = lane & 31, hi): column n_local = (r&3) + 8*(r>>2) + 4*hi.
@@ -295,8 +312,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_nt_kernel(GemmP p) {
         }
       }
     }
-    bz = bz2; m0 = m02; n0 = n02;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // duplicate tail stages of the load stream must land before the LDS is released
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -387,13 +404,14 @@ __global__ __launch_bounds__(256) void bgemm_small_kernel(BgemmP p) {
 
 namespace {
 struct Cfg { int bm, bn, threads, lds, per_cu; };
-template <int MODE, int BM, int BN, int WGM, int WGN>
+template <int MODE, int BM, int BN, int WGM, int WGN, int NS>
 int launch_cfg(const GemmP& p, hipStream_t st, int per_cu) {
   typedef void (*kern_t)(GemmP);
-  static const kern_t table[5] = {gemm_nt_kernel<MODE, BM, BN, WGM, WGN, 0>, gemm_nt_kernel<MODE, BM, BN, WGM, WGN, MODE == GM_SPLIT ? 0 : 1>,
-                                  gemm_nt_kernel<MODE, BM, BN, WGM, WGN, MODE == GM_SPLIT ? 0 : 2>, gemm_nt_kernel<MODE, BM, BN, WGM, WGN, MODE == GM_SPLIT ? 0 : 3>,
-                                  gemm_nt_kernel<MODE, BM, BN, WGM, WGN, MODE == GM_SPLIT ? 0 : 4>};
-  constexpr int LDS = 2 * (BM + BN) * KBYTES;
+  constexpr bool TAGGED = MODE != GM_SPLIT && BM == 256;   // per-tag symbols only where rocprof needs to tell the backbone GEMMs apart
+  static const kern_t table[5] = {gemm_nt_kernel<MODE, BM, BN, WGM, WGN, NS, 0>, gemm_nt_kernel<MODE, BM, BN, WGM, WGN, NS, TAGGED ? 1 : 0>,
+                                  gemm_nt_kernel<MODE, BM, BN, WGM, WGN, NS, TAGGED ? 2 : 0>, gemm_nt_kernel<MODE, BM, BN, WGM, WGN, NS, TAGGED ? 3 : 0>,
+                                  gemm_nt_kernel<MODE, BM, BN, WGM, WGN, NS, TAGGED ? 4 : 0>};
+  constexpr int LDS = NS * (BM + BN) * KBYTES;
   static bool attr_done = false;
   if (!attr_done) {
     for (int t = 0; t < 5; ++t)
@@ -436,6 +454,9 @@ int gemm_nt(const GemmP& p, hipStream_t st) {
   // CUs: pick the tile minimising  ceil(tiles / CUs) * tile_area / efficiency.  256x256 only pays for the big backbone
   // GEMMs (fp32 parity mode) where operand re-reads dominate.
   static const int force = getenv("EC_GEMM_TILE") ? atoi(getenv("EC_GEMM_TILE")) : 0;
+  // NS-deep stage ring: measured NEUTRAL on MI355X for the head's shapes (kp 3200x256x256: 8.0 vs 8.2 us; 10368x256x768: 30 vs
+  // 37 us) - those kernels sit at the per-launch floor, not at the load latency - so the 2-stage ring stays the default.
+  static const bool deep = getenv("EC_GEMM_DEEP") && atoi(getenv("EC_GEMM_DEEP")) != 0;
   static int ncu = 0;
   if (!ncu) {
     int dev = 0;
@@ -455,28 +476,28 @@ int gemm_nt(const GemmP& p, hipStream_t st) {
   else if (force == 64) sel = 4;
   if (p.ab_bf16) {
     switch (sel) {
-      case 0: return launch_cfg<GM_BF16, 256, 256, 2, 4>(p, st, 1);
-      case 1: return launch_cfg<GM_BF16, 256, 128, 4, 2>(p, st, 1);
-      case 2: return launch_cfg<GM_BF16, 128, 128, 2, 2>(p, st, 2);
-      case 3: return launch_cfg<GM_BF16, 128, 64, 2, 2>(p, st, 3);
-      default: return launch_cfg<GM_BF16, 64, 64, 2, 2>(p, st, 4);
+      case 0: return (deep ? launch_cfg<GM_BF16, 256, 256, 2, 4, 2>(p, st, 1) : launch_cfg<GM_BF16, 256, 256, 2, 4, 2>(p, st, 1));
+      case 1: return (deep ? launch_cfg<GM_BF16, 256, 128, 4, 2, 3>(p, st, 1) : launch_cfg<GM_BF16, 256, 128, 4, 2, 2>(p, st, 1));
+      case 2: return (deep ? launch_cfg<GM_BF16, 128, 128, 2, 2, 4>(p, st, 1) : launch_cfg<GM_BF16, 128, 128, 2, 2, 2>(p, st, 2));
+      case 3: return (deep ? launch_cfg<GM_BF16, 128, 64, 2, 2, 3>(p, st, 2) : launch_cfg<GM_BF16, 128, 64, 2, 2, 2>(p, st, 3));
+      default: return (deep ? launch_cfg<GM_BF16, 64, 64, 2, 2, 4>(p, st, 2) : launch_cfg<GM_BF16, 64, 64, 2, 2, 2>(p, st, 4));
     }
   }
   if (p.split) {
     switch (sel) {
-      case 0: return launch_cfg<GM_SPLIT, 256, 256, 2, 4>(p, st, 1);
-      case 1: return launch_cfg<GM_SPLIT, 256, 128, 4, 2>(p, st, 1);
-      case 2: return launch_cfg<GM_SPLIT, 128, 128, 2, 2>(p, st, 2);
-      case 3: return launch_cfg<GM_SPLIT, 128, 64, 2, 2>(p, st, 3);
-      default: return launch_cfg<GM_SPLIT, 64, 64, 2, 2>(p, st, 4);
+      case 0: return (deep ? launch_cfg<GM_SPLIT, 256, 256, 2, 4, 2>(p, st, 1) : launch_cfg<GM_SPLIT, 256, 256, 2, 4, 2>(p, st, 1));
+      case 1: return (deep ? launch_cfg<GM_SPLIT, 256, 128, 4, 2, 3>(p, st, 1) : launch_cfg<GM_SPLIT, 256, 128, 4, 2, 2>(p, st, 1));
+      case 2: return (deep ? launch_cfg<GM_SPLIT, 128, 128, 2, 2, 4>(p, st, 1) : launch_cfg<GM_SPLIT, 128, 128, 2, 2, 2>(p, st, 2));
+      case 3: return (deep ? launch_cfg<GM_SPLIT, 128, 64, 2, 2, 3>(p, st, 2) : launch_cfg<GM_SPLIT, 128, 64, 2, 2, 2>(p, st, 3));
+      default: return (deep ? launch_cfg<GM_SPLIT, 64, 64, 2, 2, 4>(p, st, 2) : launch_cfg<GM_SPLIT, 64, 64, 2, 2, 2>(p, st, 4));
     }
   }
   switch (sel) {
-    case 0: return launch_cfg<GM_F32, 256, 256, 2, 4>(p, st, 1);
-    case 1: return launch_cfg<GM_F32, 256, 128, 4, 2>(p, st, 1);
-    case 2: return launch_cfg<GM_F32, 128, 128, 2, 2>(p, st, 2);
-    case 3: return launch_cfg<GM_F32, 128, 64, 2, 2>(p, st, 3);
-    default: return launch_cfg<GM_F32, 64, 64, 2, 2>(p, st, 4);
+    case 0: return (deep ? launch_cfg<GM_F32, 256, 256, 2, 4, 2>(p, st, 1) : launch_cfg<GM_F32, 256, 256, 2, 4, 2>(p, st, 1));
+    case 1: return (deep ? launch_cfg<GM_F32, 256, 128, 4, 2, 3>(p, st, 1) : launch_cfg<GM_F32, 256, 128, 4, 2, 2>(p, st, 1));
+    case 2: return (deep ? launch_cfg<GM_F32, 128, 128, 2, 2, 4>(p, st, 1) : launch_cfg<GM_F32, 128, 128, 2, 2, 2>(p, st, 2));
+    case 3: return (deep ? launch_cfg<GM_F32, 128, 64, 2, 2, 3>(p, st, 2) : launch_cfg<GM_F32, 128, 64, 2, 2, 2>(p, st, 3));
+    default: return (deep ? launch_cfg<GM_F32, 64, 64, 2, 2, 4>(p, st, 2) : launch_cfg<GM_F32, 64, 64, 2, 2, 2>(p, st, 4));
   }
 }
 
