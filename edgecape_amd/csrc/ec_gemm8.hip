@@ -165,7 +165,9 @@ __device__ __forceinline__ void g8_epilogue(const GemmP& p, f32x4 (&acc)[8][4], 
   }
 }
 
-template <int KIND, int TAG>
+// TRACE (debug instantiation only, EC_G8_TRACE=1): lane 0 of every wave of workgroup 0 stamps s_memtime at five points of
+// every phase of one K-tile pair into its LDS staging slot; dumped to p.aux after the first tile (tools/g8_trace.py).
+template <int KIND, int TAG, bool TRACE = false>
 __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -207,6 +209,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
     rp2 = B + (long)min(rb + 32, p.N - 1) * ldb_b;
   };
   auto issue = [&](const char* rp, int half) {
+    if constexpr (TRACE) { if ((p.dbg & 16) && wr == 1) return; }   // experiment: partner group issues no DMA
     const char* src = rp + (long)ls_kt * 128;
     // (dead stream: each wave's dummy loads land in its OWN staging slot, which it only uses after draining its own loads)
     char* dst = smem + (ls_live ? ((ls_kt & 1) * G8_KT + half * G8_HALF + wave * 2048) : (G8_STAGE + wave * 4096));
@@ -235,6 +238,15 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   const char* a_base = smem + rd_off + wr * 8192;                // row-groups 4*wr.. of the A halves
   const char* b_base = smem + rd_off + wc * 4096 + G8_HALF;      // row-groups 2*wc.. of the B halves (B-h0 is slot 1)
 
+#define G8_STAMP(slot)                                                                                   \
+  do {                                                                                                    \
+    if constexpr (TRACE) {                                                                                \
+      if (trace_on) {                                                                                     \
+        const unsigned ts_ = (unsigned)__builtin_amdgcn_s_memtime();                                      \
+        if (lane == 0) ((unsigned*)(smem + G8_STAGE + wave * 4096))[slot] = ts_;                          \
+      }                                                                                                   \
+    }                                                                                                     \
+  } while (0)
   for (int t = t_first; t < t_end; t += nslot) {
     f32x4 acc[8][4];
 #pragma unroll
@@ -244,10 +256,12 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
     bf16x8 af[4][2], b0[2][2], b1[2][2];
 
     for (int kt2 = 0; kt2 < nk; kt2 += 2) {
+      const bool trace_on = TRACE && blockIdx.x == 0 && t == t_first && kt2 == 4;
 #pragma unroll
       for (int buf = 0; buf < 2; ++buf) {
         const char* ab = a_base + buf * G8_KT;
         const char* bb = b_base + buf * G8_KT;
+        G8_STAMP(buf * 20 + 0);
         // ---------------- phase 0: quadrant (m-half 0, n-half 0)
 #pragma unroll
         for (int f = 0; f < 2; ++f)
@@ -259,7 +273,9 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
           for (int kh = 0; kh < 2; ++kh) af[fi][kh] = *(const bf16x8*)(ab + fi * 2048 + kh * 1024);
         issue(rp1, 1);
         if (buf == 1 || kt2 > 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // see "tile seam" below
+        G8_STAMP(buf * 20 + 1);
         G8_BAR();
+        G8_STAMP(buf * 20 + 2);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
@@ -269,7 +285,10 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
             for (int f = 0; f < 2; ++f)
               acc[fi][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[f][kh], af[fi][kh], acc[fi][f], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+        G8_STAMP(buf * 20 + 3);
         G8_BAR();
+        G8_STAMP(buf * 20 + 4);
+        G8_STAMP(buf * 20 + 5);
         // ---------------- phase 1: quadrant (0, 1)
 #pragma unroll
         for (int f = 0; f < 2; ++f)
@@ -277,7 +296,9 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
           for (int kh = 0; kh < 2; ++kh) b1[f][kh] = *(const bf16x8*)(bb + G8_HALF + f * 2048 + kh * 1024);
         issue(rp2, 2);
         if (buf == 1 || kt2 > 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // see "tile seam" below
+        G8_STAMP(buf * 20 + 6);
         G8_BAR();
+        G8_STAMP(buf * 20 + 7);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
@@ -287,7 +308,10 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
             for (int f = 0; f < 2; ++f)
               acc[fi][2 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[f][kh], af[fi][kh], acc[fi][2 + f], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+        G8_STAMP(buf * 20 + 8);
         G8_BAR();
+        G8_STAMP(buf * 20 + 9);
+        G8_STAMP(buf * 20 + 10);
         // ---------------- phase 2: quadrant (1, 1)
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi)
@@ -295,7 +319,9 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
           for (int kh = 0; kh < 2; ++kh) af[fi][kh] = *(const bf16x8*)(ab + 3 * G8_HALF + fi * 2048 + kh * 1024);
         issue(rp3, 3);
         if (buf == 1 || kt2 > 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // see "tile seam" below
+        G8_STAMP(buf * 20 + 11);
         G8_BAR();
+        G8_STAMP(buf * 20 + 12);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
@@ -305,12 +331,17 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
             for (int f = 0; f < 2; ++f)
               acc[4 + fi][2 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[f][kh], af[fi][kh], acc[4 + fi][2 + f], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+        G8_STAMP(buf * 20 + 13);
         G8_BAR();
+        G8_STAMP(buf * 20 + 14);
+        G8_STAMP(buf * 20 + 15);
         // ---------------- phase 3: quadrant (1, 0); the load stream moves on to the next K-tile
         advance();
         issue(rp0, 0);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        G8_STAMP(buf * 20 + 16);
         G8_BAR();
+        G8_STAMP(buf * 20 + 17);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
@@ -320,7 +351,9 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
             for (int f = 0; f < 2; ++f)
               acc[4 + fi][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[f][kh], af[fi][kh], acc[4 + fi][f], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
-        if (buf == 0 || kt2 + 2 < nk) G8_BAR();   // the tile's last barrier is placed around the epilogue below
+        G8_STAMP(buf * 20 + 18);
+        if (buf == 0 || kt2 + 2 < nk) G8_BAR();
+        G8_STAMP(buf * 20 + 19);   // the tile's last barrier is placed around the epilogue below
       }
     }
 
@@ -329,6 +362,10 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
     // epilogue (g8_epilogue, right after its bias loads are issued), before any store is issued, so the first three phases of the next tile need no wait; from its phase 3 on, vmcnt(6) covers
     // loads issued after this point (loads retire in order among themselves; the epilogue's stores, also counted by
     // vmcnt, can only make that wait stricter) while the stores drain in the background under the next tile's MFMAs.
+    if constexpr (TRACE) {
+      if (blockIdx.x == 0 && t == t_first && lane < 40)
+        ((unsigned*)p.aux)[wave * 64 + lane] = ((const unsigned*)(smem + G8_STAGE + wave * 4096))[lane];
+    }
     if (wr == 0) G8_BAR();
     {
       const int m0 = (t / ntn) << 8, n0 = (t % ntn) << 8;
@@ -378,6 +415,19 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
   long grid = ncu;
   if (ntiles < grid) grid = ntiles;
   static const int dbg = getenv("EC_G8_DBG") ? atoi(getenv("EC_G8_DBG")) : 0;
+  static const bool trace = getenv("EC_G8_TRACE") != nullptr;
+  if (trace && kind == G8_BIAS_BF16 && p.aux) {   // debug: p.aux = device buffer of 8 x 64 uint32 timestamps
+    static bool tattr = false;
+    if (!tattr) {
+      EC_HIP(hipFuncSetAttribute((const void*)gemm8_bf16_kernel<1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));
+      tattr = true;
+    }
+    GemmP qt = p;
+    qt.dbg = dbg;
+    hipLaunchKernelGGL((gemm8_bf16_kernel<1, 0, true>), dim3((unsigned)grid), dim3(512), G8_LDS, st, qt);
+    EC_LAUNCH_CHECK();
+    return 1;
+  }
   GemmP q = p;
   q.dbg = dbg;
   hipLaunchKernelGGL(table[kind][p.tag], dim3((unsigned)grid), dim3(512), G8_LDS, st, q);

@@ -1,0 +1,15 @@
+#!/usr/bin/env python
+"""Decode /tmp/g8_trace.txt (EC_G8_TRACE=1 tools/gemm_bench.py bf16): per wave, per phase of one K-tile pair:
+R = phase start -> before barrier 1, B1 = barrier 1 wait, M = MFMA block, B2 = barrier 2 wait (shader cycles)."""
+import sys
+
+rows = [list(map(int, l.split())) for l in open(sys.argv[1] if len(sys.argv) > 1 else "/tmp/g8_trace.txt") if l.strip()]
+for w, r in enumerate(rows):
+    out = []
+    for ph in range(8):
+        b = (ph // 4) * 20 + (ph % 4) * 5
+        t0, t1, t2, t3, t4 = r[b:b + 5]
+        d = lambda a, c: (c - a) & 0xffffffff
+        out.append(f"R{d(t0,t1):4d} B{d(t1,t2):4d} M{d(t2,t3):4d} B{d(t3,t4):4d}")
+    tot = (r[39] - r[0]) & 0xffffffff
+    print(f"wave {w} (group {w >> 2}): " + " | ".join(out) + f" | total {tot}")
