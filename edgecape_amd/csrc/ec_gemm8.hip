@@ -169,7 +169,7 @@ __device__ __forceinline__ void g8_epilogue(const GemmP& p, f32x4 (&acc)[8][4], 
 
 // TRACE (debug instantiation only, EC_G8_TRACE=1): lane 0 of every wave of workgroup 0 stamps s_memtime at five points of
 // every phase of one K-tile pair into its LDS staging slot; dumped to p.aux after the first tile (tools/g8_trace.py).
-template <int KIND, int TAG, bool TRACE = false>
+template <int KIND, int TAG, bool TRACE = false, bool TWOPH = false>
 __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -230,7 +230,8 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   issue(rp0, 0); issue(rp1, 1); issue(rp2, 2); issue(rp3, 3);
   advance();
   issue(rp0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the five prologue half-tiles have landed (this wave's part)
+  if constexpr (TWOPH) issue(rp1, 1);                // two-phase schedule: the stream runs 6 half-tiles ahead
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue half-tiles have landed (this wave's part)
   G8_BAR();
   if (wr == 1) G8_BAR();                             // stagger: group 1 runs one barrier behind group 0
 
@@ -264,6 +265,68 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
         const char* ab = a_base + buf * G8_KT;
         const char* bb = b_base + buf * G8_KT;
         G8_STAMP(buf * 20 + 0);
+        if constexpr (TWOPH) {
+          // ---- two phases per K-tile (32 MFMAs each: half as many barrier transitions per MFMA).  Stream 6 half-tiles ahead:
+          //      phase A issues B-h1/A-h1 of K-tile +1 and waits vmcnt(8) (A-h1 of this K-tile has landed);
+          //      phase B issues A-h0/B-h0 of K-tile +2 and waits vmcnt(6) (A-h0, B-h0, B-h1 of K-tile +1 have landed).
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+              b0[f][kh] = *(const bf16x8*)(bb + f * 2048 + kh * 1024);
+              b1[f][kh] = *(const bf16x8*)(bb + G8_HALF + f * 2048 + kh * 1024);
+            }
+#pragma unroll
+          for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) af[fi][kh] = *(const bf16x8*)(ab + fi * 2048 + kh * 1024);
+          issue(rp2, 2);
+          issue(rp3, 3);
+          if (buf == 1 || kt2 > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // first K-tile after a seam: already drained
+          G8_BAR();
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+              for (int f = 0; f < 2; ++f)
+                acc[fi][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[f][kh], af[fi][kh], acc[fi][f], 0, 0, 0);
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+              for (int f = 0; f < 2; ++f)
+                acc[fi][2 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[f][kh], af[fi][kh], acc[fi][2 + f], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+          G8_BAR();
+#pragma unroll
+          for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) af[fi][kh] = *(const bf16x8*)(ab + 3 * G8_HALF + fi * 2048 + kh * 1024);
+          advance();
+          issue(rp0, 0);
+          issue(rp1, 1);
+          asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          G8_BAR();
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+              for (int f = 0; f < 2; ++f)
+                acc[4 + fi][2 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[f][kh], af[fi][kh], acc[4 + fi][2 + f], 0, 0, 0);
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+              for (int f = 0; f < 2; ++f)
+                acc[4 + fi][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[f][kh], af[fi][kh], acc[4 + fi][f], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+        } else {
         // ---------------- phase 0: quadrant (m-half 0, n-half 0)
 #pragma unroll
         for (int f = 0; f < 2; ++f)
@@ -353,6 +416,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
             for (int f = 0; f < 2; ++f)
               acc[4 + fi][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[f][kh], af[fi][kh], acc[4 + fi][f], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+        }
         G8_STAMP(buf * 20 + 18);
         if (buf == 0 || kt2 + 2 < nk) G8_BAR();
         G8_STAMP(buf * 20 + 19);   // the tile's last barrier is placed around the epilogue below
@@ -417,6 +481,21 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
   long grid = ncu;
   if (ntiles < grid) grid = ntiles;
   static const int dbg = getenv("EC_G8_DBG") ? atoi(getenv("EC_G8_DBG")) : 0;
+  static const bool twoph = getenv("EC_G8_2PH") && atoi(getenv("EC_G8_2PH")) != 0;   // A/B: two 32-MFMA phases per K-tile
+  if (twoph && kind != G8_GENERIC) {
+    static const kern_t t2[4] = {nullptr, gemm8_bf16_kernel<1, 0, false, true>, gemm8_bf16_kernel<2, 0, false, true>,
+                                 gemm8_bf16_kernel<3, 0, false, true>};
+    static bool a2 = false;
+    if (!a2) {
+      for (int k = 1; k < 4; ++k) EC_HIP(hipFuncSetAttribute((const void*)t2[k], hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));
+      a2 = true;
+    }
+    GemmP q2 = p;
+    q2.dbg = dbg;
+    hipLaunchKernelGGL(t2[kind], dim3((unsigned)grid), dim3(512), G8_LDS, st, q2);
+    EC_LAUNCH_CHECK();
+    return 1;
+  }
   static const bool trace = getenv("EC_G8_TRACE") != nullptr;
   if (trace && kind == G8_BIAS_BF16 && p.aux) {   // debug: p.aux = device buffer of 8 x 64 uint32 timestamps
     static bool tattr = false;
