@@ -22,8 +22,10 @@
 //     q+5 in phase q, vmcnt(6) leaves the three newest half-tiles in flight and retires everything phase q+1 reads.
 //     RAW: a half-tile is read one phase after the wait that retires it, with a barrier in between for both groups.
 //     WAR: a slot is re-staged >= 3 phases after its last ds_read.
-//   * 16x16x32 MFMAs, not 32x32x16: the 32x32 variant of this kernel (8 MFMAs per phase on two dependent accumulator blocks)
-//     measured 8 % slower (1265 vs 1375 TFLOP/s at 8192^3) although the 32x32 form has the higher isolated rate.
+//   * 16x16x32 MFMAs, not 32x32x16: 32x32 variants of this kernel measured 8-9 % slower (1245-1265 vs 1360-1375 TFLOP/s at
+//     8192^3, with one quadrant per phase and with two) although the 32x32 form has the higher isolated rate.  Phase
+//     timestamps (EC_G8_TRACE, tools/g8_trace.py): a 16-MFMA block issues in ~320 cycles (20 per MFMA = the 16x16 form's
+//     own rate), barrier-to-barrier ~450; two 32-MFMA phases per K-tile (EC_G8_2PH=1) gain 2 % at 8192^3, nothing at K = 768.
 //   * MFMA roles are swapped (A-operand <- weight rows n, B-operand <- activation rows m) so an accumulator lane holds one
 //     output row and 4 consecutive columns: the epilogue (bias / pos-table / GELU / LayerScale / residual / bf16 pack)
 //     works on 16-byte row segments.
@@ -442,6 +444,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   }
   if (wr == 0) G8_BAR();   // balances group 1's extra barrier at the start
 }
+
 
 }  // namespace
 
