@@ -400,6 +400,73 @@ __global__ __launch_bounds__(256) void bgemm_small_kernel(BgemmP p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same small batched GEMMs on the matrix pipe, exact fp32 (v_mfma_f32_32x32x2_f32): one wave per 32x32 output tile,
+// operands straight from global memory (they are a few hundred KB per sample and L2-resident; no reuse inside a wave worth
+// an LDS round trip).  The contraction index is permuted inside blocks of 8 (MFMA step s, k-half h <-> k = k0 + 4 h + s)
+// so a lane's four A values are one 16-byte load; B is four coalesced row loads (NN) or one 16-byte load (NT).
+// ------------------------------------------------------------------------------------------------
+template <bool TRANSB>
+__global__ __launch_bounds__(256) void bgemm_mfma_kernel(BgemmP p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bz = blockIdx.z;
+  const int m0 = blockIdx.y * 32, n0 = (blockIdx.x * 4 + wave) * 32;
+  if (n0 >= p.N) return;
+  const float* A = p.A + (long)(p.modA > 0 ? bz % p.modA : bz) * p.sA;
+  const float* B = p.B + (long)(p.modB > 0 ? bz % p.modB : bz) * p.sB;
+  float* C = p.C + (long)bz * p.sC;
+  const int i = lane & 31, h = lane >> 5;
+  const int am = min(m0 + i, p.M - 1);          // clamp: rows / columns past the edge are computed, never stored
+  const int bn = min(n0 + i, p.N - 1);
+  const float* arow = A + (long)am * p.lda + 4 * h;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int kfull = p.K & ~7;
+  for (int k0 = 0; k0 < kfull; k0 += 8) {
+    const f32x4 a = *(const f32x4*)(arow + k0);
+    f32x4 b;
+    if constexpr (TRANSB) {
+      b = *(const f32x4*)(B + (long)bn * p.ldb + k0 + 4 * h);
+    } else {
+      const float* bp = B + (long)(k0 + 4 * h) * p.ldb + bn;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) b[s] = bp[(long)s * p.ldb];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+  }
+  if (kfull < p.K) {   // ragged tail (K = 100, 324): same permutation, out-of-range k contribute zeros
+    f32x4 a, b;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int k = kfull + 4 * h + s;
+      const bool ok = k < p.K;
+      a[s] = ok ? A[(long)am * p.lda + k] : 0.f;
+      b[s] = ok ? (TRANSB ? B[(long)bn * p.ldb + k] : B[(long)k * p.ldb + bn]) : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+  }
+  // D[row][col]: lane holds column n0 + i, rows m0 + (r&3) + 8 (r>>2) + 4 h
+  const int n = n0 + i;
+  if (n >= p.N) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (m >= p.M) continue;
+    float v = p.alpha * acc[r];
+    if (p.beta != 0.f) v += p.beta * C[(long)m * p.ldc + n];
+    if (p.self) {
+      const float rs = p.rowscale[(long)(p.mod_rs > 0 ? bz % p.mod_rs : bz) * p.M + m];
+      v += rs * p.self[(long)bz * p.s_self + (long)m * p.ld_self + n];
+    }
+    if (p.relu) v = fmaxf(v, 0.f);
+    C[(long)m * p.ldc + n] = v;
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -516,6 +583,16 @@ void split_pack_weights(const float* W, long n_rows, long K, float* out) {
 
 int bgemm_small(const BgemmP& p, hipStream_t st) {
   EC_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0 && p.batch > 0, -1, "bgemm_small: empty problem");
+  static const bool valu_only = getenv("EC_BGEMM_VALU") != nullptr;   // A/B switch
+  const bool aligned = p.lda % 4 == 0 && p.sA % 4 == 0 && ((uintptr_t)p.A % 16) == 0 &&
+                       (!p.transB || (p.ldb % 4 == 0 && p.sB % 4 == 0 && ((uintptr_t)p.B % 16) == 0));
+  if (aligned && !valu_only) {   // 16-byte operand loads need 4-float aligned rows (K = 100: yes; the demos' odd K: VALU kernel below)
+    dim3 g((p.N + 127) / 128, (p.M + 31) / 32, p.batch);
+    if (p.transB) hipLaunchKernelGGL(bgemm_mfma_kernel<true>, g, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(bgemm_mfma_kernel<false>, g, dim3(256), 0, st, p);
+    EC_LAUNCH_CHECK();
+    return 0;
+  }
   dim3 grid((p.N + SB - 1) / SB, (p.M + SB - 1) / SB, p.batch);
   hipLaunchKernelGGL(bgemm_small_kernel, grid, dim3(256), 0, st, p);
   EC_LAUNCH_CHECK();

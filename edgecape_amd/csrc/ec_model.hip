@@ -113,7 +113,7 @@ struct ec_model {
   float *s_mem, *s_x, *s_tmp, *s_qkv, *s_att, *s_qc, *s_kv, *s_y, *s_z, *s_qimg, *s_kvk, *s_attimg, *s_tmpimg;
   float *e_x, *e_qkv, *e_att, *e_tmp, *e_h;
   float *p_fs, *p_fq, *p_g1, *p_fs2, *prop;
-  float *d_qin, *d_sc, *d_rp, *d_bias, *d_qkv, *d_att, *d_tmp, *d_qc, *d_kv, *d_y, *d_z, *d_hs, *d_pts, *d_k1, *d_k2, *d_hn;
+  float *d_qin, *d_sc, *d_rp, *d_bias, *d_bias_all, *d_qkv, *d_att, *d_tmp, *d_qc, *d_kv, *d_y, *d_z, *d_hs, *d_pts, *d_k1, *d_k2, *d_hn;
   float *o_sim, *o_adj, *o_init, *o_out;
 };
 
@@ -533,6 +533,8 @@ struct SupportState {
   float* adj1 = nullptr;         // [n, K, K]   predicted, soft-normalised adjacency            skeleton.py:142-150
   float* adj_out = nullptr;      // [n, 2, K, K]
   float* attn_adj = nullptr;     // [hops+1, n, K, K]                                            skeleton.py:152-161
+  float* dec_bias = nullptr;     // optional [dec_layers][n, nhead, K, K]: Markov-bias MLP of every decoder layer (bias_attn.py:188-191),
+                                 // computed with the support side (it only depends on attn_adj); nullptr -> the decoder computes it
 };
 
 // Support half of TwoStageHead.forward (head.py:175-200): pooling + query_proj + SkeletonPredictor.
@@ -601,7 +603,12 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
     if (hops1 > 4) RUN(mm(attn_adj + 2 * hop, attn_adj + 2 * hop, attn_adj + 4 * hop));
     EC_REQUIRE(hops1 <= 5, EC_ERR_ARG, "max_hops > 4 not supported");
   }
-
+  if (ss.dec_bias)   // Markov-bias MLP of every decoder layer: depends on attn_adj only, so it rides with the support side
+    for (size_t li = 0; li < m->dec.size(); ++li) {
+      const DecLayer& Ld = m->dec[li];
+      RUN(bias_mlp(attn_adj, Ld.m_w1, Ld.m_b1, Ld.m_w2, Ld.m_b2, ss.dec_bias + li * (size_t)bs * m->cfg.nhead * K * K, hops1,
+                   m->cfg.max_hops + m->cfg.nhead, m->cfg.nhead, bs, K, st));
+    }
   return 0;
 }
 
@@ -695,10 +702,12 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     RUN(sincos_coords(bi, m->dim_t, m->d_sc, d, Mk, d / 2, st));
     RUN(linear(m->d_sc, d, false, m->rp0, m->d_rp, d, false, Mk, ACT_GELU, st));
     RUN(linear(m->d_rp, d, false, m->rp1, m->d_qin + d, 2 * d, false, Mk, ACT_NONE, st));
-    RUN(bias_mlp(attn_adj, Ld.m_w1, Ld.m_b1, Ld.m_w2, Ld.m_b2, m->d_bias, hops1, m->cfg.max_hops + nh, nh, bs, K, st));
+    float* lbias = m->d_bias;
+    if (ss.dec_bias) lbias = ss.dec_bias + li * (size_t)bs * nh * K * K;
+    else RUN(bias_mlp(attn_adj, Ld.m_w1, Ld.m_b1, Ld.m_w2, Ld.m_b2, m->d_bias, hops1, m->cfg.max_hops + nh, nh, bs, K, st));
     LayerIO io;
     io.x = m->d_qin; io.ldx = 2 * d; io.mem = mem; io.s_mem = s_tok;
-    io.adj1 = ss.adj1; io.valid = ss.valid; io.kmask_fixed = ss.kmask_fixed; io.bias = m->d_bias;
+    io.adj1 = ss.adj1; io.valid = ss.valid; io.kmask_fixed = ss.kmask_fixed; io.bias = lbias;
     io.nb = bs; io.bs = bs; io.update_mem = false;
     io.kv_pre = m->d_kv + (long)li * 2 * E; io.ld_kv_pre = (long)nL * 2 * E;
     RUN(run_dec_layer(m, Ld, io, true, false, m->d_qkv, m->d_att, m->d_tmp, m->d_qc, m->d_kv, m->d_y, m->d_z, nullptr, nullptr,
@@ -730,6 +739,7 @@ static SupportState workspace_support(ec_model* m, const ec_outputs* out) {
   ss.sk = m->sk; ss.valid = m->valid; ss.kmask = m->kmask; ss.kmask_fixed = m->kmask_fixed; ss.adj1 = m->adj1;
   ss.adj_out = out->adj_dev;
   ss.attn_adj = out->attn_adj_dev ? out->attn_adj_dev : m->attn_adj;
+  ss.dec_bias = m->d_bias_all;
   return ss;
 }
 
@@ -971,7 +981,7 @@ int ec_finalize(ec_handle m) {
   const size_t Me = (size_t)bs * L;
   WS(e_x, Me * d); WS(e_qkv, Me * 3 * d); WS(e_att, Me * d); WS(e_tmp, Me * d); WS(e_h, Me * Fd);
   WS(p_fs, Mk * d); WS(p_fq, Mi * d); WS(p_g1, Mk * 128); WS(p_fs2, Mk * d);
-  WS(d_qin, Mk * 2 * d); WS(d_sc, Mk * d); WS(d_rp, Mk * d); WS(d_bias, (size_t)bs * m->cfg.nhead * KK); WS(d_qkv, Mk * 3 * d);
+  WS(d_qin, Mk * 2 * d); WS(d_sc, Mk * d); WS(d_rp, Mk * d); WS(d_bias, (size_t)bs * m->cfg.nhead * KK); WS(d_bias_all, (size_t)m->cfg.dec_layers * bs * m->cfg.nhead * KK); WS(d_qkv, Mk * 3 * d);
   WS(d_att, Mk * E); WS(d_tmp, Mk * d); WS(d_qc, Mk * E); WS(d_kv, Mi * 2 * E * m->cfg.dec_layers); WS(d_y, Mk * 2 * Fd); WS(d_z, Mk * Fd);
   WS(d_hs, 3 * Mk * d); WS(d_pts, 4 * Mk * 2); WS(d_k1, Mk * d); WS(d_k2, Mk * d);
 #undef WS
@@ -1109,7 +1119,8 @@ int ec_forward_cached(ec_handle m, ec_support_t c, const float* img_q, const int
   hipStream_t st = (hipStream_t)stream;
   EC_HIP(hipMemcpyAsync(c->d_idx, episode_of_query, (size_t)bs * 4, hipMemcpyHostToDevice, st));
   RUN(run_backbone(m, &img_q, 1, bs, m->feat, st));
-  const SupportState ws = workspace_support(m, out);
+  SupportState ws = workspace_support(m, out);
+  ws.dec_bias = nullptr;   // the bias MLP is recomputed from the gathered Markov stack (cheap) instead of being cached
   const long K = m->K, KK = K * K;
   RUN(gather_rows(ws.sk, c->ss.sk, c->d_idx, K * m->d, bs, 1, 0, 0, st));
   RUN(gather_rows(ws.valid, c->ss.valid, c->d_idx, K, bs, 1, 0, 0, st));
@@ -1271,6 +1282,15 @@ int ec_op_gemm_bench(const void* A, const void* W, const float* bias, void* C, i
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return EC_OK;
+}
+
+int ec_op_bgemm(const float* A, const float* B, float* C, int batch, int M, int N, int K, int transB, void* stream) {
+  BgemmP p;
+  p.A = A; p.lda = K; p.sA = (long)M * K;
+  p.B = B; p.ldb = transB ? K : N; p.sB = (long)N * K;
+  p.C = C; p.ldc = N; p.sC = (long)M * N;
+  p.M = M; p.N = N; p.K = K; p.batch = batch; p.transB = transB;
+  return bgemm_small(p, (hipStream_t)stream);
 }
 
 int ec_op_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int cols, float eps, void* stream) {

@@ -1,5 +1,7 @@
 // Non-GEMM kernels of the EdgeCape hot path for gfx950: HBM-bound normalisation / layout kernels
 // and the small per-sample graph kernels of the skeleton head.  64-wide waves throughout.
+#include <stdlib.h>
+
 #include "ec_ops.h"
 
 namespace ec {
@@ -193,6 +195,10 @@ __global__ __launch_bounds__(256) void pool_weights_kernel(const float* target, 
   const int tid = threadIdx.x;
   const float msk = mask_s[bk];
   float* out = Wp + (long)bk * g * g;
+  if (msk == 0.f) {   // padded keypoint slot: the pooled feature is multiplied by mask_s = 0 (head.py:187) -> weights 0, skip the heatmap
+    for (int cell = tid; cell < g * g; cell += 256) out[cell] = 0.f;
+    return;
+  }
   const float* src = target + (long)bk * hm * hm;
   float s = 0.f;
   for (int i = tid; i < hm * hm; i += 256) {
@@ -347,6 +353,40 @@ __global__ __launch_bounds__(256) void adj_combine_kernel(const float* P, const 
         m1[i * K + j] = u[t] / (rs2 + 1e-8f);
       }
     }
+  }
+}
+
+// compile-time sizes (the shipped configuration: max_hops + 1 = 5 -> 12 -> 8 heads): everything stays in registers
+template <int H1, int HID, int NH>
+__global__ __launch_bounds__(256) void bias_mlp_fixed_kernel(const float* attn_adj, const float* w1, const float* b1, const float* w2,
+                                                              const float* b2, float* out, int bs, int K) {
+  __shared__ float sw1[HID * H1], sb1[HID], sw2[NH * HID], sb2[NH];
+  for (int i = threadIdx.x; i < HID * H1; i += 256) sw1[i] = w1[i];
+  for (int i = threadIdx.x; i < HID; i += 256) sb1[i] = b1[i];
+  for (int i = threadIdx.x; i < NH * HID; i += 256) sw2[i] = w2[i];
+  for (int i = threadIdx.x; i < NH; i += 256) sb2[i] = b2[i];
+  __syncthreads();
+  const long KK = (long)K * K;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= bs * KK) return;
+  const int b = idx / KK;
+  const long ij = idx % KK;
+  float a[H1], hdn[HID];
+#pragma unroll
+  for (int d = 0; d < H1; ++d) a[d] = attn_adj[((long)d * bs + b) * KK + ij];
+#pragma unroll
+  for (int o = 0; o < HID; ++o) {
+    float s = sb1[o];
+#pragma unroll
+    for (int d = 0; d < H1; ++d) s += sw1[o * H1 + d] * a[d];
+    hdn[o] = fmaxf(s, 0.f);
+  }
+#pragma unroll
+  for (int hh = 0; hh < NH; ++hh) {
+    float s = sb2[hh];
+#pragma unroll
+    for (int o = 0; o < HID; ++o) s += sw2[hh * HID + o] * hdn[o];
+    out[((long)b * NH + hh) * KK + ij] = s;
   }
 }
 
@@ -697,6 +737,12 @@ int set_identity(float* dst, int bs, int K, hipStream_t st) {
 int bias_mlp(const float* attn_adj, const float* w1, const float* b1, const float* w2, const float* b2, float* out, int hops1,
              int hidden, int nhead, int bs, int K, hipStream_t st) {
   EC_REQUIRE(hops1 <= 8 && hidden <= 16, -1, "bias_mlp: unsupported MLP size");
+  if (hops1 == 5 && hidden == 12 && nhead == 8) {
+    hipLaunchKernelGGL((bias_mlp_fixed_kernel<5, 12, 8>), dim3(cdiv((long)bs * K * K, 256)), dim3(256), 0, st, attn_adj, w1, b1, w2, b2,
+                       out, bs, K);
+    EC_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t lds = (size_t)(hidden * hops1 + hidden + nhead * hidden + nhead) * sizeof(float);
   hipLaunchKernelGGL(bias_mlp_kernel, dim3(cdiv((long)bs * K * K, 256)), dim3(256), lds, st, attn_adj, w1, b1, w2, b2, out, hops1,
                      hidden, nhead, bs, K);

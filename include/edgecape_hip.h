@@ -164,6 +164,10 @@ int ec_op_linear(const float* A_dev, const float* W_dev, const float* bias_dev, 
  * `iters` times; returns mean kernel time in ms via *ms (HIP events on `stream`).  Used by bench.py roofline. */
 int ec_op_gemm_bench(const void* A_dev, const void* W_dev, const float* bias_dev, void* C_dev, int M, int N, int K,
                      int precision, int iters, void* stream, float* ms);
+/* C[b] = A[b] @ op(B[b]) for b < batch; A [M,K], B [K,N] (transB = 0) or [N,K] (transB = 1), C [M,N], fp32, exact-fp32 MFMA:
+ * the per-sample contractions of the head (support pooling head.py:181-184, cosine adjacency skeleton.py:136-137, Markov powers
+ * :159, GCN aggregation encoder_decoder.py:517, similarity map :75). */
+int ec_op_bgemm(const float* A_dev, const float* B_dev, float* C_dev, int batch, int M, int N, int K, int transB, void* stream);
 int ec_op_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev, int rows, int cols,
                     float eps, void* stream);
 /* softmax(q k^T * hd^-0.5 + bias, key mask) v ; q [B,Lq,H*hd], k,v [B,Lk,H*hd]; kmask [B,Lk] uint8 (1 = masked) or NULL;

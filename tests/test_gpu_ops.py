@@ -275,3 +275,20 @@ def test_gemm8_race_screen(lib, M, N, K):
     assert (outs[0] - ref).abs().max().item() < 3e-4
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+
+
+@pytest.mark.parametrize("batch,M,N,K,transB", [(3, 100, 768, 324, 0), (3, 100, 100, 100, 0), (2, 100, 100, 256, 1), (2, 100, 324, 256, 1),
+                                                (2, 17, 384, 256, 0), (2, 17, 17, 256, 1), (2, 17, 17, 17, 0), (1, 5, 256, 256, 1),
+                                                (2, 33, 65, 12, 0), (1, 1, 384, 256, 0)])
+def test_bgemm(lib, batch, M, N, K, transB):
+    """Small batched fp32 contractions of the head: MFMA kernel (4-float aligned rows) and the VALU fallback (odd K)."""
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(batch, M, K, generator=g)
+    B = torch.randn(batch, N, K, generator=g) if transB else torch.randn(batch, K, N, generator=g)
+    ref = (A.double() @ (B.double().transpose(1, 2) if transB else B.double())).float()
+    Ad, Bd = A.cuda(), B.cuda()
+    Cd = torch.full((batch, M, N), float("nan"), device="cuda")
+    _chk(lib, lib.ec_op_bgemm(_p(Ad), _p(Bd), _p(Cd), batch, M, N, K, transB, None))
+    torch.cuda.synchronize()
+    err = (Cd.cpu() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
