@@ -424,8 +424,7 @@ __global__ __launch_bounds__(256) void bgemm_mfma_kernel(BgemmP p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int kfull = p.K & ~7;
-  for (int k0 = 0; k0 < kfull; k0 += 8) {
-    const f32x4 a = *(const f32x4*)(arow + k0);
+  auto load_b = [&](int k0) {
     f32x4 b;
     if constexpr (TRANSB) {
       b = *(const f32x4*)(B + (long)bn * p.ldb + k0 + 4 * h);
@@ -434,8 +433,23 @@ __global__ __launch_bounds__(256) void bgemm_mfma_kernel(BgemmP p) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) b[s] = bp[(long)s * p.ldb];
     }
+    return b;
+  };
+  // software pipeline: the operands of block k0 + 8 are in flight while block k0 is multiplied (without the scheduling
+  // fence hipcc sinks every load next to its MFMA: five dependent memory round trips per block).  Deeper staging (32 k per
+  // stage) measured slower: the kernel is bound by vector-memory instruction issue (5 per 4 MFMAs), not by latency.
+  f32x4 a_nx = kfull > 0 ? *(const f32x4*)arow : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 b_nx = kfull > 0 ? load_b(0) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < kfull; k0 += 8) {
+    const f32x4 a = a_nx, b = b_nx;
+    if (k0 + 8 < kfull) {
+      a_nx = *(const f32x4*)(arow + k0 + 8);
+      b_nx = load_b(k0 + 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
   if (kfull < p.K) {   // ragged tail (K = 100, 324): same permutation, out-of-range k contribute zeros
     f32x4 a, b;
