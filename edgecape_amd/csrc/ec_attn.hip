@@ -447,17 +447,37 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
         s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[m], s[t], 0, 0, 0);
       }
     }
+    // key mask of the tile as 64 bits: lane l looks at key k0 + l once (one coalesced byte load instead of 32 scattered ones
+    // per lane: vector-memory instructions cost ~64 cycles of issue each), out-of-range keys count as masked
+    bool lm = k0 + lane >= p.Lk;
+    if (km && !lm && k0 + lane >= p.mask_start) lm = km[k0 + lane - p.mask_start] != 0;
+    const unsigned long long mbits = __ballot(lm) >> (4 * hi);      // bit (32 t + (r&3) + 8 (r>>2)) <-> accumulator register r
+    if (bias) {   // additive bias [Lq, Lk] of this (batch, head): the lane's keys come in runs of four consecutive k
+      const float* brow = bias + (long)qrow * p.Lk + k0 + 4 * hi;
+      const bool vec = (p.Lk & 3) == 0;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int kb = k0 + 32 * t + 8 * g + 4 * hi;
+          if (vec && kb + 3 < p.Lk) {
+            const f32x4 bv = *(const f32x4*)(brow + 32 * t + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[t][4 * g + e] = fmaf(bv[e], LOG2E, s[t][4 * g + e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (kb + e < p.Lk) s[t][4 * g + e] = fmaf(brow[32 * t + 8 * g + e], LOG2E, s[t][4 * g + e]);
+          }
+        }
+    }
     float tmax = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int kg = k0 + t * 32 + acc_row(r, hi);
-        float v = s[t][r];
-        if (bias && kg < p.Lk) v = fmaf(bias[(long)qrow * p.Lk + kg], LOG2E, v);
-        bool masked = kg >= p.Lk;
-        if (km && !masked && kg >= p.mask_start) masked = km[kg - p.mask_start] != 0;
-        v = masked ? -INFINITY : v;
+        const bool masked = (mbits >> (32 * t + (r & 3) + 8 * (r >> 2))) & 1ull;
+        const float v = masked ? -INFINITY : s[t][r];
         s[t][r] = v;
         tmax = fmaxf(tmax, v);
       }
