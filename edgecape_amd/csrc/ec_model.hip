@@ -362,14 +362,15 @@ static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_
   const int n = n_src * n_each;
   const long M = (long)n * T;
   for (int s = 0; s < n_src; ++s)
-    RUN(im2col14(imgs[s], (char*)m->bb_h + (size_t)s * n_each * HW * m->Kp * (h16 ? 2 : 4), h16, n_each, H, g, m->Kp, st));
-  {  // patch embedding GEMM, one batch entry per image so rows land at token 1.. of each image; + bias + pos[1:]
+    RUN(im2col14(imgs[s], (char*)m->bb_h + (size_t)s * n_each * T * m->Kp * (h16 ? 2 : 4), h16, n_each, H, g, m->Kp, st));
+  {  // patch embedding: ONE GEMM over all n*T token rows (the zero cls rows produce bias + pos[0], overwritten below);
+     // epilogue adds the conv bias and the positional table row m % T
     GemmP p;
-    p.A = m->bb_h; p.lda = m->Kp; p.sA = (long)HW * m->Kp; p.ab_bf16 = h16;
+    p.A = m->bb_h; p.lda = m->Kp; p.ab_bf16 = h16;
     p.B = h16 ? (const void*)m->patch.w16 : (const void*)m->patch.w; p.ldb = m->Kp;
-    p.C = m->bb_x + C; p.ldc = C; p.sC = (long)T * C;
-    p.bias = m->patch.b; p.table = m->pos + C; p.ldt = C; p.period = HW;
-    p.M = HW; p.N = C; p.K = m->Kp; p.batch = n;
+    p.C = m->bb_x; p.ldc = C;
+    p.bias = m->patch.b; p.table = m->pos; p.ldt = C; p.period = T;
+    p.M = (int)M; p.N = C; p.K = m->Kp;
     RUN(gemm_nt(p, st));
   }
   RUN(set_cls_rows(m->bb_x, C, m->cls, m->pos, n, T, C, st));
@@ -965,7 +966,7 @@ int ec_finalize(ec_handle m) {
   if ((rc = dmalloc(m, &m->bb_qkv, MT * 3 * C * es))) return rc;
   if ((rc = dmalloc(m, &m->bb_att, MT * C * es))) return rc;
   if (m->bb16 && (rc = dmalloc(m, &m->bb_y, MT * C * 2))) return rc;
-  if ((rc = dmalloc(m, &m->bb_h, std::max(MT * 4 * C, (size_t)n * HW * m->Kp) * es))) return rc;
+  if ((rc = dmalloc(m, &m->bb_h, std::max(MT * 4 * C, MT * m->Kp) * es))) return rc;
   if ((rc = dalloc(m, &m->feat, (size_t)n * HW * C))) return rc;
   if ((rc = dalloc(m, &m->feat_nchw_tmp, (size_t)n * HW * C))) return rc;
   if ((rc = dalloc(m, &m->d_off, (size_t)bs + 1))) return rc;

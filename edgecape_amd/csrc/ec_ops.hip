@@ -131,21 +131,24 @@ __global__ void transpose_pad_bf16_kernel(const float* src, bf16_t* dst, int L, 
 // row length Kp >= 588 (zero padded) so the GEMM K is a multiple of 128 bytes.
 template <bool OUT_BF16>
 __global__ void im2col14_kernel(const float* img, void* out, int H, int g, int Kp) {
-  const int patch = blockIdx.x;   // n*g*g + py*g + px
-  const int n = patch / (g * g), pp = patch % (g * g);
+  // output rows are TOKEN rows: image n owns rows n*(g*g+1) .. ; row 0 of each image (the cls token) is zero-filled so the
+  // patch embedding is ONE GEMM over M = n_img * T contiguous rows (its cls rows are overwritten by set_cls_rows)
+  const int T = g * g + 1;
+  const int n = blockIdx.x / T, tok = blockIdx.x % T;
+  const long orow = blockIdx.x;
+  const int pp = tok - 1;
   const int py = pp / g, px = pp % g;
   const float* src = img + (long)n * 3 * H * H;
   for (int k = threadIdx.x; k < Kp; k += blockDim.x) {
     float v = 0.f;
-    if (k < 588) {
+    if (tok > 0 && k < 588) {
       const int c = k / 196, r = k % 196, ky = r / 14, kx = r % 14;
       v = src[((long)c * H + (py * 14 + ky)) * H + px * 14 + kx];
     }
-    if (OUT_BF16) ((bf16_t*)out)[(long)patch * Kp + k] = f2bf(v);
-    else ((float*)out)[(long)patch * Kp + k] = v;
+    if (OUT_BF16) ((bf16_t*)out)[orow * Kp + k] = f2bf(v);
+    else ((float*)out)[orow * Kp + k] = v;
   }
 }
-
 __global__ void set_cls_kernel(float* x, long ldx, const float* cls, const float* pos0, int T, int C) {
   const int n = blockIdx.x;
   for (int c = threadIdx.x; c < C; c += blockDim.x) x[(long)n * T * ldx + c] = cls[c] + pos0[c];
@@ -673,8 +676,8 @@ int transpose_pad_bf16(const float* src, bf16_t* dst, int B, int L, int E, int L
 }
 
 int im2col14(const float* img, void* patches, int out_bf16, int n_img, int H, int g, int Kp, hipStream_t st) {
-  if (out_bf16) hipLaunchKernelGGL(im2col14_kernel<true>, dim3(n_img * g * g), dim3(256), 0, st, img, patches, H, g, Kp);
-  else hipLaunchKernelGGL(im2col14_kernel<false>, dim3(n_img * g * g), dim3(256), 0, st, img, patches, H, g, Kp);
+  if (out_bf16) hipLaunchKernelGGL(im2col14_kernel<true>, dim3(n_img * (g * g + 1)), dim3(256), 0, st, img, patches, H, g, Kp);
+  else hipLaunchKernelGGL(im2col14_kernel<false>, dim3(n_img * (g * g + 1)), dim3(256), 0, st, img, patches, H, g, Kp);
   EC_LAUNCH_CHECK();
   return 0;
 }
