@@ -79,6 +79,11 @@ struct ec_model {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_sk = nullptr, ev_join = nullptr;
   bool overlap = false;
+  // the decoder's keypoint-branch / reference-point chains (encoder_decoder.py:371-402, head.py:216-220) hang off the token
+  // state of each layer and only rejoin it at the next layer's cross-attention: they run on a second helper stream
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_aux[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool overlap_dec = false;
   std::unordered_map<std::string, Tensor> tensors;
   std::vector<void*> owned;  // every hipMalloc'd pointer
   std::unordered_map<std::string, std::pair<const float*, long>> taps;
@@ -433,6 +438,10 @@ struct LayerIO {
   bool update_mem;
   const float* kv_pre = nullptr;   // if set: K|V of the image tokens were projected beforehand ([nb, HW, ld_kv_pre], K at +0, V at +E)
   long ld_kv_pre = 0;
+  // cross-stream hand-offs (decoder helper stream): the first overwrite of x (LN1) waits for wait_x (a helper is still reading the
+  // previous layer's x), the cross-attention waits for wait_ca[] (query positional half of x / pre-projected K|V)
+  hipEvent_t wait_x = nullptr;
+  hipEvent_t wait_ca[2] = {nullptr, nullptr};
 };
 
 static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool biased, bool two_way, float* qkv, float* att,
@@ -454,7 +463,10 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
     RUN(attention(a, st));
   }
   RUN(linear(att, d, false, L.sa_out, tmp, d, false, Mk, ACT_NONE, st, nullptr, io.x, io.ldx));
+  if (io.wait_x) EC_HIP(hipStreamWaitEvent(st, io.wait_x, 0));
   RUN(ln(tmp, d, io.x, io.ldx, false, L.n1, Mk, d, 1e-5f, st));
+  for (hipEvent_t e : io.wait_ca)
+    if (e) EC_HIP(hipStreamWaitEvent(st, e, 0));
   // ---- cross attention tokens -> image (hd = E/nh = 64); Q input is [x | init_pos] (K = 2d) in the main decoder
   RUN(linear(io.x, io.ldx, false, L.ca_q, qc, E, false, Mk, ACT_NONE, st));
   {
@@ -660,6 +672,35 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
   float* kp = m->e_x + (long)HW * d;         // keypoint tokens: rows b*L+HW ..
   const long s_tok = (long)L * d;
 
+  // ---- helper stream (see the stream plan at (6)); the decoder's image K|V projection only needs the encoder output, so it
+  // starts here, beside the proposal generator
+  const bool ovd = m->overlap_dec;
+  hipStream_t ax = ovd ? m->aux : st;
+  auto fork = [&](hipEvent_t e) -> int {   // ax continues after everything enqueued on st so far
+    if (!ovd) return 0;
+    EC_HIP(hipEventRecord(e, st));
+    EC_HIP(hipStreamWaitEvent(ax, e, 0));
+    return 0;
+  };
+  auto mark = [&](hipEvent_t e) -> int {   // a point on ax that st will wait for
+    if (ovd) EC_HIP(hipEventRecord(e, ax));
+    return 0;
+  };
+  hipEvent_t const ev_fork = m->ev_aux[0], ev_x = m->ev_aux[1], ev_qpe = m->ev_aux[2], ev_kv = m->ev_aux[3], ev_done = m->ev_aux[4];
+  const int nL = (int)m->dec.size();
+  RUN(fork(ev_fork));
+  {  // the decoder never updates the image memory (two_way_attn=False, encoder_decoder.py:638): project K|V of the image
+     // tokens for ALL decoder layers in one GEMM (stacked weights [nL*2E, d], stacked positional tables [HW, nL*2E])
+    GemmP p;
+    p.A = mem; p.lda = d; p.sA = s_tok;
+    p.split = m->dec_kv_all.ws ? 1 : 0; p.B = m->dec_kv_all.wsel(p.split); p.ldb = d;
+    p.C = m->d_kv; p.ldc = (long)nL * 2 * E; p.sC = (long)HW * nL * 2 * E;
+    p.table = m->dec_kv_table; p.ldt = (long)nL * 2 * E; p.period = HW;
+    p.M = HW; p.N = nL * 2 * E; p.K = d; p.batch = bs;
+    RUN(gemm_nt(p, ax));
+  }
+  RUN(mark(ev_kv));
+
   // (5) proposal generator (encoder_decoder.py:49-112)
   {
     GemmP p;
@@ -683,26 +724,28 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
   }
   RUN(proposals(sim, out->initial_proposals_dev, pts, Mk, g, st));   // pts[0] = decoder proposals b_0
 
-  // (6) decoder (encoder_decoder.py:330-425): x lives as the left half of d_qin = [x | qpe]
+  // (6) decoder (encoder_decoder.py:330-425): x lives as the left half of d_qin = [x | qpe].
+  // Stream plan (ax = helper stream, == st when overlap is off).  With x_l the token state entering layer l and b_l its
+  // reference points:  layer l needs x_l at once but qpe_l = ref_point_head(sine(b_l)) and the image K|V only at its
+  // cross-attention, and b_{l+1} = update(b_l, kpt_branch[l](x_{l+1})) hangs off the layer's output.  So after layer l the helper
+  // runs   dec_norm(x_{l+1}) -> hs[l];  kpt_branch[l](x_{l+1}) -> b_{l+1};  sine -> ref_point_head -> qpe_{l+1};
+  //        kpt_branch[l](hs[l]) -> output_kpts[l]   (head.py:216-220)
+  // while st runs layer l+1's self-attention block; st waits for "x_{l+1} no longer read" before LN1 overwrites x and for
+  // qpe_{l+1} before the cross-attention query projection.
+  auto ref_point_embed = [&](const float* bi) -> int {   // qpe = ref_point_head(sine(b))  (encoder_decoder.py:363-371)
+    RUN(sincos_coords(bi, m->dim_t, m->d_sc, d, Mk, d / 2, ax));
+    RUN(linear(m->d_sc, d, false, m->rp0, m->d_rp, d, false, Mk, ACT_GELU, ax));
+    RUN(linear(m->d_rp, d, false, m->rp1, m->d_qin + d, 2 * d, false, Mk, ACT_NONE, ax));
+    return 0;
+  };
+  RUN(fork(ev_fork));                      // proposals (pts[0]) and the encoder output are final
+  RUN(ref_point_embed(pts));
+  RUN(mark(ev_qpe));
   RUN(copy3d(m->d_qin, 2 * d, (long)K * 2 * d, kp, d, s_tok, bs, K, d, st));
-  const int nL = (int)m->dec.size();
-  {  // the decoder never updates the image memory (two_way_attn=False, encoder_decoder.py:638): project K|V of the image
-     // tokens for ALL decoder layers in one GEMM (stacked weights [nL*2E, d], stacked positional tables [HW, nL*2E])
-    GemmP p;
-    p.A = mem; p.lda = d; p.sA = s_tok;
-    p.split = m->dec_kv_all.ws ? 1 : 0; p.B = m->dec_kv_all.wsel(p.split); p.ldb = d;
-    p.C = m->d_kv; p.ldc = (long)nL * 2 * E; p.sC = (long)HW * nL * 2 * E;
-    p.table = m->dec_kv_table; p.ldt = (long)nL * 2 * E; p.period = HW;
-    p.M = HW; p.N = nL * 2 * E; p.K = d; p.batch = bs;
-    RUN(gemm_nt(p, st));
-  }
   if (wait_adj) EC_HIP(hipStreamWaitEvent(st, wait_adj, 0));   // adjacency / Markov stack from the support side
-  for (size_t li = 0; li < m->dec.size(); ++li) {
+  for (int li = 0; li < nL; ++li) {
     const DecLayer& Ld = m->dec[li];
     float* bi = pts + (long)li * Mk * 2;
-    RUN(sincos_coords(bi, m->dim_t, m->d_sc, d, Mk, d / 2, st));
-    RUN(linear(m->d_sc, d, false, m->rp0, m->d_rp, d, false, Mk, ACT_GELU, st));
-    RUN(linear(m->d_rp, d, false, m->rp1, m->d_qin + d, 2 * d, false, Mk, ACT_NONE, st));
     float* lbias = m->d_bias;
     if (ss.dec_bias) lbias = ss.dec_bias + li * (size_t)bs * nh * K * K;
     else RUN(bias_mlp(attn_adj, Ld.m_w1, Ld.m_b1, Ld.m_w2, Ld.m_b2, m->d_bias, hops1, m->cfg.max_hops + nh, nh, bs, K, st));
@@ -711,17 +754,37 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     io.adj1 = ss.adj1; io.valid = ss.valid; io.kmask_fixed = ss.kmask_fixed; io.bias = lbias;
     io.nb = bs; io.bs = bs; io.update_mem = false;
     io.kv_pre = m->d_kv + (long)li * 2 * E; io.ld_kv_pre = (long)nL * 2 * E;
+    if (ovd) {
+      io.wait_x = li > 0 ? ev_x : nullptr;
+      io.wait_ca[0] = ev_qpe;
+      io.wait_ca[1] = li == 0 ? ev_kv : nullptr;
+    }
     RUN(run_dec_layer(m, Ld, io, true, false, m->d_qkv, m->d_att, m->d_tmp, m->d_qc, m->d_kv, m->d_y, m->d_z, nullptr, nullptr,
                       nullptr, nullptr, Fd, st));
-    RUN(ln(m->d_qin, 2 * d, m->d_hs + (long)li * Mk * d, d, false, m->dec_norm, Mk, d, 1e-5f, st));
+    // ---- helper chain of layer li
+    RUN(fork(ev_fork));
+    float* hs = m->d_hs + (long)li * Mk * d;
+    float* bnext = pts + (long)(li + 1) * Mk * 2;
+    RUN(ln(m->d_qin, 2 * d, hs, d, false, m->dec_norm, Mk, d, 1e-5f, ax));
     // b_{l+1} = sigmoid(inverse_sigmoid(b_l) + kpt_branch[l](x))   (un-normed x, :395-402)
-    RUN(kpt_mlp(m, m->kpt[li], m->d_qin, 2 * d, Mk, bi, pts + (long)(li + 1) * Mk * 2, st));
+    const KptBranch& kb = m->kpt[li];
+    RUN(linear(m->d_qin, 2 * d, false, kb.l0, m->d_k1, d, false, Mk, ACT_GELU, ax));
+    RUN(mark(ev_x));                       // x_{l+1} has been read: layer l+1 may overwrite it
+    RUN(linear(m->d_k1, d, false, kb.l2, m->d_k2, d, false, Mk, ACT_GELU, ax));
+    RUN(linear(m->d_k2, d, false, kb.l4, m->d_k1, d, false, Mk, ACT_GELU, ax));
+    RUN(kpt_out(m->d_k1, d, kb.w6, kb.b6, bi, bnext, Mk, d, ax));
+    if (li + 1 < nL) {
+      RUN(ref_point_embed(bnext));
+      RUN(mark(ev_qpe));
+    }
+    // (7) head output of this level (head.py:216-220): kpt_branch[l](hs[l]) on top of out_points[l] = b_l
+    RUN(kpt_mlp(m, kb, hs, d, Mk, bi, out->output_kpts_dev + (long)li * Mk * 2, ax));
+  }
+  if (ovd) {
+    EC_HIP(hipEventRecord(ev_done, ax));
+    EC_HIP(hipStreamWaitEvent(st, ev_done, 0));
   }
   m->taps["hs"] = {m->d_hs, (long)m->dec.size() * Mk * d};
-  // (7) head output (head.py:216-220)
-  for (size_t li = 0; li < m->dec.size(); ++li)
-    RUN(kpt_mlp(m, m->kpt[li], m->d_hs + (long)li * Mk * d, d, Mk, pts + (long)li * Mk * 2,
-                out->output_kpts_dev + (long)li * Mk * 2, st));
   return 0;
 }
 
@@ -819,6 +882,8 @@ int ec_destroy(ec_handle m) {
   for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
   if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
   for (hipEvent_t e : {m->ev_fork, m->ev_sk, m->ev_join}) if (e) (void)hipEventDestroy(e);
+  if (m->aux) { (void)hipStreamSynchronize(m->aux); (void)hipStreamDestroy(m->aux); }
+  for (hipEvent_t e : m->ev_aux) if (e) (void)hipEventDestroy(e);
   delete m;
   return EC_OK;
 }
@@ -995,6 +1060,11 @@ int ec_finalize(ec_handle m) {
       EC_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
       EC_HIP(hipEventCreateWithFlags(&m->ev_sk, hipEventDisableTiming));
       EC_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+      m->overlap_dec = !(ov && atoi(ov) == 1);   // EC_OVERLAP=1: support-side overlap only
+      if (m->overlap_dec) {
+        EC_HIP(hipStreamCreateWithFlags(&m->aux, hipStreamNonBlocking));
+        for (hipEvent_t& e : m->ev_aux) EC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      }
     }
   }
   EC_HIP(hipDeviceSynchronize());
