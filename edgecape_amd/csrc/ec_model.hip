@@ -81,9 +81,14 @@ struct ec_model {
   bool overlap = false;
   // the decoder's keypoint-branch / reference-point chains (encoder_decoder.py:371-402, head.py:216-220) hang off the token
   // state of each layer and only rejoin it at the next layer's cross-attention: they run on a second helper stream
-  hipStream_t aux = nullptr;
+  hipStream_t aux = nullptr, side2 = nullptr;   // side2: image lane of the skeleton head (run_head_support)
   hipEvent_t ev_aux[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_sup[4] = {nullptr, nullptr, nullptr, nullptr};
   bool overlap_dec = false;
+  // EC_TIMELINE=1: timed HIP events at the head's milestones on every stream, printed (us from the head's start) after a
+  // device sync at the end of the call - the unprofiled picture of which lane is critical (rocprofv3 makes the head host-bound)
+  bool timeline = false;
+  std::vector<std::pair<const char*, hipEvent_t>> tl;
   std::unordered_map<std::string, Tensor> tensors;
   std::vector<void*> owned;  // every hipMalloc'd pointer
   std::unordered_map<std::string, std::pair<const float*, long>> taps;
@@ -125,6 +130,29 @@ struct ec_model {
 struct ec_support;
 
 namespace ec {
+
+static int tl_mark(ec_model* m, const char* name, hipStream_t st) {
+  if (!m->timeline) return 0;
+  hipEvent_t e;
+  EC_HIP(hipEventCreate(&e));
+  EC_HIP(hipEventRecord(e, st));
+  m->tl.push_back({name, e});
+  return 0;
+}
+static int tl_dump(ec_model* m) {
+  if (!m->timeline || m->tl.empty()) return 0;
+  EC_HIP(hipDeviceSynchronize());
+  fprintf(stderr, "[timeline]");
+  for (size_t i = 0; i < m->tl.size(); ++i) {
+    float ms = 0.f;
+    EC_HIP(hipEventElapsedTime(&ms, m->tl[0].second, m->tl[i].second));
+    fprintf(stderr, " %s=%.0f", m->tl[i].first, ms * 1e3f);
+  }
+  fprintf(stderr, "\n");
+  for (auto& p : m->tl) (void)hipEventDestroy(p.second);
+  m->tl.clear();
+  return 0;
+}
 
 static int dmalloc(ec_model* m, void** p, size_t bytes) {
   if (bytes == 0) bytes = 16;
@@ -444,6 +472,41 @@ struct LayerIO {
   hipEvent_t wait_ca[2] = {nullptr, nullptr};
 };
 
+// K|V of the image tokens for a layer's token->image cross attention, one batch entry per sample (mem may be a strided view):
+// kv[nb, HW, 2E], the positional half of K folded into the epilogue table (encoder_decoder.py:604-617).
+static int project_image_kv(ec_model* m, const DecLayer& L, const float* mem, long s_mem, int nb, float* kv, hipStream_t st) {
+  const int d = m->d, E = m->E, HW = m->HW;
+  GemmP p;
+  p.A = mem; p.lda = d; p.sA = s_mem;
+  p.split = L.ca_kv.ws ? 1 : 0; p.B = L.ca_kv.wsel(p.split); p.ldb = d;
+  p.C = kv; p.ldc = 2 * E; p.sC = (long)HW * 2 * E;
+  p.table = L.ca_kv_table; p.ldt = 2 * E; p.period = HW;
+  p.M = HW; p.N = 2 * E; p.K = d; p.batch = nb;
+  return gemm_nt(p, st);
+}
+
+// image -> token attention of a two-way layer, NO masks (encoder_decoder.py:638-649), in two pieces: the query projection only
+// needs the image memory; the rest needs the layer's final token state x.  `x_read` (optional) is recorded once x has been read.
+static int image_update_q(ec_model* m, const DecLayer& L, const float* mem, int nb, float* qimg, hipStream_t st) {
+  return linear(mem, m->d, false, L.i2t_q, qimg, m->E, false, nb * m->HW, ACT_NONE, st, nullptr, nullptr, 0, L.i2t_q_table, m->E, m->HW);
+}
+static int image_update(ec_model* m, const DecLayer& L, const float* x, long ldx, float* mem, int nb, const float* qimg, float* kvk,
+                        float* attimg, float* tmpimg, hipStream_t st, hipEvent_t x_read) {
+  const int d = m->d, E = m->E, K = m->K, HW = m->HW, nh = m->cfg.nhead;
+  const int Mi = nb * HW, Mk = nb * K;
+  RUN(linear(x, ldx, false, L.i2t_kv, kvk, 2 * E, false, Mk, ACT_NONE, st));
+  if (x_read) EC_HIP(hipEventRecord(x_read, st));
+  AttnP a;
+  a.Q = qimg; a.K = kvk; a.V = kvk + E; a.O = attimg;
+  a.ldq = E; a.ldk = a.ldv = 2 * E; a.ldo = E;
+  a.sQ = (long)HW * E; a.sK = a.sV = (long)K * 2 * E; a.sO = (long)HW * E;
+  a.B = nb; a.H = nh; a.Lq = HW; a.Lk = K; a.hd = E / nh;
+  a.split = m->head_split ? 1 : 0;   // head throughput mode: bf16x3 MFMAs
+  RUN(attention(a, st));
+  RUN(linear(attimg, E, false, L.i2t_fold, tmpimg, d, false, Mi, ACT_NONE, st, nullptr, mem, d));
+  return ln(tmpimg, d, mem, d, false, L.n4, Mi, d, 1e-5f, st);
+}
+
 static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool biased, bool two_way, float* qkv, float* att,
                          float* tmp, float* qc, float* kv, float* y, float* z, float* qimg, float* kvk, float* attimg,
                          float* tmpimg, int F, hipStream_t st) {
@@ -473,13 +536,7 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
     const float* kvp = io.kv_pre;
     long ldkv = io.ld_kv_pre;
     if (!kvp) {
-      GemmP p;  // K|V of the image tokens, one batch entry per sample (mem may be a strided view)
-      p.A = io.mem; p.lda = d; p.sA = io.s_mem;
-      p.split = L.ca_kv.ws ? 1 : 0; p.B = L.ca_kv.wsel(p.split); p.ldb = d;
-      p.C = kv; p.ldc = 2 * E; p.sC = (long)HW * 2 * E;
-      p.table = L.ca_kv_table; p.ldt = 2 * E; p.period = HW;
-      p.M = HW; p.N = 2 * E; p.K = d; p.batch = io.nb;
-      RUN(gemm_nt(p, st));
+      RUN(project_image_kv(m, L, io.mem, io.s_mem, io.nb, kv, st));
       kvp = kv; ldkv = 2 * E;
     }
     AttnP a;
@@ -507,19 +564,8 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
   RUN(linear(z, F, false, L.ffn2, tmp, d, false, Mk, ACT_NONE, st, nullptr, io.x, io.ldx));
   RUN(ln(tmp, d, io.x, io.ldx, false, L.n3, Mk, d, 1e-5f, st));
   if (two_way && io.update_mem) {
-    // ---- image -> token attention, NO masks (encoder_decoder.py:638-649)
-    const int Mi = io.nb * HW;
-    RUN(linear(io.mem, d, false, L.i2t_q, qimg, E, false, Mi, ACT_NONE, st, nullptr, nullptr, 0, L.i2t_q_table, E, HW));
-    RUN(linear(io.x, io.ldx, false, L.i2t_kv, kvk, 2 * E, false, Mk, ACT_NONE, st));
-    AttnP a;
-    a.Q = qimg; a.K = kvk; a.V = kvk + E; a.O = attimg;
-    a.ldq = E; a.ldk = a.ldv = 2 * E; a.ldo = E;
-    a.sQ = (long)HW * E; a.sK = a.sV = (long)K * 2 * E; a.sO = (long)HW * E;
-    a.B = io.nb; a.H = nh; a.Lq = HW; a.Lk = K; a.hd = E / nh;
-    a.split = m->head_split ? 1 : 0;   // head throughput mode: bf16x3 MFMAs
-    RUN(attention(a, st));
-    RUN(linear(attimg, E, false, L.i2t_fold, tmpimg, d, false, Mi, ACT_NONE, st, nullptr, io.mem, d));
-    RUN(ln(tmpimg, d, io.mem, d, false, L.n4, Mi, d, 1e-5f, st));
+    RUN(image_update_q(m, L, io.mem, io.nb, qimg, st));
+    RUN(image_update(m, L, io.x, io.ldx, io.mem, io.nb, qimg, kvk, attimg, tmpimg, st, nullptr));
   }
   return 0;
 }
@@ -559,6 +605,25 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
   float* adj_out = ss.adj_out;
   float* attn_adj = ss.attn_adj;
 
+  // image lane of the skeleton head (see (3)): forked first so image_project overlaps the pooling chain
+  const bool ov2 = m->overlap_dec && m->side2 != nullptr;
+  hipStream_t s2 = ov2 ? m->side2 : st;
+  hipEvent_t const ev_x = m->ev_sup[0], ev_xr = m->ev_sup[1], ev_kv = m->ev_sup[2], ev_f = m->ev_sup[3];
+  if (ov2) {
+    EC_HIP(hipEventRecord(ev_f, st));
+    EC_HIP(hipStreamWaitEvent(s2, ev_f, 0));
+  }
+  const int nb = S * bs;
+  const int nsk = (int)m->skel.size();
+  for (int s = 0; s < S; ++s)
+    RUN(linear(fs[s], C, false, m->image_project, m->s_mem + (long)s * Mi * d, d, false, Mi, ACT_NONE, s2));
+  if (nsk > 0) {
+    RUN(project_image_kv(m, m->skel[0], m->s_mem, (long)HW * d, nb, m->s_kv, s2));
+    if (ov2) EC_HIP(hipEventRecord(ev_kv, s2));
+    RUN(tl_mark(m, "I.kv0", s2));
+    if (nsk > 1) RUN(image_update_q(m, m->skel[0], m->s_mem, nb, m->s_qimg, s2));
+  }
+
   // (2) support keypoint pooling + query_proj (head.py:175-188)
   for (int s = 0; s < S; ++s) {
     RUN(pool_weights(target_s[s], mask_s, 1.f / (float)S, m->Wp, bs, K, m->cfg.heatmap_size, g, st));
@@ -572,23 +637,41 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
   }
   RUN(linear(m->pooled, C, false, m->query_proj, ss.sk, d, false, Mk, ACT_NONE, st));
   m->taps["support_keypoints"] = {ss.sk, (long)Mk * d};
+  RUN(tl_mark(m, "S.pooled", st));
 
-  // (3) skeleton head (skeleton.py:58-161)
+  // (3) skeleton head (skeleton.py:58-161).  Two lanes: the token path of every layer (self-attention, token->image cross
+  // attention, GCN feed-forward) stays on st; everything that only touches the image memory - image_project, each layer's K|V
+  // and image-query projections, and the image->token update of the previous layer - runs on the helper stream s2, so layer
+  // i+1's self-attention block overlaps layer i's image update.  Hand-offs: ev_x (x_{i+1} final -> image update may read it),
+  // ev_xr (image update has read x -> LN1 of layer i+1 may overwrite it), ev_kv (K|V of layer i ready -> cross attention).
   RUN(adj_build(m->d_edges, m->d_off, mask_s, ss.valid, ss.kmask, ss.kmask_fixed, m->binary, m->adj_r1, bs, K, st));
   if (ev_sk) EC_HIP(hipEventRecord(ev_sk, st));   // support tokens + key masks are ready: the encoder may start
-  const int nb = S * bs;
-  for (int s = 0; s < S; ++s) {
-    RUN(linear(fs[s], C, false, m->image_project, m->s_mem + (long)s * Mi * d, d, false, Mi, ACT_NONE, st));
-    RUN(copy2d(m->s_x + (long)s * Mk * d, d, ss.sk, d, Mk, d, st));
-  }
-  for (size_t i = 0; i < m->skel.size(); ++i) {
+  for (int s = 0; s < S; ++s) RUN(copy2d(m->s_x + (long)s * Mk * d, d, ss.sk, d, Mk, d, st));
+  for (int i = 0; i < nsk; ++i) {
     LayerIO io;
     io.x = m->s_x; io.ldx = d; io.mem = m->s_mem; io.s_mem = (long)HW * d;
     io.adj1 = m->adj_r1; io.valid = ss.valid; io.kmask_fixed = ss.kmask_fixed; io.bias = nullptr;
     io.nb = nb; io.bs = bs;
-    io.update_mem = (i + 1 < m->skel.size());  // the last layer's image update is never read (skeleton.py:104-112)
+    io.update_mem = false;                       // done below, on s2
+    io.kv_pre = m->s_kv; io.ld_kv_pre = 2 * m->E;
+    if (ov2) {
+      io.wait_x = i > 0 ? ev_xr : nullptr;
+      io.wait_ca[0] = ev_kv;
+    }
     RUN(run_dec_layer(m, m->skel[i], io, false, true, m->s_qkv, m->s_att, m->s_tmp, m->s_qc, m->s_kv, m->s_y, m->s_z, m->s_qimg,
                       m->s_kvk, m->s_attimg, m->s_tmpimg, Fs, st));
+    RUN(tl_mark(m, i == 0 ? "S.skel0" : i == 1 ? "S.skel1" : "S.skel2", st));
+    if (i + 1 < nsk) {   // the last layer's image update is never read (skeleton.py:104-112)
+      if (ov2) {
+        EC_HIP(hipEventRecord(ev_x, st));
+        EC_HIP(hipStreamWaitEvent(s2, ev_x, 0));
+      }
+      RUN(image_update(m, m->skel[i], m->s_x, d, m->s_mem, nb, m->s_qimg, m->s_kvk, m->s_attimg, m->s_tmpimg, s2, ov2 ? ev_xr : nullptr));
+      RUN(project_image_kv(m, m->skel[i + 1], m->s_mem, (long)HW * d, nb, m->s_kv, s2));
+      if (ov2) EC_HIP(hipEventRecord(ev_kv, s2));
+      RUN(tl_mark(m, i == 0 ? "I.kv1" : "I.kv2", s2));
+      if (i + 2 < nsk) RUN(image_update_q(m, m->skel[i + 1], m->s_mem, nb, m->s_qimg, s2));
+    }
   }
   RUN(mean_over(m->kp_ref, m->s_x, (long)Mk * d, S, (long)Mk * d, st));
   m->taps["skel_kp_refined"] = {m->kp_ref, (long)Mk * d};
@@ -622,6 +705,7 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
       RUN(bias_mlp(attn_adj, Ld.m_w1, Ld.m_b1, Ld.m_w2, Ld.m_b2, ss.dec_bias + li * (size_t)bs * m->cfg.nhead * K * K, hops1,
                    m->cfg.max_hops + m->cfg.nhead, m->cfg.nhead, bs, K, st));
     }
+  RUN(tl_mark(m, "S.end", st));
   return 0;
 }
 
@@ -644,6 +728,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     p.M = HW; p.N = d; p.K = C; p.batch = bs;
     RUN(gemm_nt(p, st));
   }
+  RUN(tl_mark(m, "Q.inproj", st));
   if (wait_sk) EC_HIP(hipStreamWaitEvent(st, wait_sk, 0));
   RUN(copy3d(m->e_x + (long)HW * d, d, (long)L * d, ss.sk, d, (long)K * d, bs, K, d, st));
 
@@ -666,6 +751,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     RUN(linear(m->e_x, d, false, e.l1, m->e_h, Fd, false, Me, ACT_RELU, st));
     RUN(linear(m->e_h, Fd, false, e.l2, m->e_tmp, d, false, Me, ACT_NONE, st, nullptr, m->e_x, d));
     RUN(ln(m->e_tmp, d, m->e_x, d, false, e.n2, Me, d, 1e-5f, st));
+    RUN(tl_mark(m, i == 0 ? "Q.enc0" : i == 1 ? "Q.enc1" : "Q.enc2", st));
   }
   m->taps["enc"] = {m->e_x, (long)Me * d};
   float* mem = m->e_x;                       // image tokens of sample b: rows b*L .. b*L+HW-1
@@ -700,6 +786,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     RUN(gemm_nt(p, ax));
   }
   RUN(mark(ev_kv));
+  RUN(tl_mark(m, "A.kv", ax));
 
   // (5) proposal generator (encoder_decoder.py:49-112)
   {
@@ -723,6 +810,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     RUN(bgemm_small(p, st));
   }
   RUN(proposals(sim, out->initial_proposals_dev, pts, Mk, g, st));   // pts[0] = decoder proposals b_0
+  RUN(tl_mark(m, "Q.prop", st));
 
   // (6) decoder (encoder_decoder.py:330-425): x lives as the left half of d_qin = [x | qpe].
   // Stream plan (ax = helper stream, == st when overlap is off).  With x_l the token state entering layer l and b_l its
@@ -743,6 +831,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
   RUN(mark(ev_qpe));
   RUN(copy3d(m->d_qin, 2 * d, (long)K * 2 * d, kp, d, s_tok, bs, K, d, st));
   if (wait_adj) EC_HIP(hipStreamWaitEvent(st, wait_adj, 0));   // adjacency / Markov stack from the support side
+  RUN(tl_mark(m, "Q.adjwait", st));
   for (int li = 0; li < nL; ++li) {
     const DecLayer& Ld = m->dec[li];
     float* bi = pts + (long)li * Mk * 2;
@@ -761,6 +850,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     }
     RUN(run_dec_layer(m, Ld, io, true, false, m->d_qkv, m->d_att, m->d_tmp, m->d_qc, m->d_kv, m->d_y, m->d_z, nullptr, nullptr,
                       nullptr, nullptr, Fd, st));
+    RUN(tl_mark(m, li == 0 ? "Q.dec0" : li == 1 ? "Q.dec1" : "Q.dec2", st));
     // ---- helper chain of layer li
     RUN(fork(ev_fork));
     float* hs = m->d_hs + (long)li * Mk * d;
@@ -780,10 +870,12 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     // (7) head output of this level (head.py:216-220): kpt_branch[l](hs[l]) on top of out_points[l] = b_l
     RUN(kpt_mlp(m, kb, hs, d, Mk, bi, out->output_kpts_dev + (long)li * Mk * 2, ax));
   }
+  RUN(tl_mark(m, "A.end", ax));
   if (ovd) {
     EC_HIP(hipEventRecord(ev_done, ax));
     EC_HIP(hipStreamWaitEvent(st, ev_done, 0));
   }
+  RUN(tl_mark(m, "Q.end", st));
   m->taps["hs"] = {m->d_hs, (long)m->dec.size() * Mk * d};
   return 0;
 }
@@ -811,15 +903,18 @@ static SupportState workspace_support(ec_model* m, const ec_outputs* out) {
 static int run_head(ec_model* m, const float* fq, const float* const* fs, const float* const* target_s, const float* mask_s,
                     int bs, int S, hipStream_t st, const ec_outputs* out) {
   const SupportState ss = workspace_support(m, out);
+  RUN(tl_mark(m, "head", st));
   if (m->overlap) {
     EC_HIP(hipEventRecord(m->ev_fork, st));
     EC_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
     RUN(run_head_support(m, fs, target_s, mask_s, bs, S, m->side, ss, m->ev_sk));
     EC_HIP(hipEventRecord(m->ev_join, m->side));
-    return run_head_query(m, fq, bs, st, out, ss, m->ev_sk, m->ev_join);   // st joins the side stream before the decoder
+    RUN(run_head_query(m, fq, bs, st, out, ss, m->ev_sk, m->ev_join));   // st joins the side stream before the decoder
+    return tl_dump(m);
   }
   RUN(run_head_support(m, fs, target_s, mask_s, bs, S, st, ss));
-  return run_head_query(m, fq, bs, st, out, ss);
+  RUN(run_head_query(m, fq, bs, st, out, ss));
+  return tl_dump(m);
 }
 
 static int upload_edges(ec_model* m, const int32_t* edges, const int32_t* off, int bs, hipStream_t st) {
@@ -883,7 +978,9 @@ int ec_destroy(ec_handle m) {
   if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
   for (hipEvent_t e : {m->ev_fork, m->ev_sk, m->ev_join}) if (e) (void)hipEventDestroy(e);
   if (m->aux) { (void)hipStreamSynchronize(m->aux); (void)hipStreamDestroy(m->aux); }
+  if (m->side2) { (void)hipStreamSynchronize(m->side2); (void)hipStreamDestroy(m->side2); }
   for (hipEvent_t e : m->ev_aux) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : m->ev_sup) if (e) (void)hipEventDestroy(e);
   delete m;
   return EC_OK;
 }
@@ -1055,15 +1152,23 @@ int ec_finalize(ec_handle m) {
   {
     const char* ov = getenv("EC_OVERLAP");
     m->overlap = !(ov && atoi(ov) == 0);
+    m->timeline = getenv("EC_TIMELINE") != nullptr;
     if (m->overlap) {
-      EC_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+      // the support lane is the longer one (pooling + three two-way layers before the decoder can start): EC_SIDE_PRIO=1 gives it
+      // and its image lane the high stream priority (measured: no effect - the lanes hold one kernel in flight each)
+      int lo = 0, hi = 0;
+      EC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      const int prio = getenv("EC_SIDE_PRIO") ? hi : 0;
+      EC_HIP(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, prio));
       EC_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
       EC_HIP(hipEventCreateWithFlags(&m->ev_sk, hipEventDisableTiming));
       EC_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
       m->overlap_dec = !(ov && atoi(ov) == 1);   // EC_OVERLAP=1: support-side overlap only
       if (m->overlap_dec) {
         EC_HIP(hipStreamCreateWithFlags(&m->aux, hipStreamNonBlocking));
+        EC_HIP(hipStreamCreateWithPriority(&m->side2, hipStreamNonBlocking, prio));
         for (hipEvent_t& e : m->ev_aux) EC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipEvent_t& e : m->ev_sup) EC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       }
     }
   }

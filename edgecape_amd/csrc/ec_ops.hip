@@ -265,10 +265,13 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const int32_t* edges, co
     }
   }
   int cnt = 0;
+  const bool first = blockIdx.y == 0;   // the row blocks of a sample share the masks: block 0 writes them
   for (int k = tid; k < K; k += 256) {
     const bool v = mask_s[b * K + k] != 0.f;   // kp_mask = ~mask_s.bool() (head.py:189)
-    valid[b * K + k] = v ? 1.f : 0.f;
-    kmask[b * K + k] = v ? 0 : 1;
+    if (first) {
+      valid[b * K + k] = v ? 1.f : 0.f;
+      kmask[b * K + k] = v ? 0 : 1;
+    }
     cnt += v ? 1 : 0;
   }
   if (cnt) atomicAdd(&nvalid, cnt);
@@ -276,10 +279,10 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const int32_t* edges, co
   for (int k = tid; k < K; k += 256) {
     const bool v = mask_s[b * K + k] != 0.f;
     // tgt_key_padding_mask_remove_all_true (skeleton.py:98-99): un-mask key 0 of all-padded samples
-    kmask_fixed[b * K + k] = (v || (nvalid == 0 && k == 0)) ? 0 : 1;
+    if (first) kmask_fixed[b * K + k] = (v || (nvalid == 0 && k == 0)) ? 0 : 1;
   }
   const int wave = tid >> 6, lane = tid & 63;
-  for (int i = wave; i < K; i += 4) {
+  for (int i = blockIdx.y * 4 + wave; i < K; i += 4 * gridDim.y) {
     const bool vi = mask_s[b * K + i] != 0.f;
     float rs = 0.f;
     for (int j = lane; j < K; j += 64) {
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* x, float* y, 
   for (int c = lane; c < cols; c += 64) y[(long)row * cols + c] = x[(long)row * cols + c] * inv;
 }
 
-// predict_skeleton tail + markov normalisation (skeleton.py:139-150,158): one block per sample
+// predict_skeleton tail + markov normalisation (skeleton.py:139-150,158): one wave per adjacency row, grid (bs, ceil(K/4))
 __global__ __launch_bounds__(256) void adj_combine_kernel(const float* P, const float* binary, const float* valid,
                                                           const float* zc_w, const float* zc_b, float* adj_out, float* adj1,
                                                           float* attn_adj, int bs, int K) {
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(256) void adj_combine_kernel(const float* P, const 
   float* i0 = attn_adj + (long)b * K * K;                       // hop 0 = I
   float* m1 = attn_adj + ((long)bs + b) * K * K;                // hop 1 = A
   float* A1 = adj1 + (long)b * K * K;
-  for (int i = wave; i < K; i += 4) {
+  for (int i = blockIdx.y * 4 + wave; i < K; i += 4 * gridDim.y) {
     const float vi = valid[b * K + i];
     float u[2], rs = 0.f;
 #pragma unroll
@@ -711,7 +714,7 @@ int pool_weights(const float* target, const float* mask_s, float inv_shots, floa
 int adj_build(const int32_t* edges, const int32_t* offsets, const float* mask_s, float* valid, uint8_t* kmask,
               uint8_t* kmask_fixed, float* binary, float* adj_r1, int bs, int K, hipStream_t st) {
   EC_REQUIRE(K * K <= 64 * 1024, -1, "adj_build: K too large");
-  hipLaunchKernelGGL(adj_build_kernel, dim3(bs), dim3(256), (size_t)K * K, st, edges, offsets, mask_s, valid, kmask, kmask_fixed,
+  hipLaunchKernelGGL(adj_build_kernel, dim3(bs, 5), dim3(256), (size_t)K * K, st, edges, offsets, mask_s, valid, kmask, kmask_fixed,
                      binary, adj_r1, K);
   EC_LAUNCH_CHECK();
   return 0;
@@ -726,7 +729,7 @@ int rownorm(const float* x, float* y, int rows, int cols, hipStream_t st) {
 int adj_combine(const float* P, const float* binary, const float* valid, const float* zc_w, const float* zc_b, float* adj_out,
                 float* adj1, float* attn_adj, int bs, int K, hipStream_t st) {
   EC_REQUIRE(K <= 128, -1, "adj_combine: K must be <= 128");
-  hipLaunchKernelGGL(adj_combine_kernel, dim3(bs), dim3(256), 0, st, P, binary, valid, zc_w, zc_b, adj_out, adj1, attn_adj, bs, K);
+  hipLaunchKernelGGL(adj_combine_kernel, dim3(bs, (K + 3) / 4), dim3(256), 0, st, P, binary, valid, zc_w, zc_b, adj_out, adj1, attn_adj, bs, K);
   EC_LAUNCH_CHECK();
   return 0;
 }

@@ -7,7 +7,7 @@ import sys
 
 def main(path, head_only=False):
     db = sqlite3.connect(path)
-    rows = db.execute("select name,start,end,grid_x,grid_y,grid_z,workgroup_x from kernels order by start").fetchall()
+    rows = db.execute("select name,start,end,grid_x,grid_y,grid_z,workgroup_x,stream_id from kernels order by start").fetchall()
     idx = [i for i, r in enumerate(rows) if "im2col" in r[0]]
     step = rows[idx[-2]:]
     t0 = step[0][1]
@@ -22,7 +22,7 @@ def main(path, head_only=False):
         a[0] += 1
         a[1] += d
         if not head_only or (r[1] - t0) / 1e3 > head_only:
-            print(f"{(r[1]-t0)/1e3:9.1f} {d:8.1f}  grid {r[3]//max(r[6],1):5d}x{r[4]}x{r[5]}  {n[:70]}")
+            print(f"{(r[1]-t0)/1e3:9.1f} {d:8.1f}  s{r[7]} grid {r[3]//max(r[6],1):5d}x{r[4]}x{r[5]}  {n[:70]}")
     print("---- per-kernel totals of the step (us)")
     for n, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"{d:9.1f} {c:4d}  {n[:90]}")
