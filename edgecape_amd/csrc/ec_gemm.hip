@@ -565,6 +565,12 @@ int gemm_nt(const GemmP& p, hipStream_t st) {
     }
   }
   if (p.split) {
+    // experiment kept for A/B: wide-N wave tiles (32 x 128 per wave) share the in-register hi/lo split of an A fragment
+    // (~30 VALU) between 4 x 3 MFMAs instead of 1-2 x 3 (PMC at 128x64: 16.7 VALU per MFMA, MFMA pipe 19 % busy, waves one third
+    // parked / one third issue-stalled / one third issuing).  Measured 0-15 % SLOWER than the 2x2 configurations on every head
+    // shape (13568x768x256: 35.5 / 33.7 vs 30.9 us) - the split is not what bounds these kernels.
+    if (force == 64256) return launch_cfg<GM_SPLIT, 64, 256, 2, 2, 2>(p, st, 2);
+    if (force == 1281) return launch_cfg<GM_SPLIT, 128, 128, 4, 1, 2>(p, st, 2);
     switch (sel) {
       case 0: return (deep ? launch_cfg<GM_SPLIT, 256, 256, 2, 4, 2>(p, st, 1) : launch_cfg<GM_SPLIT, 256, 256, 2, 4, 2>(p, st, 1));
       case 1: return (deep ? launch_cfg<GM_SPLIT, 256, 128, 4, 2, 3>(p, st, 1) : launch_cfg<GM_SPLIT, 256, 128, 4, 2, 2>(p, st, 1));
