@@ -207,7 +207,7 @@ def test_attention_bf16x3(lib, B, H, Lq, Lk, hd, masked, biased):
     assert err < 1e-4, err          # plain bf16 operands give ~1e-2 here
 
 
-@pytest.mark.parametrize("B,H,L", [(2, 6, 257), (2, 12, 325), (1, 16, 730), (1, 6, 64)])
+@pytest.mark.parametrize("B,H,L", [(2, 6, 257), (2, 12, 325), (1, 16, 730), (1, 6, 64), (2, 6, 300), (2, 6, 96), (1, 6, 33), (1, 6, 161)])
 def test_attention_bf16(lib, B, H, L):
     """bf16 MFMA attention (backbone shape) vs fp64 math on the bf16-rounded operands."""
     hd = 64
