@@ -179,6 +179,18 @@ constexpr int A16_LDS = 2 * A16_STAGE;       // double buffered: 32 KiB
 // Likewise a 3-stage K/V ring (two tiles ahead, counted vmcnt(4), raw barrier): 54.9 vs 51.4 us - slower; the double buffer stays.
 // __launch_bounds__(256, 2): with a 256-register budget hipcc keeps the MFMA accumulators in VGPRs (no v_accvgpr_read/write
 // copies around the softmax: -90 of ~410 VALU instructions per key tile; the kernel is VALU-bound at 16 MFMAs per tile).
+// TRACE (debug instantiation, EC_ATTN_TRACE=1): lane 0 of every wave of one mid-grid workgroup stamps s_memtime at the
+// milestones of every key tile into p.bias (reused as a uint32 buffer); attention() prints the per-segment cycle counts.
+#define A16_STAMP(slot)                                                                          \
+  do {                                                                                           \
+    if constexpr (TRACE) {                                                                       \
+      if (tr_on) {                                                                               \
+        const unsigned ts_ = (unsigned)__builtin_amdgcn_s_memtime();                             \
+        if (lane == 0) ((unsigned*)p.bias)[wave * 128 + (k0 >> 6) * 8 + (slot)] = ts_;           \
+      }                                                                                          \
+    }                                                                                            \
+  } while (0)
+template <bool TRACE>
 __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -223,9 +235,13 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
   stage(0, smem);
   int cur = 0;
   const bool active = q0 < p.Lq;   // a wave whose 32 queries are all past Lq only helps staging (wave-uniform)
+  const bool tr_on = TRACE && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == gridDim.z / 2;
   for (int k0 = 0; k0 < p.Lk; k0 += 64) {
+    A16_STAMP(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    A16_STAMP(1);
     __syncthreads();
+    A16_STAMP(2);
     if (k0 + 64 < p.Lk) stage(k0 + 64, smem + (cur ^ 1) * A16_STAGE);
     const char* Kt = smem + cur * A16_STAGE;
     const char* Vtt = Kt + A16_TILE;
@@ -252,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
         for (int r = 0; r < 16; ++r)
           if (32 * t + (r & 3) + 8 * (r >> 2) >= lim) s[t][r] = -INFINITY;
     }
+    A16_STAMP(3);
     // raw-score maximum (the scale c > 0 is folded into the exponent below)
     float tmax = -INFINITY;
 #pragma unroll
@@ -259,8 +276,12 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[t][r]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * c;
-    // running maximum: rescale O^T only when some query's maximum actually grew (exact: alpha == 1 otherwise)
-    if (!__all(tmax <= mrun)) {
+    // LAZY running maximum: the reference point mrun only moves when some query's tile maximum exceeds it by more than 2^8
+    // (softmax is invariant to the reference; exp2 arguments stay <= 8, so P <= 256 and the row sums stay far inside fp32 /
+    // bf16 range).  With 32 queries per wave SOME row sets a new maximum in almost every tile, so an exact running maximum
+    // rescales O^T (32 multiplies + bookkeeping, ~110 of ~300 VALU instructions per tile) every time; the lazy form does it
+    // on the first tile and then practically never.
+    if (!__all(tmax <= mrun + 8.f)) {
       const float mnew = fmaxf(mrun, tmax);
       const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
       mrun = mnew;
@@ -270,6 +291,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
     }
+    A16_STAMP(4);
     float psum = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -280,6 +302,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
         psum += e;
       }
     lrun += psum;
+    A16_STAMP(5);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -307,6 +330,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
         }
       }
     }
+    A16_STAMP(6);
   }
   lrun += __shfl_xor(lrun, 32, 64);
   const float inv = 1.f / lrun;
@@ -579,7 +603,33 @@ int attention(const AttnP& p, hipStream_t st) {
   if (p.bf16) {
     EC_REQUIRE(p.hd == 64 && !p.kmask && !p.bias, -1, "attention(bf16): hd = 64, no mask / bias (backbone only)");
     EC_REQUIRE(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0, -1, "attention(bf16): stride alignment");
-    hipLaunchKernelGGL(attn_bf16_kernel, grid, dim3(256), A16_LDS, st, p);
+    static const bool trace = getenv("EC_ATTN_TRACE") != nullptr;
+    if (trace) {
+      unsigned* d_tr = nullptr;
+      EC_HIP(hipMalloc((void**)&d_tr, 4 * 128 * sizeof(unsigned)));
+      EC_HIP(hipMemsetAsync(d_tr, 0, 4 * 128 * sizeof(unsigned), st));
+      AttnP q = p;
+      q.bias = (const float*)d_tr;
+      hipLaunchKernelGGL(attn_bf16_kernel<true>, grid, dim3(256), A16_LDS, st, q);
+      EC_LAUNCH_CHECK();
+      EC_HIP(hipStreamSynchronize(st));
+      unsigned h[4 * 128];
+      EC_HIP(hipMemcpy(h, d_tr, sizeof(h), hipMemcpyDeviceToHost));
+      (void)hipFree(d_tr);
+      const int nt = (p.Lk + 63) / 64;
+      for (int w = 0; w < 4; ++w) {
+        fprintf(stderr, "[attn trace] wave %d:", w);
+        for (int t = 0; t < nt && t < 16; ++t) {
+          const unsigned* r = h + w * 128 + t * 8;
+          fprintf(stderr, " | wait %u bar %u stage+QK %u max %u exp %u PV %u", r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3],
+                  r[5] - r[4], r[6] - r[5]);
+          if (t + 1 < nt) fprintf(stderr, " (gap %u)", h[w * 128 + (t + 1) * 8] - r[6]);
+        }
+        fprintf(stderr, " | total %u\n", h[w * 128 + (nt - 1) * 8 + 6] - h[w * 128]);
+      }
+      return 0;
+    }
+    hipLaunchKernelGGL(attn_bf16_kernel<false>, grid, dim3(256), A16_LDS, st, p);
     EC_LAUNCH_CHECK();
     return 0;
   }
