@@ -292,16 +292,22 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
         for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
     }
     A16_STAMP(4);
-    float psum = 0.f;
+    // the kernel is VALU-bound (PMC: 16.6 VALU per MFMA, MFMA pipe 20 % busy): scale-and-shift and the row sums run as packed
+    // fp32 pairs (v_pk_fma_f32 / v_pk_add_f32: two scores per instruction); only v_exp_f32 stays one per score
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    f32x2 psum2 = {0.f, 0.f};
+    const f32x2 c2 = {c, c}, nm2 = {-mrun, -mrun};
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(fmaf(s[t][r], c, -mrun));
-        s[t][r] = e;
-        psum += e;
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 x = __builtin_elementwise_fma(f32x2{s[t][r], s[t][r + 1]}, c2, nm2);
+        const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+        s[t][r] = e[0];
+        s[t][r + 1] = e[1];
+        psum2 += e;
       }
-    lrun += psum;
+    lrun += psum2[0] + psum2[1];
     A16_STAMP(5);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
