@@ -13,7 +13,7 @@ counters at the end.
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0.  `roofline` is for the north-star kernel (backbone QKV GEMM, its own
-kernel symbol gemm_nt_kernel<.., 1>): algorithmic FLOPs per launch / mean launch duration measured with
+kernel symbol gemm8_bf16_kernel<1, 1, ..>): algorithmic FLOPs per launch / mean launch duration measured with
 HIP events bracketing every launch inside the timed steps (ec_profile).  `cpu_baseline` times the CPU
 oracle (a port, not the product) on the host cores over a bounded sample of the same workload.
 """
@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--arch", default="dinov2_vitb14")
     ap.add_argument("--precision", default=os.environ.get("EC_BENCH_PRECISION", "bf16"), choices=["bf16", "fp32"],
-                    help="backbone MFMA operand type (fp32 accumulate); the head is fp32")
+                    help="backbone MFMA operand type (fp32 accumulate)")
     ap.add_argument("--head-precision", default=os.environ.get("EC_BENCH_HEAD_PRECISION", "bf16x3"), choices=["fp32", "bf16x3"],
                     help="head GEMMs: exact fp32 MFMA, or split-bf16 (hi+lo, 3 MFMAs per product; fp32-class accuracy)")
     ap.add_argument("--cpu-sample", type=int, default=4, help="pairs in the CPU-baseline sample (0 = skip)")

@@ -1,0 +1,60 @@
+"""bench.py contract (task prompt section 4): one JSON line on rank 0 with the required keys, run directly and through
+torch.distributed.run with one rank (the driver's launch line), on a small configuration so it finishes in seconds."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "3", "--warmup", "1", "--batch", "4", "--arch", "dinov2_vits14", "--image-size", "224", "--no-episode",
+         "--cpu-sample", "1"]
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _check(line, with_cpu):
+    d = json.loads(line)
+    missing = (REQUIRED - ({"cpu_baseline"} if not with_cpu else set())) - set(d)
+    assert not missing, missing
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["value"] > 0 and abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) / d["value"] < 0.02      # pairs per step / step time
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and 0 < r["frac"] < 1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["launches_timed"] == 3 * 12
+    if with_cpu:
+        c = d["cpu_baseline"]
+        assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+
+
+@pytest.mark.gpu
+def test_bench_direct_small():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL, capture_output=True, text=True,
+                         timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    _check(lines[0], with_cpu=True)
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_one_rank():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline"] + SMALL
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    _check(lines[0], with_cpu=False)
