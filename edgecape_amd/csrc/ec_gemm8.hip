@@ -171,7 +171,13 @@ __device__ __forceinline__ void g8_epilogue(const GemmP& p, f32x4 (&acc)[8][4], 
 
 // TRACE (debug instantiation only, EC_G8_TRACE=1): lane 0 of every wave of workgroup 0 stamps s_memtime at five points of
 // every phase of one K-tile pair into its LDS staging slot; dumped to p.aux after the first tile (tools/g8_trace.py).
-template <int KIND, int TAG, bool TRACE = false, bool TWOPH = false>
+// ONEBAR (EC_G8_1BAR=1, A/B only - measured SLOWER: 8192^3 1300 vs 1355 TFLOP/s, QKV 1029 vs 1111-1139): one barrier per phase instead of two.  Group 0 keeps only the barrier AFTER its MFMA block, group 1 only the one BEFORE
+// its MFMA block, so physical barrier #p is {group 0 done with M_p, group 1 done with R_p}: inside one barrier interval group 0
+// runs R_p then M_p while group 1 runs M_(p-1) then R_p - the same matrix-pipe / memory-pipe alternation on every SIMD with half
+// the barrier releases.  RAW: half-tile i is waited for (vmcnt) in every wave's R_(i-2), barrier #(i-2) follows that wait in
+// both groups and precedes every read of it (R_(i-1) at the earliest).  WAR: slot of half-tile i-8 is re-staged in R_(i-5);
+// its last reads (R_(<=i-8)) were retired before barrier #(i-7) in both groups.
+template <int KIND, int TAG, bool TRACE = false, bool TWOPH = false, bool ONEBAR = false>
 __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -235,7 +241,11 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   if constexpr (TWOPH) issue(rp1, 1);                // two-phase schedule: the stream runs 6 half-tiles ahead
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue half-tiles have landed (this wave's part)
   G8_BAR();
-  if (wr == 1) G8_BAR();                             // stagger: group 1 runs one barrier behind group 0
+  if constexpr (!ONEBAR) {
+    if (wr == 1) G8_BAR();                           // stagger: group 1 runs one barrier behind group 0
+  }
+#define G8_BAR_A() do { if constexpr (ONEBAR) { if (wr == 1) G8_BAR(); } else G8_BAR(); } while (0)   /* before the MFMA block */
+#define G8_BAR_B() do { if constexpr (ONEBAR) { if (wr == 0) G8_BAR(); } else G8_BAR(); } while (0)   /* after the MFMA block */
 
   // ---- fragment read addresses ------------------------------------------------------------------------------------
   // reader lane: row r = lane&15 of the 16-row sub-tile, logical chunk lane>>4 at physical chunk (lane>>4) ^ 2*(r>=8)
@@ -338,10 +348,12 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
         for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
           for (int kh = 0; kh < 2; ++kh) af[fi][kh] = *(const bf16x8*)(ab + fi * 2048 + kh * 1024);
+        G8_STAMP(40 + buf * 8 + 0);
         issue(rp1, 1);
+        G8_STAMP(40 + buf * 8 + 1);
         if (buf == 1 || kt2 > 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // see "tile seam" below
         G8_STAMP(buf * 20 + 1);
-        G8_BAR();
+        G8_BAR_A();
         G8_STAMP(buf * 20 + 2);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -353,7 +365,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
               acc[fi][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[f][kh], af[fi][kh], acc[fi][f], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         G8_STAMP(buf * 20 + 3);
-        G8_BAR();
+        G8_BAR_B();
         G8_STAMP(buf * 20 + 4);
         G8_STAMP(buf * 20 + 5);
         // ---------------- phase 1: quadrant (0, 1)
@@ -361,10 +373,12 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
         for (int f = 0; f < 2; ++f)
 #pragma unroll
           for (int kh = 0; kh < 2; ++kh) b1[f][kh] = *(const bf16x8*)(bb + G8_HALF + f * 2048 + kh * 1024);
+        G8_STAMP(40 + buf * 8 + 2);
         issue(rp2, 2);
+        G8_STAMP(40 + buf * 8 + 3);
         if (buf == 1 || kt2 > 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // see "tile seam" below
         G8_STAMP(buf * 20 + 6);
-        G8_BAR();
+        G8_BAR_A();
         G8_STAMP(buf * 20 + 7);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -376,7 +390,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
               acc[fi][2 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[f][kh], af[fi][kh], acc[fi][2 + f], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         G8_STAMP(buf * 20 + 8);
-        G8_BAR();
+        G8_BAR_B();
         G8_STAMP(buf * 20 + 9);
         G8_STAMP(buf * 20 + 10);
         // ---------------- phase 2: quadrant (1, 1)
@@ -384,10 +398,12 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
         for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
           for (int kh = 0; kh < 2; ++kh) af[fi][kh] = *(const bf16x8*)(ab + 3 * G8_HALF + fi * 2048 + kh * 1024);
+        G8_STAMP(40 + buf * 8 + 4);
         issue(rp3, 3);
+        G8_STAMP(40 + buf * 8 + 5);
         if (buf == 1 || kt2 > 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // see "tile seam" below
         G8_STAMP(buf * 20 + 11);
-        G8_BAR();
+        G8_BAR_A();
         G8_STAMP(buf * 20 + 12);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -399,15 +415,17 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
               acc[4 + fi][2 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[f][kh], af[fi][kh], acc[4 + fi][2 + f], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         G8_STAMP(buf * 20 + 13);
-        G8_BAR();
+        G8_BAR_B();
         G8_STAMP(buf * 20 + 14);
         G8_STAMP(buf * 20 + 15);
         // ---------------- phase 3: quadrant (1, 0); the load stream moves on to the next K-tile
+        G8_STAMP(40 + buf * 8 + 6);
         advance();
         issue(rp0, 0);
+        G8_STAMP(40 + buf * 8 + 7);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         G8_STAMP(buf * 20 + 16);
-        G8_BAR();
+        G8_BAR_A();
         G8_STAMP(buf * 20 + 17);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -420,7 +438,11 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
         __builtin_amdgcn_s_setprio(0);
         }
         G8_STAMP(buf * 20 + 18);
-        if (buf == 0 || kt2 + 2 < nk) G8_BAR();
+        if constexpr (ONEBAR) {
+          G8_BAR_B();
+        } else {
+          if (buf == 0 || kt2 + 2 < nk) G8_BAR();
+        }
         G8_STAMP(buf * 20 + 19);   // the tile's last barrier is placed around the epilogue below
       }
     }
@@ -431,18 +453,24 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
     // loads issued after this point (loads retire in order among themselves; the epilogue's stores, also counted by
     // vmcnt, can only make that wait stricter) while the stores drain in the background under the next tile's MFMAs.
     if constexpr (TRACE) {
-      if (blockIdx.x == 0 && t == t_first && lane < 40)
+      if (blockIdx.x == 0 && t == t_first && lane < 56)
         ((unsigned*)p.aux)[wave * 64 + lane] = ((const unsigned*)(smem + G8_STAGE + wave * 4096))[lane];
     }
-    if (wr == 0) G8_BAR();
+    if constexpr (!ONEBAR) {
+      if (wr == 0) G8_BAR();
+    }
     {
       const int m0 = (t / ntn) << 8, n0 = (t % ntn) << 8;
       if (KIND != G8_GENERIC && m0 + 256 <= p.M && n0 + 256 <= p.N) g8_epilogue<KIND, true>(p, acc, smem, m0, n0, wr, wc, lane);
       else g8_epilogue<KIND, false>(p, acc, smem, m0, n0, wr, wc, lane);
     }
-    if (wr == 1) G8_BAR();
+    if constexpr (!ONEBAR) {
+      if (wr == 1) G8_BAR();
+    }
   }
-  if (wr == 0) G8_BAR();   // balances group 1's extra barrier at the start
+  if constexpr (!ONEBAR) {
+    if (wr == 0) G8_BAR();   // balances group 1's extra barrier at the start
+  }
 }
 
 
@@ -496,6 +524,21 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
     GemmP q2 = p;
     q2.dbg = dbg;
     hipLaunchKernelGGL(t2[kind], dim3((unsigned)grid), dim3(512), G8_LDS, st, q2);
+    EC_LAUNCH_CHECK();
+    return 1;
+  }
+  static const bool onebar = getenv("EC_G8_1BAR") && atoi(getenv("EC_G8_1BAR")) != 0;   // A/B: one barrier per phase
+  if (onebar) {
+    static const kern_t t1[4] = {gemm8_bf16_kernel<0, 0, false, false, true>, gemm8_bf16_kernel<1, 0, false, false, true>,
+                                 gemm8_bf16_kernel<2, 0, false, false, true>, gemm8_bf16_kernel<3, 0, false, false, true>};
+    static bool a1 = false;
+    if (!a1) {
+      for (int k = 0; k < 4; ++k) EC_HIP(hipFuncSetAttribute((const void*)t1[k], hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));
+      a1 = true;
+    }
+    GemmP q1 = p;
+    q1.dbg = dbg;
+    hipLaunchKernelGGL(t1[kind], dim3((unsigned)grid), dim3(512), G8_LDS, st, q1);
     EC_LAUNCH_CHECK();
     return 1;
   }

@@ -1448,7 +1448,7 @@ int ec_op_gemm_bench(const void* A, const void* W, const float* bias, void* C, i
     FILE* f = fopen("/tmp/g8_trace.txt", "w");
     if (f) {
       for (int w = 0; w < 8; ++w) {
-        for (int i = 0; i < 40; ++i) fprintf(f, "%u ", h[w * 64 + i]);
+        for (int i = 0; i < 56; ++i) fprintf(f, "%u ", h[w * 64 + i]);
         fprintf(f, "\n");
       }
       fclose(f);
