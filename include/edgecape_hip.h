@@ -22,7 +22,9 @@
  *   - return 0 on success, negative ec_status on failure; ec_last_error() gives the text.
  *     No exceptions cross the ABI.  No hidden synchronisation: work is enqueued on `stream`
  *     (a hipStream_t passed as void*; NULL = the legacy default stream).
- *   - a handle is not thread-safe; use one handle per stream.
+ *   - a handle is not thread-safe; use one handle per stream.  ec_forward / ec_head fork internal helper streams (support
+ *     lane, image lane, decoder helper lane) off `stream` and join them back before returning control of `stream`'s order:
+ *     everything the call enqueues is complete when `stream` reaches the end of the call's work.
  *   - layouts: images NCHW fp32; heatmaps [bs,K,hm,hm] fp32; features token-major [n,HW,C] fp32
  *     (EC_LAYOUT_TOKENS) or the reference's NCHW (EC_LAYOUT_NCHW).
  */
