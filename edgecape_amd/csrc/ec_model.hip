@@ -625,7 +625,12 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
   }
 
   // (2) support keypoint pooling + query_proj (head.py:175-188)
+  static const bool pool_dense = getenv("EC_POOL_DENSE") != nullptr;   // A/B: tap-weight matrix + dense batched GEMM
   for (int s = 0; s < S; ++s) {
+    if (!pool_dense) {
+      RUN(pool_gather(target_s[s], mask_s, 1.f / (float)S, fs[s], m->pooled, s == 0 ? 0.f : 1.f, bs, K, m->cfg.heatmap_size, g, C, st));
+      continue;
+    }
     RUN(pool_weights(target_s[s], mask_s, 1.f / (float)S, m->Wp, bs, K, m->cfg.heatmap_size, g, st));
     BgemmP p;
     p.A = m->Wp; p.lda = HW; p.sA = (long)K * HW;

@@ -243,6 +243,108 @@ __global__ __launch_bounds__(256) void pool_weights_kernel(const float* target, 
   }
 }
 
+// Fused support-keypoint pooling (head.py:175-186): the same tap weights as pool_weights_kernel, then the pooled feature
+//   pooled[b,k,:] (+)= sum_cell w[cell] * F[b,cell,:]
+// directly, visiting only the non-zero weights in cell order.  The targets of this pipeline are Gaussian blobs (sigma 2 on the
+// 64x64 heatmap = ~4x4 of the 18x18 token grid), so ~16-30 of the 324 cells are non-zero and the dense [K,HW]@[HW,C]
+// contraction (and its launch) disappears; a dense heatmap is still exact, just slower (every cell is visited).
+// Both resize passes run over (cell-row, column) pairs with per-coordinate tap tables, summing in ascending source order.
+__global__ __launch_bounds__(256) void pool_gather_kernel(const float* target, const float* mask_s, float inv_shots, const float* F,
+                                                          float* pooled, float beta, int K, int hm, int g, int C) {
+  extern __shared__ float sm[];
+  float* t = sm;                       // hm*hm heatmap
+  float* tmp = t + hm * hm;            // g*hm : tmp[cy][x]
+  float* wts = tmp + g * hm;           // g*g tap weights
+  float* tl = wts + g * g;             // hm   : lambda of source coordinate
+  int* ti0 = (int*)(tl + hm);          // hm   : first target cell of source coordinate
+  int* ti1 = ti0 + hm;                 // hm   : second target cell
+  int* nzi = ti1 + hm;                 // g*g  : compacted non-zero cells
+  float* red = (float*)(nzi + g * g);  // 4 + 1 (count)
+  const int bk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = bk / K;
+  const float msk = mask_s[bk];
+  float* out = pooled + (long)bk * C;
+  if (msk == 0.f) {   // padded keypoint slot: pooled feature is multiplied by mask_s = 0 (head.py:187)
+    if (beta == 0.f)
+      for (int c = tid; c < C; c += 256) out[c] = 0.f;
+    return;
+  }
+  const float* src = target + (long)bk * hm * hm;
+  const float scale = (float)g / (float)hm;
+  float s = 0.f;
+  for (int i = tid; i < hm * hm; i += 256) {
+    const float v = src[i];
+    t[i] = v;
+    s += v;
+  }
+  if (tid < hm) {
+    int i0, i1; float l;
+    bilinear_src(tid, scale, g, i0, i1, l);
+    ti0[tid] = i0; ti1[tid] = i1; tl[tid] = l;
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const float total = red[0] + red[1] + red[2] + red[3];
+  const float inv_scale = (float)hm / (float)g;
+  // tmp[cy][x] = sum_y wy(cy, y) t[y][x], y ascending; only sources within one cell of cy can contribute
+  for (int idx = tid; idx < g * hm; idx += 256) {
+    const int cy = idx / hm, x = idx - cy * hm;
+    const int ylo = max(0, (int)((float)(cy - 1) * inv_scale) - 1), yhi = min(hm - 1, (int)((float)(cy + 2) * inv_scale) + 1);
+    float acc = 0.f;
+    for (int y = ylo; y <= yhi; ++y) {
+      const float v = t[y * hm + x], l = tl[y];
+      if (ti0[y] == cy) acc += (1.f - l) * v;
+      if (ti1[y] == cy) acc += l * v;
+    }
+    tmp[idx] = acc;
+  }
+  __syncthreads();
+  const float norm = msk * inv_shots / (total + 1e-8f);
+  for (int cell = tid; cell < g * g; cell += 256) {
+    const int cy = cell / g, cx = cell - cy * g;
+    const int xlo = max(0, (int)((float)(cx - 1) * inv_scale) - 1), xhi = min(hm - 1, (int)((float)(cx + 2) * inv_scale) + 1);
+    float acc = 0.f;
+    for (int x = xlo; x <= xhi; ++x) {
+      const float l = tl[x];
+      float w = 0.f;
+      if (ti0[x] == cx) w += 1.f - l;
+      if (ti1[x] == cx) w += l;
+      if (w != 0.f) acc += w * tmp[cy * hm + x];
+    }
+    wts[cell] = acc * norm;
+  }
+  __syncthreads();
+  if (wave == 0) {   // ordered compaction of the non-zero cells
+    int n = 0;
+    for (int c0 = 0; c0 < g * g; c0 += 64) {
+      const int cell = c0 + lane;
+      const bool nz = cell < g * g && wts[cell] != 0.f;
+      const unsigned long long m = __ballot(nz);
+      if (nz) nzi[n + __popcll(m & ((1ull << lane) - 1ull))] = cell;
+      n += __popcll(m);
+    }
+    if (lane == 0) ((int*)red)[4] = n;
+  }
+  __syncthreads();
+  const int nnz = ((const int*)red)[4];
+  const float* Fb = F + (long)b * g * g * C;
+  for (int c = tid; c < C; c += 256) {
+    float acc = 0.f;
+    int i = 0;
+    for (; i + 4 <= nnz; i += 4) {   // four rows in flight; summation order stays i ascending
+      const int c0 = nzi[i], c1 = nzi[i + 1], c2 = nzi[i + 2], c3 = nzi[i + 3];
+      const float f0 = Fb[(long)c0 * C + c], f1 = Fb[(long)c1 * C + c], f2 = Fb[(long)c2 * C + c], f3 = Fb[(long)c3 * C + c];
+      acc = fmaf(wts[c0], f0, acc);
+      acc = fmaf(wts[c1], f1, acc);
+      acc = fmaf(wts[c2], f2, acc);
+      acc = fmaf(wts[c3], f3, acc);
+    }
+    for (; i < nnz; ++i) acc = fmaf(wts[nzi[i]], Fb[(long)nzi[i] * C + c], acc);
+    out[c] = beta != 0.f ? beta * out[c] + acc : acc;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // adj_mx_from_edges + normalize_adj + (gt_adj > 0) + soft_normalize_adj  (skeleton.py:171-205,72,91)
 // one block per sample
@@ -707,6 +809,15 @@ int pool_weights(const float* target, const float* mask_s, float inv_shots, floa
   const size_t lds = (size_t)(hm * hm + g * hm + 4) * sizeof(float);
   EC_REQUIRE(lds <= 64 * 1024, -1, "pool_weights: heatmap too large for LDS");
   hipLaunchKernelGGL(pool_weights_kernel, dim3(bs * K), dim3(256), lds, st, target, mask_s, inv_shots, Wp, K, hm, g);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int pool_gather(const float* target, const float* mask_s, float inv_shots, const float* F, float* pooled, float beta, int bs, int K,
+                int hm, int g, int C, hipStream_t st) {
+  const size_t lds = (size_t)(hm * hm + g * hm + g * g + hm) * sizeof(float) + (size_t)(2 * hm + g * g) * sizeof(int) + 8 * sizeof(float);
+  EC_REQUIRE(lds <= 64 * 1024, -1, "pool_gather: heatmap too large for LDS");
+  hipLaunchKernelGGL(pool_gather_kernel, dim3(bs * K), dim3(256), lds, st, target, mask_s, inv_shots, F, pooled, beta, K, hm, g, C);
   EC_LAUNCH_CHECK();
   return 0;
 }
