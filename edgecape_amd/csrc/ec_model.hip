@@ -678,9 +678,13 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
       if (i + 2 < nsk) RUN(image_update_q(m, m->skel[i + 1], m->s_mem, nb, m->s_qimg, s2));
     }
   }
-  RUN(mean_over(m->kp_ref, m->s_x, (long)Mk * d, S, (long)Mk * d, st));
-  m->taps["skel_kp_refined"] = {m->kp_ref, (long)Mk * d};
-  RUN(rownorm(m->kp_ref, m->kn, Mk, d, st));
+  const float* kp_ref = m->s_x;              // mean over the shots (skeleton.py:114); one shot: the tokens themselves
+  if (S > 1) {
+    RUN(mean_over(m->kp_ref, m->s_x, (long)Mk * d, S, (long)Mk * d, st));
+    kp_ref = m->kp_ref;
+  }
+  m->taps["skel_kp_refined"] = {kp_ref, (long)Mk * d};
+  RUN(rownorm(kp_ref, m->kn, Mk, d, st));
   {
     BgemmP p;
     p.A = m->kn; p.lda = d; p.sA = (long)K * d;
@@ -700,11 +704,30 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
     };
     float* A1 = attn_adj + hop;
     if (hops1 > 2) RUN(mm(A1, A1, attn_adj + 2 * hop));
-    if (hops1 > 3) RUN(mm(attn_adj + 2 * hop, A1, attn_adj + 3 * hop));
-    if (hops1 > 4) RUN(mm(attn_adj + 2 * hop, attn_adj + 2 * hop, attn_adj + 4 * hop));
+    if (hops1 > 4) {   // A^3 = A^2 A and A^4 = A^2 A^2 in ONE launch: batch z < bs -> (A^2[z], A[z]) -> hop 3, z >= bs -> (A^2, A^2) -> hop 4
+      BgemmP p;        // (hops 1,2 and hops 3,4 are adjacent in the stack, so B and C are plain strided batches of 2*bs)
+      p.A = attn_adj + 2 * hop; p.lda = K; p.sA = KK; p.modA = bs;
+      p.B = A1; p.ldb = K; p.sB = KK; p.transB = 0;
+      p.C = attn_adj + 3 * hop; p.ldc = K; p.sC = KK; p.M = K; p.N = K; p.K = K; p.batch = 2 * bs;
+      RUN(bgemm_small(p, st));
+    } else if (hops1 > 3) {
+      RUN(mm(attn_adj + 2 * hop, A1, attn_adj + 3 * hop));
+    }
     EC_REQUIRE(hops1 <= 5, EC_ERR_ARG, "max_hops > 4 not supported");
   }
-  if (ss.dec_bias)   // Markov-bias MLP of every decoder layer: depends on attn_adj only, so it rides with the support side
+  bool bias_done = false;
+  if (ss.dec_bias) {   // all decoder layers' Markov-bias MLPs in one launch when the fused shape applies
+    const float *w1[4], *b1[4], *w2[4], *b2[4];
+    const int nl = (int)m->dec.size();
+    if (nl <= 4) {
+      for (int li = 0; li < nl; ++li) { w1[li] = m->dec[li].m_w1; b1[li] = m->dec[li].m_b1; w2[li] = m->dec[li].m_w2; b2[li] = m->dec[li].m_b2; }
+      const int rc = bias_mlp_layers(attn_adj, w1, b1, w2, b2, nl, ss.dec_bias, (long)bs * m->cfg.nhead * K * K, hops1,
+                                     m->cfg.max_hops + m->cfg.nhead, m->cfg.nhead, bs, K, st);
+      if (rc < 0) return rc;
+      bias_done = rc == 1;
+    }
+  }
+  if (ss.dec_bias && !bias_done)   // Markov-bias MLP of every decoder layer: depends on attn_adj only, so it rides with the support side
     for (size_t li = 0; li < m->dec.size(); ++li) {
       const DecLayer& Ld = m->dec[li];
       RUN(bias_mlp(attn_adj, Ld.m_w1, Ld.m_b1, Ld.m_w2, Ld.m_b2, ss.dec_bias + li * (size_t)bs * m->cfg.nhead * K * K, hops1,

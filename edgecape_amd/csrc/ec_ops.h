@@ -69,6 +69,8 @@ int adj_combine(const float* P, const float* binary, const float* valid, const f
                 float* adj_out, float* adj1, float* attn_adj, int bs, int K, hipStream_t st);
 int set_identity(float* dst, int bs, int K, hipStream_t st);
 // bias_attn.py:188-191 — MLP(hops+1 -> hops+nhead -> nhead) over the Markov stack
+int bias_mlp_layers(const float* attn_adj, const float* const* w1, const float* const* b1, const float* const* w2, const float* const* b2,
+                    int n_layers, float* out, long out_stride, int hops1, int hidden, int nhead, int bs, int K, hipStream_t st);
 int bias_mlp(const float* attn_adj, const float* w1, const float* b1, const float* w2, const float* b2, float* out,
              int hops1, int hidden, int nhead, int bs, int K, hipStream_t st);
 // encoder_decoder.py:76-112 — softmax, soft-argmax, argmax 3x3 window local soft-argmax

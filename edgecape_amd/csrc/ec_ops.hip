@@ -465,10 +465,15 @@ __global__ __launch_bounds__(256) void adj_combine_kernel(const float* P, const 
 }
 
 // compile-time sizes (the shipped configuration: max_hops + 1 = 5 -> 12 -> 8 heads): everything stays in registers
+struct BiasMlpLayers {   // weights of up to 4 decoder layers' Markov-bias MLPs; layer = blockIdx.y, outputs `stride` floats apart
+  const float* w1[4]; const float* b1[4]; const float* w2[4]; const float* b2[4];
+  long stride;
+};
 template <int H1, int HID, int NH>
-__global__ __launch_bounds__(256) void bias_mlp_fixed_kernel(const float* attn_adj, const float* w1, const float* b1, const float* w2,
-                                                              const float* b2, float* out, int bs, int K) {
+__global__ __launch_bounds__(256) void bias_mlp_fixed_kernel(const float* attn_adj, BiasMlpLayers L, float* out, int bs, int K) {
   __shared__ float sw1[HID * H1], sb1[HID], sw2[NH * HID], sb2[NH];
+  const float *w1 = L.w1[blockIdx.y], *b1 = L.b1[blockIdx.y], *w2 = L.w2[blockIdx.y], *b2 = L.b2[blockIdx.y];
+  out += (long)blockIdx.y * L.stride;
   for (int i = threadIdx.x; i < HID * H1; i += 256) sw1[i] = w1[i];
   for (int i = threadIdx.x; i < HID; i += 256) sb1[i] = b1[i];
   for (int i = threadIdx.x; i < NH * HID; i += 256) sw2[i] = w2[i];
@@ -855,8 +860,9 @@ int bias_mlp(const float* attn_adj, const float* w1, const float* b1, const floa
              int hidden, int nhead, int bs, int K, hipStream_t st) {
   EC_REQUIRE(hops1 <= 8 && hidden <= 16, -1, "bias_mlp: unsupported MLP size");
   if (hops1 == 5 && hidden == 12 && nhead == 8) {
-    hipLaunchKernelGGL((bias_mlp_fixed_kernel<5, 12, 8>), dim3(cdiv((long)bs * K * K, 256)), dim3(256), 0, st, attn_adj, w1, b1, w2, b2,
-                       out, bs, K);
+    BiasMlpLayers L = {};
+    L.w1[0] = w1; L.b1[0] = b1; L.w2[0] = w2; L.b2[0] = b2;
+    hipLaunchKernelGGL((bias_mlp_fixed_kernel<5, 12, 8>), dim3(cdiv((long)bs * K * K, 256), 1), dim3(256), 0, st, attn_adj, L, out, bs, K);
     EC_LAUNCH_CHECK();
     return 0;
   }
@@ -865,6 +871,19 @@ int bias_mlp(const float* attn_adj, const float* w1, const float* b1, const floa
                      hidden, nhead, bs, K);
   EC_LAUNCH_CHECK();
   return 0;
+}
+
+// All decoder layers' bias MLPs in one launch (they read the same Markov stack); returns 0 if the shape has no fused kernel.
+int bias_mlp_layers(const float* attn_adj, const float* const* w1, const float* const* b1, const float* const* w2, const float* const* b2,
+                    int n_layers, float* out, long out_stride, int hops1, int hidden, int nhead, int bs, int K, hipStream_t st) {
+  if (!(hops1 == 5 && hidden == 12 && nhead == 8) || n_layers < 1 || n_layers > 4) return 0;
+  BiasMlpLayers L = {};
+  for (int i = 0; i < n_layers; ++i) { L.w1[i] = w1[i]; L.b1[i] = b1[i]; L.w2[i] = w2[i]; L.b2[i] = b2[i]; }
+  L.stride = out_stride;
+  hipLaunchKernelGGL((bias_mlp_fixed_kernel<5, 12, 8>), dim3(cdiv((long)bs * K * K, 256), n_layers), dim3(256), 0, st, attn_adj, L, out, bs,
+                     K);
+  EC_LAUNCH_CHECK();
+  return 1;
 }
 
 int proposals(const float* sim, float* prop_loss, float* prop, int rows, int g, hipStream_t st) {
