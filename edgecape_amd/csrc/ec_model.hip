@@ -470,6 +470,7 @@ struct LayerIO {
   // previous layer's x), the cross-attention waits for wait_ca[] (query positional half of x / pre-projected K|V)
   hipEvent_t wait_x = nullptr;
   hipEvent_t wait_ca[2] = {nullptr, nullptr};
+  hipEvent_t wait_kv = nullptr;   // pre-projected K|V ready: waited for AFTER the query projection, right before the cross attention
 };
 
 // K|V of the image tokens for a layer's token->image cross attention, one batch entry per sample (mem may be a strided view):
@@ -539,6 +540,7 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
       RUN(project_image_kv(m, L, io.mem, io.s_mem, io.nb, kv, st));
       kvp = kv; ldkv = 2 * E;
     }
+    if (io.wait_kv) EC_HIP(hipStreamWaitEvent(st, io.wait_kv, 0));
     AttnP a;
     a.Q = qc; a.K = kvp; a.V = kvp + E; a.O = att;
     a.ldq = E; a.ldk = a.ldv = ldkv; a.ldo = E;
@@ -661,7 +663,7 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
     io.kv_pre = m->s_kv; io.ld_kv_pre = 2 * m->E;
     if (ov2) {
       io.wait_x = i > 0 ? ev_xr : nullptr;
-      io.wait_ca[0] = ev_kv;
+      io.wait_kv = ev_kv;
     }
     RUN(run_dec_layer(m, m->skel[i], io, false, true, m->s_qkv, m->s_att, m->s_tmp, m->s_qc, m->s_kv, m->s_y, m->s_z, m->s_qimg,
                       m->s_kvk, m->s_attimg, m->s_tmpimg, Fs, st));
@@ -874,7 +876,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     if (ovd) {
       io.wait_x = li > 0 ? ev_x : nullptr;
       io.wait_ca[0] = ev_qpe;
-      io.wait_ca[1] = li == 0 ? ev_kv : nullptr;
+      io.wait_kv = li == 0 ? ev_kv : nullptr;
     }
     RUN(run_dec_layer(m, Ld, io, true, false, m->d_qkv, m->d_att, m->d_tmp, m->d_qc, m->d_kv, m->d_y, m->d_z, nullptr, nullptr,
                       nullptr, nullptr, Fd, st));
