@@ -123,7 +123,7 @@ struct ec_model {
   float *s_mem, *s_x, *s_tmp, *s_qkv, *s_att, *s_qc, *s_kv, *s_y, *s_z, *s_qimg, *s_kvk, *s_attimg, *s_tmpimg;
   float *e_x, *e_qkv, *e_att, *e_tmp, *e_h;
   float *p_fs, *p_fq, *p_g1, *p_fs2, *prop;
-  float *d_qin, *d_sc, *d_rp, *d_bias, *d_bias_all, *d_qkv, *d_att, *d_tmp, *d_qc, *d_kv, *d_y, *d_z, *d_hs, *d_pts, *d_k1, *d_k2, *d_hn;
+  float *d_qin, *d_sc, *d_rp, *d_bias, *d_bias_all, *d_qkv, *d_att, *d_tmp, *d_qc, *d_kv, *d_y, *d_z, *d_hs, *d_pts, *d_k1, *d_k2, *d_k3, *d_k4, *d_hn;
   float *o_sim, *o_adj, *o_init, *o_out;
 };
 
@@ -573,12 +573,13 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
 }
 
 static int kpt_mlp(ec_model* m, const KptBranch& kb, const float* x, long ldx, int rows, const float* prev, float* out,
-                   hipStream_t st) {
+                   hipStream_t st, float* t1 = nullptr, float* t2 = nullptr) {
   const int d = m->d;
-  RUN(linear(x, ldx, false, kb.l0, m->d_k1, d, false, rows, ACT_GELU, st));
-  RUN(linear(m->d_k1, d, false, kb.l2, m->d_k2, d, false, rows, ACT_GELU, st));
-  RUN(linear(m->d_k2, d, false, kb.l4, m->d_k1, d, false, rows, ACT_GELU, st));
-  return kpt_out(m->d_k1, d, kb.w6, kb.b6, prev, out, rows, d, st);
+  if (!t1) { t1 = m->d_k1; t2 = m->d_k2; }   // scratch pair; a second pair lets two branches run on two streams
+  RUN(linear(x, ldx, false, kb.l0, t1, d, false, rows, ACT_GELU, st));
+  RUN(linear(t1, d, false, kb.l2, t2, d, false, rows, ACT_GELU, st));
+  RUN(linear(t2, d, false, kb.l4, t1, d, false, rows, ACT_GELU, st));
+  return kpt_out(t1, d, kb.w6, kb.b6, prev, out, rows, d, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -885,7 +886,9 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     RUN(fork(ev_fork));
     float* hs = m->d_hs + (long)li * Mk * d;
     float* bnext = pts + (long)(li + 1) * Mk * 2;
-    RUN(ln(m->d_qin, 2 * d, hs, d, false, m->dec_norm, Mk, d, 1e-5f, ax));
+    const bool last_split = ovd && li + 1 == nL;   // after the last layer nothing is left to hide under: the two keypoint
+                                                  // branches (on x and on dec_norm(x)) run side by side on st and ax
+    RUN(ln(m->d_qin, 2 * d, hs, d, false, m->dec_norm, Mk, d, 1e-5f, last_split ? st : ax));
     // b_{l+1} = sigmoid(inverse_sigmoid(b_l) + kpt_branch[l](x))   (un-normed x, :395-402)
     const KptBranch& kb = m->kpt[li];
     RUN(linear(m->d_qin, 2 * d, false, kb.l0, m->d_k1, d, false, Mk, ACT_GELU, ax));
@@ -898,7 +901,8 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
       RUN(mark(ev_qpe));
     }
     // (7) head output of this level (head.py:216-220): kpt_branch[l](hs[l]) on top of out_points[l] = b_l
-    RUN(kpt_mlp(m, kb, hs, d, Mk, bi, out->output_kpts_dev + (long)li * Mk * 2, ax));
+    if (last_split) RUN(kpt_mlp(m, kb, hs, d, Mk, bi, out->output_kpts_dev + (long)li * Mk * 2, st, m->d_k3, m->d_k4));
+    else RUN(kpt_mlp(m, kb, hs, d, Mk, bi, out->output_kpts_dev + (long)li * Mk * 2, ax));
   }
   RUN(tl_mark(m, "A.end", ax));
   if (ovd) {
@@ -1176,7 +1180,7 @@ int ec_finalize(ec_handle m) {
   WS(p_fs, Mk * d); WS(p_fq, Mi * d); WS(p_g1, Mk * 128); WS(p_fs2, Mk * d);
   WS(d_qin, Mk * 2 * d); WS(d_sc, Mk * d); WS(d_rp, Mk * d); WS(d_bias, (size_t)bs * m->cfg.nhead * KK); WS(d_bias_all, (size_t)m->cfg.dec_layers * bs * m->cfg.nhead * KK); WS(d_qkv, Mk * 3 * d);
   WS(d_att, Mk * E); WS(d_tmp, Mk * d); WS(d_qc, Mk * E); WS(d_kv, Mi * 2 * E * m->cfg.dec_layers); WS(d_y, Mk * 2 * Fd); WS(d_z, Mk * Fd);
-  WS(d_hs, 3 * Mk * d); WS(d_pts, 4 * Mk * 2); WS(d_k1, Mk * d); WS(d_k2, Mk * d);
+  WS(d_hs, 3 * Mk * d); WS(d_pts, 4 * Mk * 2); WS(d_k1, Mk * d); WS(d_k2, Mk * d); WS(d_k3, Mk * d); WS(d_k4, Mk * d);
 #undef WS
   EC_REQUIRE(m->pg_dyn0.N <= 128, EC_ERR_ARG, "dynamic_proj_dim must be <= 128");
   {
