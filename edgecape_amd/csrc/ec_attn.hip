@@ -250,14 +250,21 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
     const bool edge = k0 + 64 > p.Lk;    // only the last tile needs the key-range mask
     f32x16 s[2];
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    {  // all eight K fragments first (one LDS latency instead of eight read -> wait -> MFMA round trips), then the two
+       // accumulator chains interleaved so consecutive MFMAs never depend on each other
+      bf16x8 ka[2][4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int row = t * 32 + j;
+      for (int t = 0; t < 2; ++t) {
+        const int row = t * 32 + j;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const bf16x8 a = *(const bf16x8*)(Kt + row * 128 + (((2 * m + hi) ^ ((row >> 1) & 7)) << 4));
-        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[m], m == 0 ? zero16 : s[t], 0, 0, 0);   // C = inline 0 on the first step
+        for (int m = 0; m < 4; ++m) ka[t][m] = *(const bf16x8*)(Kt + row * 128 + (((2 * m + hi) ^ ((row >> 1) & 7)) << 4));
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[t][m], qf[m], m == 0 ? zero16 : s[t], 0, 0, 0);   // C = inline 0 first
     }
     if (edge) {   // last key tile only (a real branch: the empty asm keeps the compiler from if-converting it into 64 selects)
       asm volatile("" ::: "memory");
