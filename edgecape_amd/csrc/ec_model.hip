@@ -114,7 +114,7 @@ struct ec_model {
 
   // workspace (device)
   int n_img_max = 0;
-  float* bb_x = nullptr; void* bb_xn = nullptr; void* bb_qkv = nullptr; void* bb_att = nullptr; void* bb_h = nullptr; void* bb_y = nullptr;
+  float* bb_x = nullptr; void* bb_xn = nullptr; void* bb_qkv = nullptr; void* bb_att = nullptr; void* bb_h = nullptr; void* bb_y = nullptr; void* bb_y2 = nullptr;
   float* feat = nullptr;      // [n_img_max, HW, C] tokens; query first, then shot s at (1+s)*bs
   float* feat_nchw_tmp = nullptr;
   int32_t *d_edges = nullptr, *d_off = nullptr; int edges_cap = 0;
@@ -372,11 +372,11 @@ static int linear(const void* A, long lda, bool a16, const Lin& W, void* C, long
 }
 
 static int ln(const float* x, long ldx, void* y, long ldy, bool y16, const Norm& n, int rows, int cols, float eps, hipStream_t st,
-              int drop_period = 0, const void* add = nullptr, long ldadd = 0) {
+              int drop_period = 0, const void* add = nullptr, long ldadd = 0, const void* add2 = nullptr, bool write_x = true) {
   LnP p;
   p.x = x; p.ldx = ldx; p.y = y; p.ldy = ldy; p.y_bf16 = y16; p.w = n.w; p.b = n.b; p.rows = rows; p.cols = cols; p.eps = eps;
   p.drop_period = drop_period;
-  p.add = add; p.ldadd = ldadd; p.xsum = add ? const_cast<float*>(x) : nullptr;
+  p.add = add; p.ldadd = ldadd; p.add2 = add2; p.xsum = (add && write_x) ? const_cast<float*>(x) : nullptr;
   return layernorm(p, st);
 }
 
@@ -411,11 +411,13 @@ static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_
   // bf16 mode: the branch GEMMs (proj, fc2) write y = gamma * (acc + bias) as bf16 and the residual add x += y is fused
   // into the FOLLOWING LayerNorm (same HBM bytes, but the fp32 read-modify-write leaves the GEMM epilogue).
   // fp32 mode: the residual is added in the GEMM epilogue (exact fp32 stream).
-  const void* pend = nullptr;   // branch output not yet added to x
+  // The attention branch y1 is NOT written into x by norm2 (it only normalises x + y1): the next norm1 adds both pending
+  // branches, x <- (x + y1) + y2, the same two fp32 additions in the same order.  22 instead of 24 bytes per element and block.
+  const void *pend = nullptr, *pend2 = nullptr;   // branch outputs not yet added to x (attention branch, MLP branch)
   for (size_t i = 0; i < m->blocks.size(); ++i) {
     const BBlock& b = m->blocks[i];
-    RUN(ln(m->bb_x, C, m->bb_xn, C, h16, b.n1, (int)M, C, 1e-6f, st, 0, pend, C));
-    pend = nullptr;
+    RUN(ln(m->bb_x, C, m->bb_xn, C, h16, b.n1, (int)M, C, 1e-6f, st, 0, pend, C, pend2));
+    pend = pend2 = nullptr;
     const bool prof = m->prof_on && m->prof_used + 2 <= m->prof_ev.size();
     if (prof) EC_HIP(hipEventRecord(m->prof_ev[m->prof_used++], st));
     {
@@ -438,10 +440,10 @@ static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_
     RUN(attention(a, st));
     if (h16) {
       RUN(linear(m->bb_att, C, true, b.proj, m->bb_y, C, true, (int)M, ACT_NONE, st, b.ls1, nullptr, 0, nullptr, 0, 1, nullptr, 0, 2));
-      RUN(ln(m->bb_x, C, m->bb_xn, C, true, b.n2, (int)M, C, 1e-6f, st, 0, m->bb_y, C));
+      RUN(ln(m->bb_x, C, m->bb_xn, C, true, b.n2, (int)M, C, 1e-6f, st, 0, m->bb_y, C, nullptr, false));
       RUN(linear(m->bb_xn, C, true, b.fc1, m->bb_h, 4 * C, true, (int)M, ACT_GELU, st, nullptr, nullptr, 0, nullptr, 0, 1, nullptr, 0, 3));
-      RUN(linear(m->bb_h, 4 * C, true, b.fc2, m->bb_y, C, true, (int)M, ACT_NONE, st, b.ls2, nullptr, 0, nullptr, 0, 1, nullptr, 0, 4));
-      pend = m->bb_y;
+      RUN(linear(m->bb_h, 4 * C, true, b.fc2, m->bb_y2, C, true, (int)M, ACT_NONE, st, b.ls2, nullptr, 0, nullptr, 0, 1, nullptr, 0, 4));
+      pend = m->bb_y; pend2 = m->bb_y2;
     } else {
       RUN(linear(m->bb_att, C, false, b.proj, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls1, m->bb_x, C, nullptr, 0, 1, nullptr, 0, 2));
       RUN(ln(m->bb_x, C, m->bb_xn, C, false, b.n2, (int)M, C, 1e-6f, st));
@@ -449,7 +451,7 @@ static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_
       RUN(linear(m->bb_h, 4 * C, false, b.fc2, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls2, m->bb_x, C, nullptr, 0, 1, nullptr, 0, 4));
     }
   }
-  RUN(ln(m->bb_x, C, feat_out ? feat_out : m->feat, C, false, m->bnorm, (int)M, C, 1e-6f, st, T, pend, C));
+  RUN(ln(m->bb_x, C, feat_out ? feat_out : m->feat, C, false, m->bnorm, (int)M, C, 1e-6f, st, T, pend, C, pend2, false));
   return 0;
 }
 
@@ -1162,6 +1164,7 @@ int ec_finalize(ec_handle m) {
   if ((rc = dmalloc(m, &m->bb_qkv, MT * 3 * C * es))) return rc;
   if ((rc = dmalloc(m, &m->bb_att, MT * C * es))) return rc;
   if (m->bb16 && (rc = dmalloc(m, &m->bb_y, MT * C * 2))) return rc;
+  if (m->bb16 && (rc = dmalloc(m, &m->bb_y2, MT * C * 2))) return rc;
   if ((rc = dmalloc(m, &m->bb_h, std::max(MT * 4 * C, MT * m->Kp) * es))) return rc;
   if ((rc = dalloc(m, &m->feat, (size_t)n * HW * C))) return rc;
   if ((rc = dalloc(m, &m->feat_nchw_tmp, (size_t)n * HW * C))) return rc;

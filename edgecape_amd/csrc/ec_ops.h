@@ -17,7 +17,8 @@ struct LnP {
   // optional fused residual add (bf16 backbone): x' = x + add (bf16 [rows, ldadd]); x' is written to xsum (may alias x,
   // same stride) and normalised.  Replaces the fp32 residual read-modify-write in the GEMM epilogue.
   const void* add = nullptr; long ldadd = 0;
-  float* xsum = nullptr;
+  const void* add2 = nullptr;   // optional second branch (same stride): x' = (x + add) + add2
+  float* xsum = nullptr;        // null with add set: x' is normalised but not written back
 };
 int layernorm(const LnP& p, hipStream_t st);
 

@@ -34,7 +34,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnP p) {
         const bf16x4 a = *(const bf16x4*)((const bf16_t*)p.add + (long)row * p.ldadd + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[i][e] += bf2f((bf16_t)a[e]);
-        *(f32x4*)(p.xsum + (long)row * p.ldx + c) = v[i];
+        if (p.add2) {   // a second pending branch: x <- (x + add) + add2, the same two fp32 additions as two separate passes
+          const bf16x4 a2 = *(const bf16x4*)((const bf16_t*)p.add2 + (long)row * p.ldadd + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[i][e] += bf2f((bf16_t)a2[e]);
+        }
+        if (p.xsum) *(f32x4*)(p.xsum + (long)row * p.ldx + c) = v[i];   // null: the sum is only normalised, x stays as it was
       }
       s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
@@ -648,7 +653,8 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 int layernorm(const LnP& p, hipStream_t st) {
   EC_REQUIRE(p.cols % 4 == 0 && p.cols <= 1024, -1, "layernorm: cols must be a multiple of 4 and <= 1024");
   EC_REQUIRE(p.ldx % 4 == 0 && p.ldy % 4 == 0, -1, "layernorm: strides must be multiples of 4");
-  EC_REQUIRE(!p.add || (p.xsum && p.ldadd % 4 == 0), -1, "layernorm: fused residual add needs xsum and a 4-aligned stride");
+  EC_REQUIRE(!p.add || p.ldadd % 4 == 0, -1, "layernorm: fused residual add needs a 4-aligned stride");
+  EC_REQUIRE(!p.add2 || p.add, -1, "layernorm: add2 without add");
   const dim3 grid(cdiv(p.rows, 4));
   if (p.add) {
     if (p.y_bf16) hipLaunchKernelGGL((layernorm_kernel<true, true>), grid, dim3(256), 0, st, p);
