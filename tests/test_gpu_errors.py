@@ -71,6 +71,42 @@ def test_single_pair_and_single_keypoint(eng):
     assert np.abs(o["adj"].cpu().numpy() - out_ref["adj"].numpy()).max() < 1e-4
 
 
+def test_sample_with_no_visible_support_keypoint(eng):
+    """One pair whose support keypoints are ALL invisible (target_weight_s = 0 everywhere): the reference un-masks key 0 of
+    such a sample so the softmax over the keypoint tokens stays finite (encoder_decoder.py:359-360, skeleton.py:98-99).
+    Every output of that pair must match the oracle (no 'valid' subset to hide behind) and the other pair must not notice."""
+    from oracle import edgecape_oracle as orc
+    e, sd = eng
+    b, mask, skel = _batch(2, seed=21)
+    b["target_weight_s"][0][0] = 0.0                      # sample 0: nothing visible
+    mask = b["target_weight_s"][0]
+    o = e.forward(b["img_q"], b["img_s"], b["target_s"], mask, skel)
+    torch.cuda.synchronize()
+    res_ref, out_ref = orc.forward_test(sd, b, synth.ARCHS["dinov2_vits14"]["heads"])
+    got, ref = o["output_kpts"].cpu().numpy(), out_ref["output_kpts"].numpy()
+    assert np.isfinite(got).all() and np.isfinite(ref).all()
+    assert np.abs(got[:, 0] - ref[:, 0]).max() < 1e-3                                  # the all-invisible pair, all K slots
+    valid1 = mask[1, :, 0] > 0
+    assert np.abs(got[:, 1][:, valid1] - ref[:, 1][:, valid1]).max() < 1e-3            # its neighbour in the batch
+    assert np.abs(o["adj"].cpu().numpy() - out_ref["adj"].numpy()).max() < 1e-4
+
+
+def test_dense_support_heatmaps(eng):
+    """Support heatmaps that are NOT Gaussian blobs (every pixel positive): the fused pooling kernel then visits all 324 token
+    cells per keypoint instead of the usual ~20 - slower, but it must be the same weighted sum (head.py:175-186)."""
+    from oracle import edgecape_oracle as orc
+    e, sd = eng
+    b, mask, skel = _batch(2, seed=33)
+    rng = np.random.default_rng(0)
+    b["target_s"][0] = (b["target_s"][0] + rng.uniform(0.05, 1.0, b["target_s"][0].shape)).astype(np.float32)
+    o = e.forward(b["img_q"], b["img_s"], b["target_s"], mask, skel)
+    torch.cuda.synchronize()
+    res_ref, out_ref = orc.forward_test(sd, b, synth.ARCHS["dinov2_vits14"]["heads"])
+    valid = mask[:, :, 0] > 0
+    err = np.abs(o["output_kpts"].cpu().numpy() - out_ref["output_kpts"].numpy())[:, valid].max()
+    assert err < 1e-3, err
+
+
 def test_detector_rejects_what_the_reference_rejects():
     from edgecape_amd.detector import EdgeCape
     head = dict(type="TwoStageHead", in_channels=384,
