@@ -1319,7 +1319,9 @@ int ec_support_encode(ec_handle m, ec_support_t c, const float* const* img_s, co
   for (int s = 0; s < S; ++s) fsp[s] = m->feat + s * per;
   RUN(run_backbone(m, img_s, S, n_episodes, m->feat, st));
   c->n = n_episodes; c->S = S;
-  return run_head_support(m, fsp.data(), target_s, mask_s, n_episodes, S, st, c->ss);
+  RUN(tl_mark(m, "support-only", st));
+  RUN(run_head_support(m, fsp.data(), target_s, mask_s, n_episodes, S, st, c->ss));
+  return tl_dump(m);
 }
 
 int ec_forward_cached(ec_handle m, ec_support_t c, const float* img_q, const int32_t* episode_of_query, int bs, void* stream,

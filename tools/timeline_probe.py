@@ -22,3 +22,9 @@ outs = eng._outputs(bs)
 for _ in range(4):
     eng.forward_resident(iq, is_, ts, ms, edges, off, outs)
 torch.cuda.synchronize()
+if os.environ.get("SUPPORT_ONLY"):   # the support lanes alone (episode-cache path): how much does the query lane cost them?
+    skel = [m["sample_skeleton"][0] for m in b["img_metas"]]
+    cache = None
+    for _ in range(3):
+        cache = eng.support_encode(b["img_s"], b["target_s"], b["target_weight_s"][0].reshape(bs, -1), skel, cache)
+    torch.cuda.synchronize()
