@@ -176,6 +176,10 @@ constexpr int A16_LDS = 2 * A16_STAGE;       // double buffered: 32 KiB
 // Negative result kept for the record: a half-size (32-key) instantiation of the tile body for sequence tails <= 32 keys
 // (T = 257 / 325 / 730: tails 1 / 5 / 26, i.e. 1/12 fewer sub-tiles at T = 325) did not change the kernel time (52.0 vs 51.2 us):
 // at six key tiles per workgroup the per-tile wait-stage-barrier chain, not the tail tile's arithmetic, sets the time.
+// And a K/V-RESIDENT form (one 768-thread workgroup per (image, head), all six K/V tiles staged once, no wait or barrier in the
+// key loop): 56.1 vs 50.9 us - slower.  Per tile and wave the SIMD spends ~1450 cycles on VALU (265 instructions, v_exp at 4x)
+// plus 512 on MFMA, and the two do not overlap across the three waves of a SIMD here: the kernel is bound by that sum, not by
+// staging, barriers or load latency.
 // Likewise a 3-stage K/V ring (two tiles ahead, counted vmcnt(4), raw barrier): 54.9 vs 51.4 us - slower; the double buffer stays.
 // __launch_bounds__(256, 2): with a 256-register budget hipcc keeps the MFMA accumulators in VGPRs (no v_accvgpr_read/write
 // copies around the softmax: -90 of ~410 VALU instructions per key tile; the kernel is VALU-bound at 16 MFMAs per tile).
