@@ -180,6 +180,8 @@ constexpr int A16_LDS = 2 * A16_STAGE;       // double buffered: 32 KiB
 // key loop): 56.1 vs 50.9 us - slower.  Per tile and wave the SIMD spends ~1450 cycles on VALU (265 instructions, v_exp at 4x)
 // plus 512 on MFMA, and the two do not overlap across the three waves of a SIMD here: the kernel is bound by that sum, not by
 // staging, barriers or load latency.
+// Occupancy: 3 workgroups per CU (136 VGPRs) is the optimum - 51.2 us; a 128-VGPR build at 4 per CU 55.5, LDS-capped 2 per CU 57.0,
+// 1 per CU 80.1 (so one wave per SIMD already reaches 64 % of the three-wave rate: the waves are busy, not waiting).
 // Likewise a 3-stage K/V ring (two tiles ahead, counted vmcnt(4), raw barrier): 54.9 vs 51.4 us - slower; the double buffer stays.
 // __launch_bounds__(256, 2): with a 256-register budget hipcc keeps the MFMA accumulators in VGPRs (no v_accvgpr_read/write
 // copies around the softmax: -90 of ~410 VALU instructions per key tile; the kernel is VALU-bound at 16 MFMAs per tile).
