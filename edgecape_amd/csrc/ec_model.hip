@@ -473,6 +473,7 @@ struct LayerIO {
   hipEvent_t wait_x = nullptr;
   hipEvent_t wait_ca[2] = {nullptr, nullptr};
   hipEvent_t wait_kv = nullptr;   // pre-projected K|V ready: waited for AFTER the query projection, right before the cross attention
+  hipEvent_t wait_sa = nullptr;   // adjacency / attention bias ready: waited for after the self-attention input projection
 };
 
 // K|V of the image tokens for a layer's token->image cross attention, one batch entry per sample (mem may be a strided view):
@@ -526,6 +527,7 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
     a.bias = io.bias;
     a.B = io.nb; a.H = nh; a.Lq = K; a.Lk = K; a.hd = d / nh;
     a.split = m->head_split ? 1 : 0;   // head throughput mode: bf16x3 MFMAs
+    if (io.wait_sa) EC_HIP(hipStreamWaitEvent(st, io.wait_sa, 0));
     RUN(attention(a, st));
   }
   RUN(linear(att, d, false, L.sa_out, tmp, d, false, Mk, ACT_NONE, st, nullptr, io.x, io.ldx));
@@ -863,7 +865,9 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
   RUN(ref_point_embed(pts));
   RUN(mark(ev_qpe));
   RUN(copy3d(m->d_qin, 2 * d, (long)K * 2 * d, kp, d, s_tok, bs, K, d, st));
-  if (wait_adj) EC_HIP(hipStreamWaitEvent(st, wait_adj, 0));   // adjacency / Markov stack from the support side
+  // adjacency / Markov stack from the support side: first needed by layer 0's self-attention kernel (bias, key mask) - its input
+  // projection runs before the wait.  Without the precomputed bias stack the bias MLP itself reads attn_adj: wait here.
+  if (wait_adj && !ss.dec_bias) EC_HIP(hipStreamWaitEvent(st, wait_adj, 0));
   RUN(tl_mark(m, "Q.adjwait", st));
   for (int li = 0; li < nL; ++li) {
     const DecLayer& Ld = m->dec[li];
@@ -876,6 +880,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     io.adj1 = ss.adj1; io.valid = ss.valid; io.kmask_fixed = ss.kmask_fixed; io.bias = lbias;
     io.nb = bs; io.bs = bs; io.update_mem = false;
     io.kv_pre = m->d_kv + (long)li * 2 * E; io.ld_kv_pre = (long)nL * 2 * E;
+    if (li == 0 && ss.dec_bias) io.wait_sa = wait_adj;
     if (ovd) {
       io.wait_x = li > 0 ? ev_x : nullptr;
       io.wait_ca[0] = ev_qpe;
