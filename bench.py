@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "bf16x3": 2500.0 / 3, "fp32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks
 
 
 def parse():
@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--shots", type=int, default=1)
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--arch", default="dinov2_vitb14")
-    ap.add_argument("--precision", default=os.environ.get("EC_BENCH_PRECISION", "bf16"), choices=["bf16", "fp32"],
+    ap.add_argument("--precision", default=os.environ.get("EC_BENCH_PRECISION", "bf16"), choices=["bf16", "fp16", "bf16x3", "fp32"],
                     help="backbone MFMA operand type (fp32 accumulate)")
     ap.add_argument("--head-precision", default=os.environ.get("EC_BENCH_HEAD_PRECISION", "bf16x3"), choices=["fp32", "bf16x3"],
                     help="head GEMMs: exact fp32 MFMA, or split-bf16 (hi+lo, 3 MFMAs per product; fp32-class accuracy)")
@@ -148,7 +148,7 @@ def main():
             "metric": "query images/sec (1-shot, 256x256, DINOv2 ViT-B/14 + EdgeCape head, forward_test)",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"bf16": "bf16", "fp16": "f16", "bf16x3": "bf16x3", "fp32": "f32"}[args.precision], "data": "synthetic",
             "config": {"workload": f"{S}-shot split1-style synthetic pairs, batch={bs}/GPU, {H}x{H}, {arch}, K=100 padded keypoints, "
                                    f"backbone {args.precision} MFMA / fp32 accumulate, head {args.head_precision}",
                        "global_batch": world * bs, "parallelism": f"dp{world} (independent pair shards, one all-reduce of PCK counters)"},

@@ -13,13 +13,14 @@ from . import build as _build
 
 _LIB = None
 
-EC_F32, EC_BF16, EC_BF16X3 = 0, 1, 2
+EC_F32, EC_BF16, EC_BF16X3, EC_F16 = 0, 1, 2, 3
+EC_ABI_VERSION = 2   # include/edgecape_hip.h EC_ABI_VERSION: bumped whenever a struct layout or a signature changes
 EC_DT_F32, EC_DT_F16, EC_DT_BF16, EC_DT_F64 = 0, 1, 2, 3
 EC_LAYOUT_TOKENS, EC_LAYOUT_NCHW = 0, 1
 
 EXPORTS = ["ec_last_error", "ec_version", "ec_create", "ec_destroy", "ec_load_tensor", "ec_set_pos_embed", "ec_finalize",
            "ec_backbone", "ec_head", "ec_forward", "ec_support_create", "ec_support_destroy", "ec_support_encode", "ec_forward_cached", "ec_preprocess_images", "ec_msra_targets", "ec_debug_read", "ec_profile", "ec_profile_read", "ec_op_linear", "ec_op_gemm_bench", "ec_op_bgemm", "ec_op_layernorm",
-           "ec_op_attention"]
+           "ec_op_attention", "ec_abi_sizes"]
 
 
 class EcConfig(C.Structure):
@@ -52,10 +53,26 @@ def load():
         raise EdgeCapeHipError(
             f"{path} not found: build it with `python -m edgecape_amd.build` (needs hipcc). "
             "The EdgeCape hot path has no CPU/PyTorch fallback.")
+    if _build.needs_build():
+        # a prebuilt library from other sources would be called with mismatched struct layouts: rebuild where hipcc exists
+        # (build container, GPU box), refuse otherwise
+        try:
+            _build.build(verbose=False)
+        except Exception as e:  # noqa: BLE001
+            raise EdgeCapeHipError(f"{path} is stale (sources changed since it was built) and could not be rebuilt: {e}") from e
     lib = C.CDLL(path)
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     lib.ec_last_error.restype = C.c_char_p
     lib.ec_version.restype = ci
+    if lib.ec_version() != EC_ABI_VERSION:
+        raise EdgeCapeHipError(f"{path}: ABI version {lib.ec_version()} != binding version {EC_ABI_VERSION}")
+    lib.ec_abi_sizes.argtypes = [C.POINTER(ci), C.POINTER(ci)]
+    lib.ec_abi_sizes.restype = ci
+    sc, so = ci(), ci()
+    lib.ec_abi_sizes(C.byref(sc), C.byref(so))
+    if (sc.value, so.value) != (C.sizeof(EcConfig), C.sizeof(EcOutputs)):
+        raise EdgeCapeHipError(f"{path}: struct sizes {sc.value}/{so.value} differ from the ctypes mirrors "
+                               f"{C.sizeof(EcConfig)}/{C.sizeof(EcOutputs)}")
     lib.ec_create.argtypes = [C.POINTER(EcConfig), C.POINTER(vp)]
     lib.ec_destroy.argtypes = [vp]
     lib.ec_load_tensor.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), ci, ci]
@@ -79,7 +96,7 @@ def load():
     lib.ec_op_layernorm.argtypes = [vp, vp, vp, vp, ci, ci, cf, vp]
     lib.ec_op_attention.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     for n in EXPORTS:
-        if n not in ("ec_last_error", "ec_version"):
+        if n not in ("ec_last_error", "ec_version", "ec_abi_sizes"):
             getattr(lib, n).restype = ci
     _LIB = lib
     return lib

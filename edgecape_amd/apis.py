@@ -1,80 +1,210 @@
-"""Evaluation loops with the reference's contract (EdgeCape/apis/test.py).
+"""Evaluation loops with the reference's contract (EdgeCape/apis/test.py) and the one-process-per-GPU plumbing around them.
 
-`single_gpu_test` mirrors apis/test.py:14-47 (per-sample split of the batch result).  `multi_gpu_test`
-replaces the reference's pickled-results all_gather (apis/test.py:154-198) by ONE fixed-size
-all_gather of float32 predictions over RCCL (backend "nccl" on ROCm) — pairs are independent, nothing
-else crosses GPUs.  Works with gloo on CPU tensors as well (used by the CPU tests).
+`single_gpu_test`   apis/test.py:14-47: run the loader, split every batch result into per-sample result dicts.
+`multi_gpu_test`    apis/test.py:50-91 + collect_results_gpu (:154-198): every rank runs its shard, rank 0 gets the per-sample
+                    result dicts of the whole dataset in dataset order (sampler padding truncated), other ranks get None.
+                    The reference pickles python objects and all_gathers the bytes; here every sample is ONE fixed-size
+                    byte record (preds [K,3] f32 | box [6] f32 | bbox_id i64 | path) and the exchange is one all_gather of a
+                    [n, record] uint8 tensor - RCCL over xGMI with backend "nccl", the same code on CPU tensors with gloo.
+`init_distributed / timed_steps / allreduce_counts / max_over_ranks`
+                    the rank / barrier / timing / counter-reduction helpers `bench.py` runs on the GPUs; the world-size-2 gloo
+                    tests (tests/test_dist_gloo.py) call exactly these functions.
+Pairs are independent: nothing but results and PCK counters ever crosses GPUs.
 """
+import os
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
 
-
-def _batch_size(data):
-    return len(next(iter(data.values()))[0])
+PATH_BYTES = 254   # fixed path field of a result record (longer paths are an error, never silently cut)
 
 
-def single_gpu_test(model, data_loader):
-    model.eval()
-    results = []
-    for data in data_loader:
-        result = model(return_loss=False, **data)
-        batch_size = _batch_size(data)
-        if "preds" in result:
-            for i in range(batch_size):
-                results.append({
-                    "preds": result["preds"][i][None],
-                    "boxes": result["boxes"][i][None],
-                    "bbox_ids": [result["bbox_ids"][i]],
-                    "image_paths": [result["image_paths"][i]],
-                })
-    return results
+# ---- process group --------------------------------------------------------------------------------------------------
+def dist_on():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
-def shard_indices(n_total, rank, world_size):
-    """DistributedSampler(shuffle=False) semantics: pad to equal length, rank r takes r, r+W, ..."""
-    per = (n_total + world_size - 1) // world_size
-    idx = list(range(n_total))
-    pad = per * world_size - n_total
-    if pad > 0 and n_total > 0:
-        idx += (idx * ((pad + n_total - 1) // n_total))[:pad]   # wraps more than once when n_total < world_size
-    return idx[rank::world_size]
+def rank_world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
 
 
-def gather_predictions(local_preds, n_total, device=None):
-    """all_gather of [n_local, K, 3] float32 predictions; returns [n_total, K, 3] in dataset order
-    (interleave by rank, truncate the sampler padding — apis/test.py:187-196)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return np.asarray(local_preds)[:n_total]
-    W = dist.get_world_size()
-    t = torch.as_tensor(np.ascontiguousarray(local_preds), dtype=torch.float32)
-    if device is None:
-        device = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    t = t.to(device)
-    parts = [torch.empty_like(t) for _ in range(W)]
-    dist.all_gather(parts, t)
-    stacked = torch.stack(parts, 1).reshape(-1, *t.shape[1:])   # index i*W + r  <-  rank r, local i
-    return stacked[:n_total].cpu().numpy()
+def comm_device(device=None):
+    if device is not None:
+        return torch.device(device)
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
 
 
-def multi_gpu_test(model, data_loader, n_total=None, gpu_collect=True):
-    """Each rank runs its shard (data_loader yields only its pairs); rank-ordered results are gathered."""
-    local = single_gpu_test(model, data_loader)
-    if not local:
-        preds = np.zeros((0, 1, 3), np.float32)
-    else:
-        preds = np.concatenate([r["preds"] for r in local], 0)
-    if n_total is None:
-        n_total = len(local) * (dist.get_world_size() if dist.is_initialized() else 1)
-    return gather_predictions(preds, n_total)
+def init_distributed(backend=None):
+    """One process per GPU, launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment).
+    backend None -> "nccl" (= RCCL on ROCm) when a GPU is visible, else "gloo".  Returns (rank, world, local_rank)."""
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = dict(device_id=torch.device("cuda", local_rank)) if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local_rank
+
+
+def finalize_distributed():
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def _device_sync():
+    if torch.cuda.is_available() and (not dist.is_initialized() or dist.get_backend() == "nccl"):
+        torch.cuda.synchronize()
+
+
+def barrier():
+    """Rendezvous of all ranks with the local device drained on both sides."""
+    _device_sync()
+    if dist_on():
+        dist.barrier()
+    _device_sync()
+
+
+def max_over_ranks(value):
+    if not dist_on():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=comm_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def allreduce_counts(counts, device=None):
-    """Sum a small float64 vector (PCK hit/count) over ranks."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return np.asarray(counts, np.float64)
-    if device is None:
-        device = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    t = torch.as_tensor(np.asarray(counts, np.float64)).to(device)
+    """Sum a small float64 vector (the PCK hit / pair counters of evaluation.pck_counts) over the ranks."""
+    c = np.asarray(counts, np.float64)
+    if not dist_on():
+        return c
+    t = torch.from_numpy(c.copy()).to(comm_device(device))
     dist.all_reduce(t)
     return t.cpu().numpy()
+
+
+def timed_steps(step, steps, warmup, collective=None):
+    """bench.py's timed region: `warmup` untimed steps, then EXACTLY `steps` steps between two barriers (device drained on both
+    sides); `collective` (the job's only cross-rank exchange) runs inside the region; returns the MAX over ranks of the wall time."""
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    if collective is not None:
+        collective()
+    barrier()
+    return max_over_ranks(time.perf_counter() - t0)
+
+
+# ---- sharding -------------------------------------------------------------------------------------------------------
+def shard_indices(n_total, rank, world_size):
+    """DistributedSampler(shuffle=False) semantics: pad to equal length by wrapping around, rank r takes r, r+W, ..."""
+    per = -(-n_total // world_size)
+    idx = list(range(n_total))
+    pad = per * world_size - n_total
+    if pad > 0 and n_total > 0:
+        idx += (idx * (-(-pad // n_total)))[:pad]   # wraps more than once when n_total < world_size
+    return idx[rank::world_size]
+
+
+# ---- evaluation loops -----------------------------------------------------------------------------------------------
+def _per_sample(result):
+    """Split one batch result of `model(return_loss=False, ...)` into the reference's per-sample result dicts."""
+    if "preds" not in result:
+        return
+    preds, boxes = np.asarray(result["preds"]), np.asarray(result["boxes"])
+    for i, (bid, path) in enumerate(zip(result["bbox_ids"], result["image_paths"])):
+        yield {"preds": preds[i:i + 1], "boxes": boxes[i:i + 1], "bbox_ids": [bid], "image_paths": [path]}
+
+
+def single_gpu_test(model, data_loader):
+    """apis/test.py:14-47.  Returns the list of per-sample result dicts in loader order."""
+    model.eval()
+    out = []
+    for data in data_loader:
+        out.extend(_per_sample(model(return_loss=False, **data)))
+    return out
+
+
+def _pack(results, n_rows, K):
+    """per-sample result dicts -> uint8 [n_rows, record]; rows past len(results) are marked invalid."""
+    rec = 1 + K * 12 + 24 + 8 + 2 + PATH_BYTES
+    buf = np.zeros((n_rows, rec), np.uint8)
+    for i, r in enumerate(results):
+        p = np.ascontiguousarray(r["preds"], np.float32).reshape(-1)
+        if p.size != K * 3:
+            raise ValueError(f"result {i}: {p.size // 3} keypoints, expected {K} on every rank")
+        path = str(r["image_paths"][0]).encode()
+        if len(path) > PATH_BYTES:
+            raise ValueError(f"image path longer than {PATH_BYTES} bytes: {path[:40]!r}...")
+        row, o = buf[i], 1
+        row[0] = 1
+        row[o:o + K * 12] = p.view(np.uint8); o += K * 12
+        row[o:o + 24] = np.ascontiguousarray(r["boxes"], np.float32).reshape(6).view(np.uint8); o += 24
+        row[o:o + 8] = np.array([int(r["bbox_ids"][0])], np.int64).view(np.uint8); o += 8
+        row[o:o + 2] = np.array([len(path)], np.uint16).view(np.uint8); o += 2
+        row[o:o + len(path)] = np.frombuffer(path, np.uint8)
+    return buf
+
+
+def _unpack(row, K):
+    o = 1
+    preds = row[o:o + K * 12].copy().view(np.float32).reshape(1, K, 3); o += K * 12
+    boxes = row[o:o + 24].copy().view(np.float32).reshape(1, 6); o += 24
+    bid = int(row[o:o + 8].copy().view(np.int64)[0]); o += 8
+    n = int(row[o:o + 2].copy().view(np.uint16)[0]); o += 2
+    return {"preds": preds, "boxes": boxes, "bbox_ids": [bid], "image_paths": [bytes(row[o:o + n]).decode()]}
+
+
+def collect_results(local_results, size, device=None, all_ranks=False):
+    """collect_results_gpu (apis/test.py:154-198) on fixed-size records.  `local_results`: this rank's per-sample dicts in its
+    shard order (rank r holds dataset items r, r+W, ...); `size` = len(dataset).  Rank 0 (every rank with all_ranks=True) gets
+    the `size` result dicts in dataset order, the others None.  Ranks may hold unequal (even zero) numbers of samples."""
+    rank, world = rank_world()
+    if world == 1:
+        return list(local_results)[:size]
+    dev = comm_device(device)
+    K_loc = int(np.asarray(local_results[0]["preds"]).shape[-2]) if local_results else 0
+    meta = torch.tensor([len(local_results), K_loc], dtype=torch.int64, device=dev)
+    dist.all_reduce(meta, op=dist.ReduceOp.MAX)          # rows per rank and K agreed without assuming equal shards
+    n_rows, K = int(meta[0].item()), int(meta[1].item())
+    mine = torch.from_numpy(_pack(local_results, n_rows, K)).to(dev)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    if rank != 0 and not all_ranks:
+        return None
+    rows = torch.stack(parts, 1).reshape(n_rows * world, -1).cpu().numpy()   # row i*W + r  <-  rank r, local i
+    ordered = [_unpack(r, K) for r in rows if r[0]]
+    return ordered[:size]                                 # "the dataloader may pad some samples"
+
+
+def multi_gpu_test(model, data_loader, size=None, tmpdir=None, gpu_collect=True, all_ranks=False):
+    """apis/test.py:50-91.  `data_loader` yields this rank's shard; `size` defaults to len(data_loader.dataset)."""
+    if size is None:
+        ds = getattr(data_loader, "dataset", None)
+        if ds is None:
+            raise ValueError("multi_gpu_test needs `size` (len(dataset)) when the loader has no .dataset")
+        size = len(ds)
+    return collect_results(single_gpu_test(model, data_loader), size, all_ranks=all_ranks)
+
+
+def gather_predictions(local_preds, n_total, device=None):
+    """all_gather of [n_local, K, 3] float32 predictions only; returns [n_total, K, 3] in dataset order on every rank."""
+    local_preds = np.asarray(local_preds, np.float32)
+    if not dist_on():
+        return local_preds[:n_total]
+    res = [{"preds": p[None], "boxes": np.zeros((1, 6), np.float32), "bbox_ids": [0], "image_paths": [""]} for p in local_preds]
+    out = collect_results(res, n_total, device=device, all_ranks=True)
+    return np.concatenate([r["preds"] for r in out], 0) if out else np.zeros((0,) + local_preds.shape[1:], np.float32)

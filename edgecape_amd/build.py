@@ -1,5 +1,6 @@
 """Build libedgecape_hip.so (gfx950) in-tree with hipcc.  `python -m edgecape_amd.build [--force]`."""
 import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -22,12 +23,30 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def deps():
+    return sorted(sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h")))
+
+
+def source_hash():
+    """sha256 over every source / header the library is built from (content, not mtimes: the .so travels to the GPU box in a
+    snapshot whose timestamps mean nothing)."""
+    h = hashlib.sha256()
+    for d in deps():
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+STAMP = LIB + ".srchash"
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    """True when the library is missing or was built from different sources than the ones in the tree."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != source_hash()
 
 
 def build(force=False, verbose=True):
@@ -53,6 +72,8 @@ def build(force=False, verbose=True):
     if r.returncode != 0:
         raise RuntimeError("link failed: " + " ".join(cmd) + "\n" + r.stdout)
     os.replace(LIB + ".tmp", LIB)
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
     if verbose:
         print(f"built {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB)")
     return LIB

@@ -196,7 +196,7 @@ constexpr int A16_LDS = 2 * A16_STAGE;       // double buffered: 32 KiB
       }                                                                                          \
     }                                                                                            \
   } while (0)
-template <bool TRACE>
+template <bool TRACE, bool F16>
 __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[t][m], qf[m], m == 0 ? zero16 : s[t], 0, 0, 0);   // C = inline 0 first
+          s[t] = mfma32x32x16_h<F16>(ka[t][m], qf[m], m == 0 ? zero16 : s[t]);   // C = inline 0 first
     }
     if (edge) {   // last key tile only (a real branch: the empty asm keeps the compiler from if-converting it into 64 selects)
       asm volatile("" ::: "memory");
@@ -329,7 +329,9 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
         f32x8 pv;
 #pragma unroll
         for (int e = 0; e < 8; ++e) pv[e] = s[t][8 * uu + e];
-        const bf16x8 pb = __builtin_bit_cast(bf16x8, __builtin_convertvector(pv, bf16v8));
+        bf16x8 pb;   // P <= 2^8 by the lazy maximum: inside the fp16 range as well
+        if constexpr (F16) pb = __builtin_bit_cast(bf16x8, __builtin_convertvector(pv, f16x8));
+        else pb = __builtin_bit_cast(bf16x8, __builtin_convertvector(pv, bf16v8));
         // V^T fragment by transposing reads: this lane's 16-lane group covers d = 32*dt + 16*G .. +15; lane i of
         // the group points at key row (i>>2) of a 4-key block and d-quad (i&3), and gets the 4 keys of column i.
         const int i16 = lane & 15, G = (lane >> 4) & 1;
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
           bf16x8 av;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { av[e] = lo[e]; av[4 + e] = hi2[e]; }
-          ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pb, ot[d], 0, 0, 0);
+          ot[d] = mfma32x32x16_h<F16>(av, pb, ot[d]);
         }
       }
     }
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
       for (int g = 0; g < 4; ++g) {
         bf16x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (short)f2bf(ot[d][4 * g + e] * inv);
+        for (int e = 0; e < 4; ++e) o[e] = (short)f2h<F16>(ot[d][4 * g + e] * inv);
         *(bf16x4*)(O + (d * 32 + 8 * g + 4 * hi) * 2) = o;
       }
   }
@@ -623,13 +625,13 @@ int attention(const AttnP& p, hipStream_t st) {
     EC_REQUIRE(p.hd == 64 && !p.kmask && !p.bias, -1, "attention(bf16): hd = 64, no mask / bias (backbone only)");
     EC_REQUIRE(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0, -1, "attention(bf16): stride alignment");
     static const bool trace = getenv("EC_ATTN_TRACE") != nullptr;
-    if (trace) {
+    if (trace && !p.f16) {
       unsigned* d_tr = nullptr;
       EC_HIP(hipMalloc((void**)&d_tr, 4 * 128 * sizeof(unsigned)));
       EC_HIP(hipMemsetAsync(d_tr, 0, 4 * 128 * sizeof(unsigned), st));
       AttnP q = p;
       q.bias = (const float*)d_tr;
-      hipLaunchKernelGGL(attn_bf16_kernel<true>, grid, dim3(256), A16_LDS, st, q);
+      hipLaunchKernelGGL((attn_bf16_kernel<true, false>), grid, dim3(256), A16_LDS, st, q);
       EC_LAUNCH_CHECK();
       EC_HIP(hipStreamSynchronize(st));
       unsigned h[4 * 128];
@@ -648,7 +650,8 @@ int attention(const AttnP& p, hipStream_t st) {
       }
       return 0;
     }
-    hipLaunchKernelGGL(attn_bf16_kernel<false>, grid, dim3(256), A16_LDS, st, p);
+    if (p.f16) hipLaunchKernelGGL((attn_bf16_kernel<false, true>), grid, dim3(256), A16_LDS, st, p);
+    else hipLaunchKernelGGL((attn_bf16_kernel<false, false>), grid, dim3(256), A16_LDS, st, p);
     EC_LAUNCH_CHECK();
     return 0;
   }

@@ -11,6 +11,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 
 void set_error(const std::string& s);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
@@ -49,6 +52,67 @@ __host__ __device__ inline bf16_t f2bf(float f) {
 __host__ __device__ inline float bf2f(bf16_t h) {
   union { float f; uint32_t u; } v;
   v.u = ((uint32_t)h) << 16;
+  return v.f;
+}
+
+// ---- 16-bit operand formats of the backbone's throughput modes -------------------------------------------------------------
+// F16 = false: bfloat16 (8 significand bits); F16 = true: IEEE binary16 (11 significand bits, same MFMA rate on gfx950:
+// v_mfma_f32_*_f16 / v_cvt_pk_f16_f32).  Storage is a raw 16-bit pattern (bf16_t) either way; only the conversions and the
+// MFMA opcode differ, so every 16-bit kernel takes the format as a template parameter.
+template <bool F16> __device__ __forceinline__ f32x4 mfma16x16x32_h(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16> __device__ __forceinline__ f32x16 mfma32x32x16_h(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// 4 floats -> 4 packed 16-bit values (round to nearest even): 2 x v_cvt_pk_{bf16,f16}_f32
+template <bool F16> __device__ __forceinline__ u32x2_t pack4_h(f32x4 v) {
+  if constexpr (F16) return __builtin_bit_cast(u32x2_t, __builtin_convertvector(v, f16x4));
+  else {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16v4_;
+    return __builtin_bit_cast(u32x2_t, __builtin_convertvector(v, bf16v4_));
+  }
+}
+template <bool F16> __device__ __forceinline__ bf16_t f2h(float f) {
+  if constexpr (F16) return __builtin_bit_cast(bf16_t, (_Float16)f);
+  else return __builtin_bit_cast(bf16_t, (__bf16)f);
+}
+template <bool F16> __device__ __forceinline__ float h2f(bf16_t h) {
+  if constexpr (F16) return (float)__builtin_bit_cast(_Float16, h);
+  else return __uint_as_float(((uint32_t)h) << 16);
+}
+// host: float -> IEEE binary16 bit pattern, round to nearest even (weights of the fp16 mode are converted once at ec_finalize)
+inline bf16_t f2half_host(float f) {
+  union { float f; uint32_t u; } v;
+  v.f = f;
+  const uint32_t sign = (v.u >> 16) & 0x8000u;
+  const uint32_t a = v.u & 0x7fffffffu;
+  if (a >= 0x7f800000u) return (bf16_t)(sign | 0x7c00u | (a > 0x7f800000u ? 0x200u : 0u));   // inf / NaN
+  if (a >= 0x477ff000u) return (bf16_t)(sign | 0x7c00u);                                        // rounds to >= 65520: inf
+  if (a < 0x33000001u) return (bf16_t)sign;                                                      // < 2^-25 (or == 2^-25: ties to even 0)
+  int e = (int)(a >> 23) - 127;
+  uint32_t m = (a & 0x7fffffu) | 0x800000u;
+  int shift = e < -14 ? (13 + (-14 - e)) : 13;        // subnormal halves lose extra bits
+  uint32_t h = m >> shift;
+  const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+  if (rem > half || (rem == half && (h & 1u))) ++h;
+  if (e < -14) return (bf16_t)(sign | h);             // h may carry into the smallest normal: still the right pattern
+  return (bf16_t)(sign | (uint32_t)(((e + 15) << 10) + (h - 0x400u)));   // mantissa carry propagates into the exponent
+}
+
+inline float half2f_host(bf16_t h) {
+  const uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+  union { float f; uint32_t u; } v;
+  if (e == 0) {
+    v.f = (float)m * 5.9604644775390625e-08f;   // m * 2^-24 (zero and subnormals), exact in fp32
+    v.u |= sign;
+  } else if (e == 31) {
+    v.u = sign | 0x7f800000u | (m << 13);
+  } else {
+    v.u = sign | ((e + 112u) << 23) | (m << 13);
+  }
   return v.f;
 }
 
@@ -97,10 +161,10 @@ struct GemmP {
   int period = 1;
   int act = ACT_NONE;
   int c_bf16 = 0;   // store C as bf16
-  int ab_bf16 = 0;  // A and B are bf16 (else fp32)
+  int ab_bf16 = 0;  // A and B are 16-bit (else fp32)
+  int h_f16 = 0;    // the 16-bit format (operands and, with c_bf16, the output) is IEEE fp16 instead of bf16
   int split = 0;    // bf16x3: A fp32, B pre-split into [32 hi | 32 lo] bf16 per 32-k block (split_pack_weights)
   int tag = 0;      // kernel-symbol tag (profiling only): 1 qkv, 2 proj, 3 fc1, 4 fc2
-  int dbg = 0;      // timing experiments (EC_G8_DBG): bit 0 = skip the C stores
 };
 int gemm_nt(const GemmP& p, hipStream_t st);
 // host: W [N,K] fp32 -> bf16x3 packing of the same byte size: per row, per 32-k block, 32 hi bf16 then 32 lo bf16
@@ -141,7 +205,8 @@ struct AttnP {
   int mask_start = 0, mask_len = 0, mask_mod = 0;
   const float* bias = nullptr;                  // [B, H, Lq, Lk]
   int B = 0, H = 0, Lq = 0, Lk = 0, hd = 0;
-  int bf16 = 0;                                 // Q/K/V/O are bf16
+  int bf16 = 0;                                 // Q/K/V/O are 16-bit
+  int f16 = 0;                                  // ... in IEEE fp16 instead of bf16
   int split = 0;                                // fp32 data, bf16x3 MFMAs (head throughput mode)
 };
 int attention(const AttnP& p, hipStream_t st);

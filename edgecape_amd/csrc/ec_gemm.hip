@@ -71,7 +71,7 @@ __device__ inline float gelu_fast(float x) {
 // the host into the same 128-byte K-blocks ([32 hi | 32 lo] bf16 per 32 k) so staging and addressing are those of fp32;
 // acc += hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate): ~2^-17 relative operand error at 16/3 of the
 // fp32 MFMA rate — the head's throughput mode (the head is 6 % of the FLOPs; keeping it fp32-class keeps the 1e-3 gate).
-enum { GM_F32 = 0, GM_BF16 = 1, GM_SPLIT = 2 };
+enum { GM_F32 = 0, GM_BF16 = 1, GM_SPLIT = 2, GM_F16 = 3 };   // GM_F16: as GM_BF16 with IEEE fp16 operands / output
 
 __device__ __forceinline__ void split8(const f32x4 x0, const f32x4 x1, bf16x8& hi, bf16x8& lo) {
   typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -95,7 +95,8 @@ __device__ __forceinline__ void split8(const f32x4 x0, const f32x4 x1, bf16x8& h
 // latency; with NS = 4 the latencies overlap (cdna_hip_programming.md §5 "Pipelining across barriers").
 template <int MODE, int BM, int BN, int WGM, int WGN, int NS, int TAG>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_nt_kernel(GemmP p) {
-  constexpr bool BF16 = MODE == GM_BF16;
+  constexpr bool BF16 = MODE == GM_BF16 || MODE == GM_F16;   // 16-bit operands
+  constexpr bool F16 = MODE == GM_F16;
   constexpr int LPS = BM / 8 / (WGM * WGN) + BN / 8 / (WGM * WGN);   // LDS-DMA instructions per thread per stage
   constexpr int NW = WGM * WGN;
   constexpr int MT = BM / WGM / 32, NT = BN / WGN / 32;
@@ -222,8 +223,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_nt_kernel(GemmP p) {
           for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int j = 0; j < MT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[i]),
-                                                                  __builtin_bit_cast(bf16x8, xa[j]), acc[i][j], 0, 0, 0);
+              acc[i][j] = mfma32x32x16_h<F16>(__builtin_bit_cast(bf16x8, wb[i]), __builtin_bit_cast(bf16x8, xa[j]), acc[i][j]);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_nt_kernel(GemmP p) {
           if (p.c_bf16) {
             u32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (unsigned)f2bf(v[2 * e]) | ((unsigned)f2bf(v[2 * e + 1]) << 16);
+            for (int e = 0; e < 4; ++e) o[e] = (unsigned)f2h<F16>(v[2 * e]) | ((unsigned)f2h<F16>(v[2 * e + 1]) << 16);
             *(u32x4*)(Cb + ((long)m * p.ldc + n) * 2) = o;
           } else {
             f32x4 o0, o1;
@@ -488,23 +488,24 @@ struct Cfg { int bm, bn, threads, lds, per_cu; };
 template <int MODE, int BM, int BN, int WGM, int WGN, int NS>
 int launch_cfg(const GemmP& p, hipStream_t st, int per_cu) {
   typedef void (*kern_t)(GemmP);
-  constexpr bool TAGGED = MODE != GM_SPLIT && BM == 256;   // per-tag symbols only where rocprof needs to tell the backbone GEMMs apart
+  constexpr bool TAGGED = MODE != GM_SPLIT && MODE != GM_F16 && BM == 256;   // per-tag symbols only where rocprof needs to tell the backbone GEMMs apart
   static const kern_t table[5] = {gemm_nt_kernel<MODE, BM, BN, WGM, WGN, NS, 0>, gemm_nt_kernel<MODE, BM, BN, WGM, WGN, NS, TAGGED ? 1 : 0>,
                                   gemm_nt_kernel<MODE, BM, BN, WGM, WGN, NS, TAGGED ? 2 : 0>, gemm_nt_kernel<MODE, BM, BN, WGM, WGN, NS, TAGGED ? 3 : 0>,
                                   gemm_nt_kernel<MODE, BM, BN, WGM, WGN, NS, TAGGED ? 4 : 0>};
   constexpr int LDS = NS * (BM + BN) * KBYTES;
-  static bool attr_done = false;
-  if (!attr_done) {
+  // per-device: the dynamic-LDS limit is a per-device function attribute (a process may drive several GPUs)
+  static bool attr_done[64] = {};
+  static int ncu_dev[64] = {};
+  int dev = 0;
+  EC_HIP(hipGetDevice(&dev));
+  EC_REQUIRE(dev >= 0 && dev < 64, -1, "gemm_nt: device ordinal out of range");
+  if (!attr_done[dev]) {
     for (int t = 0; t < 5; ++t)
       EC_HIP(hipFuncSetAttribute((const void*)table[t], hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_done = true;
+    EC_HIP(hipDeviceGetAttribute(&ncu_dev[dev], hipDeviceAttributeMultiprocessorCount, dev));
+    attr_done[dev] = true;
   }
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0;
-    EC_HIP(hipGetDevice(&dev));
-    EC_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-  }
+  const int ncu = ncu_dev[dev];
   const long ntiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.batch;
   long grid = (long)ncu * per_cu;
   if (ntiles < grid) grid = ntiles;
@@ -538,12 +539,12 @@ int gemm_nt(const GemmP& p, hipStream_t st) {
   // NS-deep stage ring: measured NEUTRAL on MI355X for the head's shapes (kp 3200x256x256: 8.0 vs 8.2 us; 10368x256x768: 30 vs
   // 37 us) - those kernels sit at the per-launch floor, not at the load latency - so the 2-stage ring stays the default.
   static const bool deep = getenv("EC_GEMM_DEEP") && atoi(getenv("EC_GEMM_DEEP")) != 0;
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0;
-    EC_HIP(hipGetDevice(&dev));
-    EC_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-  }
+  static int ncu_dev[64] = {};
+  int dev = 0;
+  EC_HIP(hipGetDevice(&dev));
+  EC_REQUIRE(dev >= 0 && dev < 64, -1, "gemm_nt: device ordinal out of range");
+  if (!ncu_dev[dev]) EC_HIP(hipDeviceGetAttribute(&ncu_dev[dev], hipDeviceAttributeMultiprocessorCount, dev));
+  const int ncu = ncu_dev[dev];
   struct Opt { int bm, bn; float eff; };
   static const Opt opts[5] = {{256, 256, 1.00f}, {256, 128, 1.00f}, {128, 128, 0.95f}, {128, 64, 0.85f}, {64, 64, 0.75f}};
   int sel = 2;
@@ -555,6 +556,15 @@ int gemm_nt(const GemmP& p, hipStream_t st) {
   }
   if (force == 256) sel = 0; else if (force == 256128) sel = 1; else if (force == 128) sel = 2; else if (force == 12864) sel = 3;
   else if (force == 64) sel = 4;
+  if (p.ab_bf16 && p.h_f16) {   // fp16 operands: the small-shape fallbacks of the fp16 backbone mode (2-stage ring only)
+    switch (sel) {
+      case 0: return launch_cfg<GM_F16, 256, 256, 2, 4, 2>(p, st, 1);
+      case 1: return launch_cfg<GM_F16, 256, 128, 4, 2, 2>(p, st, 1);
+      case 2: return launch_cfg<GM_F16, 128, 128, 2, 2, 2>(p, st, 2);
+      case 3: return launch_cfg<GM_F16, 128, 64, 2, 2, 2>(p, st, 3);
+      default: return launch_cfg<GM_F16, 64, 64, 2, 2, 2>(p, st, 4);
+    }
+  }
   if (p.ab_bf16) {
     switch (sel) {
       case 0: return (deep ? launch_cfg<GM_BF16, 256, 256, 2, 4, 2>(p, st, 1) : launch_cfg<GM_BF16, 256, 256, 2, 4, 2>(p, st, 1));

@@ -59,20 +59,30 @@ constexpr int G8_AHEAD = 5;               // half-tiles the load stream runs ahe
 // Epilogue kinds (compile-time): the three shapes of the bf16 backbone blocks + a generic one (every GemmP option).
 enum { G8_GENERIC = 0, G8_BIAS_BF16 = 1, G8_SCALE_BF16 = 2, G8_GELU_BF16 = 3 };
 
-// GELU for bf16 outputs: x * Phi(x) with Phi(x) = 1 / (1 + 2^(x * P(x^2))), P an even minimax polynomial fitted to the erf
-// form (nn.GELU default, dinov2 Mlp) on |x| <= 9: max |err| 2.5e-5, far below the bf16 rounding of the result.
-// 6 plain VALU ops + exp2 + rcp per element (the epilogue of fc1 is VALU-bound: 128 GELUs per lane per tile).
+// GELU for 16-bit outputs: x * Phi(x) with Phi(x) = 1 / (1 + 2^(x * P(x^2))), P an even minimax polynomial fitted to the erf
+// form (nn.GELU default, dinov2 Mlp) on |x| <= 9.  bf16 outputs: degree 2 in x^2, max |err| 2.5e-5 (far below the bf16 rounding
+// of the result), 6 plain VALU ops + exp2 + rcp per element (the epilogue of fc1 is VALU-bound: 128 GELUs per lane per tile).
+// fp16 outputs carry three more significand bits: degree 4, max |err| 3.0e-6 (two more FMAs).
+template <bool F16>
 __device__ __forceinline__ float gelu_fast8(float x) {
   const float s = fminf(x * x, 81.f);
-  float q = fmaf(1.01453915e-03f, s, -1.06777424e-01f);
-  q = fmaf(q, s, -2.30111947e+00f);
+  float q;
+  if constexpr (F16) {
+    q = fmaf(-3.229071e-06f, s, 8.82395e-05f);
+    q = fmaf(q, s, 3.6026796e-04f);
+    q = fmaf(q, s, -1.0522668e-01f);
+    q = fmaf(q, s, -2.3020453e+00f);
+  } else {
+    q = fmaf(1.01453915e-03f, s, -1.06777424e-01f);
+    q = fmaf(q, s, -2.30111947e+00f);
+  }
   const float e = __builtin_amdgcn_exp2f(x * q);
   return x * __builtin_amdgcn_rcpf(1.f + e);
 }
 
 // acc[mi][ni] (f32x4) of lane l: row m = m0 + wr*128 + (mi>>2)*64 + (mi&3)*16 + (l&15),
 //                                cols n = n0 + wc*64 + (ni>>1)*32 + (ni&1)*16 + (l>>4)*4 .. +3
-template <int KIND, bool FULL>
+template <int KIND, bool FULL, bool F16>
 __device__ __forceinline__ void g8_epilogue(const GemmP& p, f32x4 (&acc)[8][4], char* smem, int m0, int n0, int wr, int wc, int lane) {
   const int ncol = n0 + wc * 64 + (lane >> 4) * 4;
   const int mrow = m0 + wr * 128 + (lane & 15);
@@ -102,12 +112,12 @@ __device__ __forceinline__ void g8_epilogue(const GemmP& p, f32x4 (&acc)[8][4], 
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         } else if (p.act == ACT_GELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = p.c_bf16 ? gelu_fast8(v[e]) : gelu_erf(v[e]);
+          for (int e = 0; e < 4; ++e) v[e] = p.c_bf16 ? gelu_fast8<F16>(v[e]) : gelu_erf(v[e]);
         }
         v *= gam4[ni];
         if (p.resid) v += *(const f32x4*)(p.resid + (long)m * p.ldr + n);
         if (p.c_bf16) {
-          *(u32x2*)((char*)p.C + ((long)m * p.ldc + n) * 2) = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16v4));
+          *(u32x2*)((char*)p.C + ((long)m * p.ldc + n) * 2) = pack4_h<F16>(v);
         } else {
           *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = v;
         }
@@ -148,15 +158,14 @@ __device__ __forceinline__ void g8_epilogue(const GemmP& p, f32x4 (&acc)[8][4], 
           f32x4 v = acc[mi][ni] + bias4[ni];
           if constexpr (KIND == G8_GELU_BF16) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_fast8(v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = gelu_fast8<F16>(v[e]);
           }
           if constexpr (KIND == G8_SCALE_BF16) v *= gam4[ni];
-          const u32x2 o = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16v4));   // 2 x v_cvt_pk_bf16_f32 (RNE)
+          const u32x2 o = pack4_h<F16>(v);   // 2 x v_cvt_pk_{bf16,f16}_f32 (RNE)
           const int chunk = (ni >> 1) * 4 + (ni & 1) * 2 + (wq >> 1);
           *(u32x2*)(stg + row * 128 + ((chunk ^ (row & 7)) << 4) + (wq & 1) * 8) = o;
         }
       }
-      if (p.dbg & 1) continue;   // timing experiments only: no stores
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = j * 8 + rrow;
@@ -177,8 +186,9 @@ __device__ __forceinline__ void g8_epilogue(const GemmP& p, f32x4 (&acc)[8][4], 
 // the barrier releases.  RAW: half-tile i is waited for (vmcnt) in every wave's R_(i-2), barrier #(i-2) follows that wait in
 // both groups and precedes every read of it (R_(i-1) at the earliest).  WAR: slot of half-tile i-8 is re-staged in R_(i-5);
 // its last reads (R_(<=i-8)) were retired before barrier #(i-7) in both groups.
-template <int KIND, int TAG, bool TRACE = false, bool TWOPH = false, bool ONEBAR = false>
+template <int KIND, int TAG, bool F16 = false, bool TRACE = false>
 __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
+  constexpr bool TWOPH = false, ONEBAR = false;   // rejected schedules (see the header comment), kept out of the build
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -219,7 +229,6 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
     rp2 = B + (long)min(rb + 32, p.N - 1) * ldb_b;
   };
   auto issue = [&](const char* rp, int half) {
-    if constexpr (TRACE) { if ((p.dbg & 16) && wr == 1) return; }   // experiment: partner group issues no DMA
     const char* src = rp + (long)ls_kt * 128;
     // (dead stream: each wave's dummy loads land in its OWN staging slot, which it only uses after draining its own loads)
     char* dst = smem + (ls_live ? ((ls_kt & 1) * G8_KT + half * G8_HALF + wave * 2048) : (G8_STAGE + wave * 4096));
@@ -303,14 +312,14 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
             for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
               for (int f = 0; f < 2; ++f)
-                acc[fi][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[f][kh], af[fi][kh], acc[fi][f], 0, 0, 0);
+                acc[fi][f] = mfma16x16x32_h<F16>(b0[f][kh], af[fi][kh], acc[fi][f]);
 #pragma unroll
           for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
             for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
               for (int f = 0; f < 2; ++f)
-                acc[fi][2 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[f][kh], af[fi][kh], acc[fi][2 + f], 0, 0, 0);
+                acc[fi][2 + f] = mfma16x16x32_h<F16>(b1[f][kh], af[fi][kh], acc[fi][2 + f]);
           __builtin_amdgcn_s_setprio(0);
           G8_BAR();
 #pragma unroll
@@ -329,14 +338,14 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
             for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
               for (int f = 0; f < 2; ++f)
-                acc[4 + fi][2 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[f][kh], af[fi][kh], acc[4 + fi][2 + f], 0, 0, 0);
+                acc[4 + fi][2 + f] = mfma16x16x32_h<F16>(b1[f][kh], af[fi][kh], acc[4 + fi][2 + f]);
 #pragma unroll
           for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
             for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
               for (int f = 0; f < 2; ++f)
-                acc[4 + fi][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[f][kh], af[fi][kh], acc[4 + fi][f], 0, 0, 0);
+                acc[4 + fi][f] = mfma16x16x32_h<F16>(b0[f][kh], af[fi][kh], acc[4 + fi][f]);
           __builtin_amdgcn_s_setprio(0);
         } else {
         // ---------------- phase 0: quadrant (m-half 0, n-half 0)
@@ -362,7 +371,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
           for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
             for (int f = 0; f < 2; ++f)
-              acc[fi][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[f][kh], af[fi][kh], acc[fi][f], 0, 0, 0);
+              acc[fi][f] = mfma16x16x32_h<F16>(b0[f][kh], af[fi][kh], acc[fi][f]);
         __builtin_amdgcn_s_setprio(0);
         G8_STAMP(buf * 20 + 3);
         G8_BAR_B();
@@ -387,7 +396,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
           for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
             for (int f = 0; f < 2; ++f)
-              acc[fi][2 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[f][kh], af[fi][kh], acc[fi][2 + f], 0, 0, 0);
+              acc[fi][2 + f] = mfma16x16x32_h<F16>(b1[f][kh], af[fi][kh], acc[fi][2 + f]);
         __builtin_amdgcn_s_setprio(0);
         G8_STAMP(buf * 20 + 8);
         G8_BAR_B();
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
           for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
             for (int f = 0; f < 2; ++f)
-              acc[4 + fi][2 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[f][kh], af[fi][kh], acc[4 + fi][2 + f], 0, 0, 0);
+              acc[4 + fi][2 + f] = mfma16x16x32_h<F16>(b1[f][kh], af[fi][kh], acc[4 + fi][2 + f]);
         __builtin_amdgcn_s_setprio(0);
         G8_STAMP(buf * 20 + 13);
         G8_BAR_B();
@@ -434,7 +443,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
           for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
             for (int f = 0; f < 2; ++f)
-              acc[4 + fi][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[f][kh], af[fi][kh], acc[4 + fi][f], 0, 0, 0);
+              acc[4 + fi][f] = mfma16x16x32_h<F16>(b0[f][kh], af[fi][kh], acc[4 + fi][f]);
         __builtin_amdgcn_s_setprio(0);
         }
         G8_STAMP(buf * 20 + 18);
@@ -461,8 +470,8 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
     }
     {
       const int m0 = (t / ntn) << 8, n0 = (t % ntn) << 8;
-      if (KIND != G8_GENERIC && m0 + 256 <= p.M && n0 + 256 <= p.N) g8_epilogue<KIND, true>(p, acc, smem, m0, n0, wr, wc, lane);
-      else g8_epilogue<KIND, false>(p, acc, smem, m0, n0, wr, wc, lane);
+      if (KIND != G8_GENERIC && m0 + 256 <= p.M && n0 + 256 <= p.N) g8_epilogue<KIND, true, F16>(p, acc, smem, m0, n0, wr, wc, lane);
+      else g8_epilogue<KIND, false, F16>(p, acc, smem, m0, n0, wr, wc, lane);
     }
     if constexpr (!ONEBAR) {
       if (wr == 1) G8_BAR();
@@ -474,6 +483,13 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
 }
 
 
+}  // namespace
+
+// Per-device launch state: the 160 KiB dynamic-LDS attribute is a per-device function attribute and the CU count differs per
+// device, so a process that drives several GPUs (one engine per device) gets both for every device it touches.
+namespace {
+struct G8Dev { bool attr_done = false; bool trace_attr = false; int ncu = 0; };
+G8Dev g8_dev[64];
 }  // namespace
 
 // Returns 1 if this kernel handled the problem, 0 if the shape is not eligible (caller falls back), <0 on error.
@@ -490,74 +506,39 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
     else if (p.act == ACT_NONE && p.gamma) kind = G8_SCALE_BF16;
     else if (p.act == ACT_GELU && !p.gamma) kind = G8_GELU_BF16;
   }
-  static const kern_t table[4][5] = {
-      {gemm8_bf16_kernel<0, 0>, gemm8_bf16_kernel<0, 1>, gemm8_bf16_kernel<0, 2>, gemm8_bf16_kernel<0, 3>, gemm8_bf16_kernel<0, 4>},
-      {gemm8_bf16_kernel<1, 0>, gemm8_bf16_kernel<1, 1>, gemm8_bf16_kernel<1, 0>, gemm8_bf16_kernel<1, 0>, gemm8_bf16_kernel<1, 0>},
-      {gemm8_bf16_kernel<2, 0>, gemm8_bf16_kernel<2, 0>, gemm8_bf16_kernel<2, 2>, gemm8_bf16_kernel<2, 0>, gemm8_bf16_kernel<2, 4>},
-      {gemm8_bf16_kernel<3, 0>, gemm8_bf16_kernel<3, 0>, gemm8_bf16_kernel<3, 0>, gemm8_bf16_kernel<3, 3>, gemm8_bf16_kernel<3, 0>}};
-  static bool attr_done = false;
-  if (!attr_done) {
-    for (int k = 0; k < 4; ++k)
-      for (int t = 0; t < 5; ++t)
-        EC_HIP(hipFuncSetAttribute((const void*)table[k][t], hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));
-    attr_done = true;
-  }
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0;
-    EC_HIP(hipGetDevice(&dev));
-    EC_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+#define G8_ROW(F) \
+      {gemm8_bf16_kernel<0, 0, F>, gemm8_bf16_kernel<0, 1, F>, gemm8_bf16_kernel<0, 2, F>, gemm8_bf16_kernel<0, 3, F>, gemm8_bf16_kernel<0, 4, F>}, \
+      {gemm8_bf16_kernel<1, 0, F>, gemm8_bf16_kernel<1, 1, F>, gemm8_bf16_kernel<1, 0, F>, gemm8_bf16_kernel<1, 0, F>, gemm8_bf16_kernel<1, 0, F>}, \
+      {gemm8_bf16_kernel<2, 0, F>, gemm8_bf16_kernel<2, 0, F>, gemm8_bf16_kernel<2, 2, F>, gemm8_bf16_kernel<2, 0, F>, gemm8_bf16_kernel<2, 4, F>}, \
+      {gemm8_bf16_kernel<3, 0, F>, gemm8_bf16_kernel<3, 0, F>, gemm8_bf16_kernel<3, 0, F>, gemm8_bf16_kernel<3, 3, F>, gemm8_bf16_kernel<3, 0, F>}
+  static const kern_t table[2][4][5] = {{G8_ROW(false)}, {G8_ROW(true)}};
+#undef G8_ROW
+  int dev = 0;
+  EC_HIP(hipGetDevice(&dev));
+  EC_REQUIRE(dev >= 0 && dev < 64, -1, "gemm8: device ordinal out of range");
+  G8Dev& ds = g8_dev[dev];
+  if (!ds.attr_done) {
+    for (int f = 0; f < 2; ++f)
+      for (int k = 0; k < 4; ++k)
+        for (int t = 0; t < 5; ++t)
+          EC_HIP(hipFuncSetAttribute((const void*)table[f][k][t], hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));
+    EC_HIP(hipDeviceGetAttribute(&ds.ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    ds.attr_done = true;
   }
   const long ntiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-  long grid = ncu;
+  long grid = ds.ncu;
   if (ntiles < grid) grid = ntiles;
-  static const int dbg = getenv("EC_G8_DBG") ? atoi(getenv("EC_G8_DBG")) : 0;
-  static const bool twoph = getenv("EC_G8_2PH") && atoi(getenv("EC_G8_2PH")) != 0;   // A/B: two 32-MFMA phases per K-tile
-  if (twoph && kind != G8_GENERIC) {
-    static const kern_t t2[4] = {nullptr, gemm8_bf16_kernel<1, 0, false, true>, gemm8_bf16_kernel<2, 0, false, true>,
-                                 gemm8_bf16_kernel<3, 0, false, true>};
-    static bool a2 = false;
-    if (!a2) {
-      for (int k = 1; k < 4; ++k) EC_HIP(hipFuncSetAttribute((const void*)t2[k], hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));
-      a2 = true;
-    }
-    GemmP q2 = p;
-    q2.dbg = dbg;
-    hipLaunchKernelGGL(t2[kind], dim3((unsigned)grid), dim3(512), G8_LDS, st, q2);
-    EC_LAUNCH_CHECK();
-    return 1;
-  }
-  static const bool onebar = getenv("EC_G8_1BAR") && atoi(getenv("EC_G8_1BAR")) != 0;   // A/B: one barrier per phase
-  if (onebar) {
-    static const kern_t t1[4] = {gemm8_bf16_kernel<0, 0, false, false, true>, gemm8_bf16_kernel<1, 0, false, false, true>,
-                                 gemm8_bf16_kernel<2, 0, false, false, true>, gemm8_bf16_kernel<3, 0, false, false, true>};
-    static bool a1 = false;
-    if (!a1) {
-      for (int k = 0; k < 4; ++k) EC_HIP(hipFuncSetAttribute((const void*)t1[k], hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));
-      a1 = true;
-    }
-    GemmP q1 = p;
-    q1.dbg = dbg;
-    hipLaunchKernelGGL(t1[kind], dim3((unsigned)grid), dim3(512), G8_LDS, st, q1);
-    EC_LAUNCH_CHECK();
-    return 1;
-  }
   static const bool trace = getenv("EC_G8_TRACE") != nullptr;
-  if (trace && kind == G8_BIAS_BF16 && p.aux) {   // debug: p.aux = device buffer of 8 x 64 uint32 timestamps
-    static bool tattr = false;
-    if (!tattr) {
-      EC_HIP(hipFuncSetAttribute((const void*)gemm8_bf16_kernel<1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));
-      tattr = true;
+  if (trace && kind == G8_BIAS_BF16 && !p.h_f16 && p.aux) {   // debug: p.aux = device buffer of 8 x 64 uint32 timestamps
+    if (!ds.trace_attr) {
+      EC_HIP(hipFuncSetAttribute((const void*)gemm8_bf16_kernel<1, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));
+      ds.trace_attr = true;
     }
-    GemmP qt = p;
-    qt.dbg = dbg;
-    hipLaunchKernelGGL((gemm8_bf16_kernel<1, 0, true>), dim3((unsigned)grid), dim3(512), G8_LDS, st, qt);
+    hipLaunchKernelGGL((gemm8_bf16_kernel<1, 0, false, true>), dim3((unsigned)grid), dim3(512), G8_LDS, st, p);
     EC_LAUNCH_CHECK();
     return 1;
   }
-  GemmP q = p;
-  q.dbg = dbg;
-  hipLaunchKernelGGL(table[kind][p.tag], dim3((unsigned)grid), dim3(512), G8_LDS, st, q);
+  hipLaunchKernelGGL(table[p.h_f16 ? 1 : 0][kind][p.tag], dim3((unsigned)grid), dim3(512), G8_LDS, st, p);
   EC_LAUNCH_CHECK();
   return 1;
 }

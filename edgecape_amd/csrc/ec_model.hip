@@ -43,6 +43,7 @@ struct Lin {  // a Linear layer view: W [N,K] (+ optional bf16 copy), bias [N]
   const float* ws = nullptr;   // bf16x3 split-packed copy (head_precision = EC_BF16X3), same byte size as w
   const float* b = nullptr;
   int N = 0, K = 0;
+  bool w16_is_f16 = false;     // w16 holds IEEE fp16 (EC_F16 backbone) instead of bf16
   const void* wsel(bool split) const { return split ? (const void*)ws : (const void*)w; }
 };
 struct Norm { const float* w = nullptr; const float* b = nullptr; };
@@ -72,7 +73,9 @@ struct ec_model {
   int g = 0, HW = 0, T = 0, C = 0, K = 0, d = 0, L = 0, E = 0;
   int Kp = 640;  // padded im2col width (588 -> 640: multiple of 128 bytes for fp32 and bf16)
   bool finalized = false;
-  bool bb16 = false;
+  bool bb16 = false;         // backbone GEMM operands / activations are 16-bit ...
+  bool bbf16 = false;        // ... in IEEE fp16 (EC_F16) instead of bf16 (EC_BF16)
+  bool bb_split = false;     // EC_BF16X3 backbone: fp32 activations, every MFMA operand split hi+lo bf16 (3 MFMAs per product)
   bool head_split = false;   // head GEMMs in bf16x3 (ec_gemm.hip GM_SPLIT)
   // the support half of the head (pooling + SkeletonPredictor) has no query input: it runs on a side stream, concurrently
   // with input_proj / encoder / proposal generator on the caller's stream (both are small-grid, latency-bound kernels)
@@ -118,6 +121,8 @@ struct ec_model {
   float* feat = nullptr;      // [n_img_max, HW, C] tokens; query first, then shot s at (1+s)*bs
   float* feat_nchw_tmp = nullptr;
   int32_t *d_edges = nullptr, *d_off = nullptr; int edges_cap = 0;
+  int32_t *h_edges = nullptr, *h_off = nullptr;   // pinned staging of the skeleton edge lists
+  hipEvent_t ev_edges = nullptr;
   float *Wp, *pooled, *sk, *valid, *binary, *adj_r1, *adj1, *P, *kn, *kp_ref, *attn_adj;
   uint8_t *kmask, *kmask_fixed;
   float *s_mem, *s_x, *s_tmp, *s_qkv, *s_att, *s_qc, *s_kv, *s_y, *s_z, *s_qimg, *s_kvk, *s_attimg, *s_tmpimg;
@@ -172,7 +177,8 @@ static int upload(ec_model* m, const std::vector<float>& h, const float** out) {
 }
 static int upload16(ec_model* m, const std::vector<float>& h, const bf16_t** out) {
   std::vector<bf16_t> t(h.size());
-  for (size_t i = 0; i < h.size(); ++i) t[i] = f2bf(h[i]);
+  if (m->bbf16) for (size_t i = 0; i < h.size(); ++i) t[i] = f2half_host(h[i]);
+  else for (size_t i = 0; i < h.size(); ++i) t[i] = f2bf(h[i]);
   bf16_t* p = nullptr;
   int rc = dalloc(m, &p, t.size());
   if (rc) return rc;
@@ -210,7 +216,8 @@ static int make_lin(ec_model* m, const std::string& wname, const std::string& bn
   if (want16) {
     int rc = upload16(m, w->host, &out->w16);
     if (rc) return rc;
-  } else if (m->head_split && name_is_head(wname)) {
+    out->w16_is_f16 = m->bbf16;
+  } else if ((m->head_split && name_is_head(wname)) || (m->bb_split && !name_is_head(wname))) {
     int rc = upload_split(m, w->host.data(), out->N, out->K, &out->ws);
     if (rc) return rc;
   }
@@ -360,7 +367,7 @@ static int linear(const void* A, long lda, bool a16, const Lin& W, void* C, long
                   long ldt = 0, int period = 1, const float* aux = nullptr, long ldaux = 0, int tag = 0) {
   GemmP p;
   p.tag = tag;
-  p.A = A; p.lda = lda; p.ab_bf16 = a16 ? 1 : 0;
+  p.A = A; p.lda = lda; p.ab_bf16 = a16 ? 1 : 0; p.h_f16 = (a16 && W.w16_is_f16) ? 1 : 0;
   p.split = (!a16 && W.ws) ? 1 : 0;     // head in bf16x3 mode: every head Lin carries a split-packed copy
   p.B = a16 ? (const void*)W.w16 : W.wsel(p.split); p.ldb = W.K;
   EC_REQUIRE(p.B != nullptr, EC_ERR_STATE, "linear: weight copy for this precision was not built");
@@ -371,10 +378,11 @@ static int linear(const void* A, long lda, bool a16, const Lin& W, void* C, long
   return gemm_nt(p, st);
 }
 
-static int ln(const float* x, long ldx, void* y, long ldy, bool y16, const Norm& n, int rows, int cols, float eps, hipStream_t st,
-              int drop_period = 0, const void* add = nullptr, long ldadd = 0, const void* add2 = nullptr, bool write_x = true) {
+static int ln(const float* x, long ldx, void* y, long ldy, int y16, const Norm& n, int rows, int cols, float eps, hipStream_t st,
+              int drop_period = 0, const void* add = nullptr, long ldadd = 0, const void* add2 = nullptr, bool write_x = true,
+              int add_fmt = 0) {
   LnP p;
-  p.x = x; p.ldx = ldx; p.y = y; p.ldy = ldy; p.y_bf16 = y16; p.w = n.w; p.b = n.b; p.rows = rows; p.cols = cols; p.eps = eps;
+  p.x = x; p.ldx = ldx; p.y = y; p.ldy = ldy; p.y_bf16 = y16; p.add_fmt = add_fmt; p.w = n.w; p.b = n.b; p.rows = rows; p.cols = cols; p.eps = eps;
   p.drop_period = drop_period;
   p.add = add; p.ldadd = ldadd; p.add2 = add2; p.xsum = (add && write_x) ? const_cast<float*>(x) : nullptr;
   return layernorm(p, st);
@@ -391,16 +399,18 @@ static int ln(const float* x, long ldx, void* y, long ldy, bool y16, const Norm&
 static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_each, float* feat_out, hipStream_t st) {
   const int C = m->C, T = m->T, HW = m->HW, g = m->g, H = m->cfg.image_size;
   const bool h16 = m->bb16;
+  const int hfmt = h16 ? (m->bbf16 ? 2 : 1) : 0;   // 16-bit storage format: 0 fp32, 1 bf16, 2 fp16
   const int nh = m->cfg.num_heads;
   const int n = n_src * n_each;
   const long M = (long)n * T;
   for (int s = 0; s < n_src; ++s)
-    RUN(im2col14(imgs[s], (char*)m->bb_h + (size_t)s * n_each * T * m->Kp * (h16 ? 2 : 4), h16, n_each, H, g, m->Kp, st));
+    RUN(im2col14(imgs[s], (char*)m->bb_h + (size_t)s * n_each * T * m->Kp * (h16 ? 2 : 4), hfmt, n_each, H, g, m->Kp, st));
   {  // patch embedding: ONE GEMM over all n*T token rows (the zero cls rows produce bias + pos[0], overwritten below);
      // epilogue adds the conv bias and the positional table row m % T
     GemmP p;
-    p.A = m->bb_h; p.lda = m->Kp; p.ab_bf16 = h16;
-    p.B = h16 ? (const void*)m->patch.w16 : (const void*)m->patch.w; p.ldb = m->Kp;
+    p.A = m->bb_h; p.lda = m->Kp; p.ab_bf16 = h16; p.h_f16 = m->bbf16;
+    p.split = m->bb_split ? 1 : 0;
+    p.B = h16 ? (const void*)m->patch.w16 : m->patch.wsel(m->bb_split); p.ldb = m->Kp;
     p.C = m->bb_x; p.ldc = C;
     p.bias = m->patch.b; p.table = m->pos; p.ldt = C; p.period = T;
     p.M = (int)M; p.N = C; p.K = m->Kp;
@@ -416,15 +426,16 @@ static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_
   const void *pend = nullptr, *pend2 = nullptr;   // branch outputs not yet added to x (attention branch, MLP branch)
   for (size_t i = 0; i < m->blocks.size(); ++i) {
     const BBlock& b = m->blocks[i];
-    RUN(ln(m->bb_x, C, m->bb_xn, C, h16, b.n1, (int)M, C, 1e-6f, st, 0, pend, C, pend2));
+    RUN(ln(m->bb_x, C, m->bb_xn, C, hfmt, b.n1, (int)M, C, 1e-6f, st, 0, pend, C, pend2));
     pend = pend2 = nullptr;
     const bool prof = m->prof_on && m->prof_used + 2 <= m->prof_ev.size();
     if (prof) EC_HIP(hipEventRecord(m->prof_ev[m->prof_used++], st));
     {
       GemmP p;
       p.tag = 1;
-      p.A = m->bb_xn; p.lda = C; p.ab_bf16 = h16;
-      p.B = h16 ? (const void*)b.qkv.w16 : (const void*)b.qkv.w; p.ldb = C;
+      p.A = m->bb_xn; p.lda = C; p.ab_bf16 = h16; p.h_f16 = m->bbf16;
+      p.split = m->bb_split ? 1 : 0;
+      p.B = h16 ? (const void*)b.qkv.w16 : b.qkv.wsel(m->bb_split); p.ldb = C;
       p.C = m->bb_qkv; p.ldc = 3 * C; p.c_bf16 = h16; p.bias = b.qkv.b;
       p.M = (int)M; p.N = 3 * C; p.K = C;
       RUN(gemm_nt(p, st));
@@ -436,11 +447,11 @@ static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_
     a.O = m->bb_att;
     a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
     a.sQ = a.sK = a.sV = (long)T * 3 * C; a.sO = (long)T * C;
-    a.B = n; a.H = nh; a.Lq = T; a.Lk = T; a.hd = C / nh; a.bf16 = h16;
+    a.B = n; a.H = nh; a.Lq = T; a.Lk = T; a.hd = C / nh; a.bf16 = h16; a.f16 = m->bbf16; a.split = m->bb_split ? 1 : 0;
     RUN(attention(a, st));
     if (h16) {
       RUN(linear(m->bb_att, C, true, b.proj, m->bb_y, C, true, (int)M, ACT_NONE, st, b.ls1, nullptr, 0, nullptr, 0, 1, nullptr, 0, 2));
-      RUN(ln(m->bb_x, C, m->bb_xn, C, true, b.n2, (int)M, C, 1e-6f, st, 0, m->bb_y, C, nullptr, false));
+      RUN(ln(m->bb_x, C, m->bb_xn, C, hfmt, b.n2, (int)M, C, 1e-6f, st, 0, m->bb_y, C, nullptr, false));
       RUN(linear(m->bb_xn, C, true, b.fc1, m->bb_h, 4 * C, true, (int)M, ACT_GELU, st, nullptr, nullptr, 0, nullptr, 0, 1, nullptr, 0, 3));
       RUN(linear(m->bb_h, 4 * C, true, b.fc2, m->bb_y2, C, true, (int)M, ACT_NONE, st, b.ls2, nullptr, 0, nullptr, 0, 1, nullptr, 0, 4));
       pend = m->bb_y; pend2 = m->bb_y2;
@@ -451,7 +462,7 @@ static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_
       RUN(linear(m->bb_h, 4 * C, false, b.fc2, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls2, m->bb_x, C, nullptr, 0, 1, nullptr, 0, 4));
     }
   }
-  RUN(ln(m->bb_x, C, feat_out ? feat_out : m->feat, C, false, m->bnorm, (int)M, C, 1e-6f, st, T, pend, C, pend2, false));
+  RUN(ln(m->bb_x, C, feat_out ? feat_out : m->feat, C, 0, m->bnorm, (int)M, C, 1e-6f, st, T, pend, C, pend2, false, hfmt));
   return 0;
 }
 
@@ -611,6 +622,7 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
   const int Mk = bs * K, Mi = bs * HW;
   float* adj_out = ss.adj_out;
   float* attn_adj = ss.attn_adj;
+  EC_REQUIRE(hops1 <= 5, EC_ERR_ARG, "max_hops > 4 not supported");   // all argument checks happen before the first fork
 
   // image lane of the skeleton head (see (3)): forked first so image_project overlaps the pooling chain
   const bool ov2 = m->overlap_dec && m->side2 != nullptr;
@@ -720,7 +732,6 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
     } else if (hops1 > 3) {
       RUN(mm(attn_adj + 2 * hop, A1, attn_adj + 3 * hop));
     }
-    EC_REQUIRE(hops1 <= 5, EC_ERR_ARG, "max_hops > 4 not supported");
   }
   bool bias_done = false;
   if (ss.dec_bias) {   // all decoder layers' Markov-bias MLPs in one launch when the fused shape applies
@@ -940,6 +951,16 @@ static SupportState workspace_support(ec_model* m, const ec_outputs* out) {
   return ss;
 }
 
+// Error path of the multi-stream head: work already forked onto the helper streams may still read caller-owned buffers
+// (features, heatmaps, masks) and write the outputs.  The header promises that nothing of a failed call is still running when it
+// returns, so drain the helper streams before reporting the error.
+static int join_on_error(ec_model* m, int rc) {
+  if (rc == 0) return 0;
+  for (hipStream_t s : {m->side, m->side2, m->aux})
+    if (s) (void)hipStreamSynchronize(s);
+  return rc;
+}
+
 // TwoStageHead.forward (head.py:161-222).  fq: [bs,HW,C] tokens, fs: S pointers [bs,HW,C].
 static int run_head(ec_model* m, const float* fq, const float* const* fs, const float* const* target_s, const float* mask_s,
                     int bs, int S, hipStream_t st, const ec_outputs* out) {
@@ -948,13 +969,13 @@ static int run_head(ec_model* m, const float* fq, const float* const* fs, const 
   if (m->overlap) {
     EC_HIP(hipEventRecord(m->ev_fork, st));
     EC_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
-    RUN(run_head_support(m, fs, target_s, mask_s, bs, S, m->side, ss, m->ev_sk));
+    RUN(join_on_error(m, run_head_support(m, fs, target_s, mask_s, bs, S, m->side, ss, m->ev_sk)));
     EC_HIP(hipEventRecord(m->ev_join, m->side));
-    RUN(run_head_query(m, fq, bs, st, out, ss, m->ev_sk, m->ev_join));   // st joins the side stream before the decoder
+    RUN(join_on_error(m, run_head_query(m, fq, bs, st, out, ss, m->ev_sk, m->ev_join)));   // st joins the side stream before the decoder
     return tl_dump(m);
   }
-  RUN(run_head_support(m, fs, target_s, mask_s, bs, S, st, ss));
-  RUN(run_head_query(m, fq, bs, st, out, ss));
+  RUN(join_on_error(m, run_head_support(m, fs, target_s, mask_s, bs, S, st, ss)));
+  RUN(join_on_error(m, run_head_query(m, fq, bs, st, out, ss)));
   return tl_dump(m);
 }
 
@@ -964,13 +985,32 @@ static int upload_edges(ec_model* m, const int32_t* edges, const int32_t* off, i
   for (int b = 0; b < bs; ++b) EC_REQUIRE(off[b + 1] >= off[b], EC_ERR_ARG, "edge_offsets must be non-decreasing");
   for (int e = 0; e < 2 * ne; ++e)
     EC_REQUIRE(edges[e] >= 0 && edges[e] < m->K, EC_ERR_ARG, "skeleton edge index out of range [0, K)");  // reference: IndexError
-  if (ne > m->edges_cap) {
-    int cap = ne * 2 + 64;
-    RUN(dalloc(m, &m->d_edges, (size_t)cap * 2));
-    m->edges_cap = cap;
+  if (ne > m->edges_cap) {   // grow: the old buffer may still be read by work enqueued earlier on this stream
+    const int cap = ne * 2 + 64;
+    int32_t *nd = nullptr, *nh = nullptr;
+    EC_HIP(hipMalloc((void**)&nd, (size_t)cap * 2 * sizeof(int32_t)));
+    if (hipHostMalloc((void**)&nh, (size_t)cap * 2 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
+      (void)hipFree(nd);
+      return hip_fail(hipErrorOutOfMemory, "hipHostMalloc(edge staging)", __FILE__, __LINE__);
+    }
+    if (m->d_edges) {
+      EC_HIP(hipStreamSynchronize(st));
+      (void)hipFree(m->d_edges);
+      (void)hipHostFree(m->h_edges);
+    }
+    m->d_edges = nd; m->h_edges = nh; m->edges_cap = cap;
   }
-  if (ne > 0) EC_HIP(hipMemcpyAsync(m->d_edges, edges, (size_t)ne * 2 * sizeof(int32_t), hipMemcpyHostToDevice, st));
-  EC_HIP(hipMemcpyAsync(m->d_off, off, (size_t)(bs + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  // staged through pinned host buffers owned by the model: the copies are truly asynchronous and the caller's arrays may be
+  // released as soon as the call returns.  The previous step's copy must have been consumed before the staging is rewritten.
+  if (m->ev_edges) EC_HIP(hipEventSynchronize(m->ev_edges));
+  else EC_HIP(hipEventCreateWithFlags(&m->ev_edges, hipEventDisableTiming));
+  if (ne > 0) {
+    memcpy(m->h_edges, edges, (size_t)ne * 2 * sizeof(int32_t));
+    EC_HIP(hipMemcpyAsync(m->d_edges, m->h_edges, (size_t)ne * 2 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  }
+  memcpy(m->h_off, off, (size_t)(bs + 1) * sizeof(int32_t));
+  EC_HIP(hipMemcpyAsync(m->d_off, m->h_off, (size_t)(bs + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  EC_HIP(hipEventRecord(m->ev_edges, st));
   return 0;
 }
 
@@ -982,7 +1022,12 @@ static int upload_edges(ec_model* m, const int32_t* edges, const int32_t* off, i
 extern "C" {
 
 const char* ec_last_error(void) { return g_err.c_str(); }
-int ec_version(void) { return 1; }
+int ec_version(void) { return EC_ABI_VERSION; }
+int ec_abi_sizes(int* config_bytes, int* outputs_bytes) {
+  if (config_bytes) *config_bytes = (int)sizeof(ec_config);
+  if (outputs_bytes) *outputs_bytes = (int)sizeof(ec_outputs);
+  return EC_OK;
+}
 
 int ec_create(const ec_config* cfg, ec_handle* out) {
   EC_REQUIRE(cfg && out, EC_ERR_ARG, "null argument");
@@ -997,6 +1042,11 @@ int ec_create(const ec_config* cfg, ec_handle* out) {
   // K is dynamic in the reference (target_s[0].shape[1]; 100 in the test configs, the number of clicked points in the demos)
   EC_REQUIRE(cfg->num_kpts > 0 && cfg->num_kpts <= 128, EC_ERR_ARG, "num_kpts must be within 1..128");
   EC_REQUIRE(cfg->max_hops == 4, EC_ERR_ARG, "max_hops must be 4");
+  // layer counts: the workspace and the launch plans are sized from them; the helper-stream plan of the decoder carries per-layer
+  // timeline names for up to 8 layers.  skel_layers >= 1: the skeleton head's image lane is joined through its first layer.
+  EC_REQUIRE(cfg->dec_layers >= 1 && cfg->dec_layers <= 8, EC_ERR_ARG, "num_decoder_layers must be within 1..8");
+  EC_REQUIRE(cfg->enc_layers >= 0 && cfg->enc_layers <= 8, EC_ERR_ARG, "num_encoder_layers must be within 0..8");
+  EC_REQUIRE(cfg->skel_layers >= 1 && cfg->skel_layers <= 8, EC_ERR_ARG, "skeleton_predictor depth must be within 1..8");
   EC_REQUIRE(cfg->head_precision == EC_F32 || cfg->head_precision == EC_BF16X3, EC_ERR_ARG,
              "head_precision: EC_F32 (exact) or EC_BF16X3 (split-bf16 MFMA, fp32-class accuracy)");
   EC_REQUIRE(cfg->max_batch > 0 && cfg->max_shots > 0, EC_ERR_ARG, "max_batch / max_shots must be positive");
@@ -1005,7 +1055,11 @@ int ec_create(const ec_config* cfg, ec_handle* out) {
   m->g = cfg->image_size / cfg->patch;
   m->HW = m->g * m->g; m->T = m->HW + 1; m->C = cfg->embed_dim; m->K = cfg->num_kpts; m->d = cfg->d_model;
   m->L = m->HW + m->K; m->E = 2 * m->d;
-  m->bb16 = cfg->backbone_precision == EC_BF16;
+  EC_REQUIRE(cfg->backbone_precision >= EC_F32 && cfg->backbone_precision <= EC_F16, EC_ERR_ARG,
+             "backbone_precision: EC_F32 (exact), EC_BF16X3 (split bf16, fp32-class), EC_BF16 or EC_F16 (16-bit MFMA operands)");
+  m->bb_split = cfg->backbone_precision == EC_BF16X3;
+  m->bb16 = cfg->backbone_precision == EC_BF16 || cfg->backbone_precision == EC_F16;
+  m->bbf16 = cfg->backbone_precision == EC_F16;
   m->head_split = cfg->head_precision == EC_BF16X3;
   EC_REQUIRE(m->g >= 2 && m->g <= 32, EC_ERR_ARG, "token grid must be within 2..32");
   *out = m;
@@ -1015,6 +1069,10 @@ int ec_create(const ec_config* cfg, ec_handle* out) {
 int ec_destroy(ec_handle m) {
   if (!m) return EC_OK;
   for (void* p : m->owned) (void)hipFree(p);
+  if (m->d_edges) (void)hipFree(m->d_edges);
+  if (m->h_edges) (void)hipHostFree(m->h_edges);
+  if (m->h_off) (void)hipHostFree(m->h_off);
+  if (m->ev_edges) (void)hipEventDestroy(m->ev_edges);
   for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
   if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
   for (hipEvent_t e : {m->ev_fork, m->ev_sk, m->ev_join}) if (e) (void)hipEventDestroy(e);
@@ -1067,6 +1125,7 @@ int ec_finalize(ec_handle m) {
     m->patch.N = C; m->patch.K = m->Kp; m->patch.b = pb->dev;
     if ((rc = upload(m, Wp, &m->patch.w))) return rc;
     if (m->bb16 && (rc = upload16(m, Wp, &m->patch.w16))) return rc;
+    if (m->bb_split && (rc = upload_split(m, Wp.data(), C, m->Kp, &m->patch.ws))) return rc;
     GET(cls, bp + "cls_token"); GET(pos, "@pos_table");
     m->cls = cls->dev; m->pos = pos->dev;
     if ((rc = make_norm(m, bp + "norm", &m->bnorm))) return rc;
@@ -1174,6 +1233,7 @@ int ec_finalize(ec_handle m) {
   if ((rc = dalloc(m, &m->feat, (size_t)n * HW * C))) return rc;
   if ((rc = dalloc(m, &m->feat_nchw_tmp, (size_t)n * HW * C))) return rc;
   if ((rc = dalloc(m, &m->d_off, (size_t)bs + 1))) return rc;
+  EC_HIP(hipHostMalloc((void**)&m->h_off, ((size_t)bs + 1) * sizeof(int32_t), hipHostMallocDefault));
   const size_t Mk = (size_t)bs * K, Mi = (size_t)bs * HW, KK = (size_t)K * K;
   const int Fs = m->cfg.skel_ffn_dim, Fd = m->cfg.ffn_dim;
 #define WS(ptr, count) if ((rc = dalloc(m, &m->ptr, (size_t)(count)))) return rc
@@ -1188,7 +1248,7 @@ int ec_finalize(ec_handle m) {
   WS(p_fs, Mk * d); WS(p_fq, Mi * d); WS(p_g1, Mk * 128); WS(p_fs2, Mk * d);
   WS(d_qin, Mk * 2 * d); WS(d_sc, Mk * d); WS(d_rp, Mk * d); WS(d_bias, (size_t)bs * m->cfg.nhead * KK); WS(d_bias_all, (size_t)m->cfg.dec_layers * bs * m->cfg.nhead * KK); WS(d_qkv, Mk * 3 * d);
   WS(d_att, Mk * E); WS(d_tmp, Mk * d); WS(d_qc, Mk * E); WS(d_kv, Mi * 2 * E * m->cfg.dec_layers); WS(d_y, Mk * 2 * Fd); WS(d_z, Mk * Fd);
-  WS(d_hs, 3 * Mk * d); WS(d_pts, 4 * Mk * 2); WS(d_k1, Mk * d); WS(d_k2, Mk * d); WS(d_k3, Mk * d); WS(d_k4, Mk * d);
+  WS(d_hs, (size_t)m->cfg.dec_layers * Mk * d); WS(d_pts, (size_t)(m->cfg.dec_layers + 1) * Mk * 2); WS(d_k1, Mk * d); WS(d_k2, Mk * d); WS(d_k3, Mk * d); WS(d_k4, Mk * d);
 #undef WS
   EC_REQUIRE(m->pg_dyn0.N <= 128, EC_ERR_ARG, "dynamic_proj_dim must be <= 128");
   {
@@ -1325,7 +1385,7 @@ int ec_support_encode(ec_handle m, ec_support_t c, const float* const* img_s, co
   RUN(run_backbone(m, img_s, S, n_episodes, m->feat, st));
   c->n = n_episodes; c->S = S;
   RUN(tl_mark(m, "support-only", st));
-  RUN(run_head_support(m, fsp.data(), target_s, mask_s, n_episodes, S, st, c->ss));
+  RUN(join_on_error(m, run_head_support(m, fsp.data(), target_s, mask_s, n_episodes, S, st, c->ss)));
   return tl_dump(m);
 }
 
@@ -1349,7 +1409,7 @@ int ec_forward_cached(ec_handle m, ec_support_t c, const float* img_q, const int
   RUN(gather_rows(ws.adj1, c->ss.adj1, c->d_idx, KK, bs, 1, 0, 0, st));
   RUN(gather_rows(ws.adj_out, c->ss.adj_out, c->d_idx, 2 * KK, bs, 1, 0, 0, st));
   RUN(gather_rows(ws.attn_adj, c->ss.attn_adj, c->d_idx, KK, bs, m->cfg.max_hops + 1, (long)c->n * KK, (long)bs * KK, st));
-  return run_head_query(m, m->feat, bs, st, out, ws);
+  return join_on_error(m, run_head_query(m, m->feat, bs, st, out, ws));
 }
 
 // ---- on-device input pipeline ---------------------------------------------------------------
@@ -1430,13 +1490,14 @@ int ec_op_linear(const float* A, const float* W, const float* bias, const float*
   GemmP p;
   p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N; p.C = C; p.bias = bias; p.gamma = gamma; p.resid = resid; p.ldr = N;
   p.act = act;
-  if (precision == EC_BF16) {
+  if (precision == EC_BF16 || precision == EC_F16) {
+    const int f16 = precision == EC_F16;
     bf16_t *a16 = nullptr, *w16 = nullptr;
     EC_HIP(hipMalloc((void**)&a16, (size_t)M * K * 2));
     EC_HIP(hipMalloc((void**)&w16, (size_t)N * K * 2));
-    int rc = f32_to_bf16(A, a16, (long)M * K, st);
-    if (!rc) rc = f32_to_bf16(W, w16, (long)N * K, st);
-    p.A = a16; p.B = w16; p.ab_bf16 = 1;
+    int rc = f32_to_bf16(A, a16, (long)M * K, st, f16);
+    if (!rc) rc = f32_to_bf16(W, w16, (long)N * K, st, f16);
+    p.A = a16; p.B = w16; p.ab_bf16 = 1; p.h_f16 = f16;
     if (!rc) rc = gemm_nt(p, st);
     (void)hipStreamSynchronize(st);
     (void)hipFree(a16); (void)hipFree(w16);
@@ -1467,7 +1528,7 @@ int ec_op_gemm_bench(const void* A, const void* W, const float* bias, void* C, i
   hipStream_t st = (hipStream_t)stream;
   GemmP p;
   p.A = A; p.B = W; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N;
-  p.ab_bf16 = precision == EC_BF16; p.c_bf16 = p.ab_bf16;
+  p.ab_bf16 = precision == EC_BF16 || precision == EC_F16; p.c_bf16 = p.ab_bf16; p.h_f16 = precision == EC_F16;
   p.split = precision == EC_BF16X3;   // timing only: W is interpreted as an already split-packed buffer
   float* trace_buf = nullptr;
   if (getenv("EC_G8_TRACE")) {        // debug: phase timestamps of the 8-phase kernel (tools/g8_trace.py)
@@ -1521,9 +1582,10 @@ int ec_op_layernorm(const float* x, const float* w, const float* b, float* y, in
 
 int ec_op_attention(const float* q, const float* k, const float* v, const uint8_t* kmask, const float* bias, float* o, int B, int H,
                     int Lq, int Lk, int hd, int precision, void* stream) {
-  if (precision == EC_BF16) {
-    // test path: round q,k,v to bf16 on device, build V^T, run the bf16 kernel, widen the result
-    EC_REQUIRE(hd == 64 && !kmask && !bias, EC_ERR_ARG, "ec_op_attention(bf16): hd = 64, no mask / bias");
+  if (precision == EC_BF16 || precision == EC_F16) {
+    // test path: round q,k,v to the 16-bit format on device, run the 16-bit kernel, widen the result
+    const int f16 = precision == EC_F16;
+    EC_REQUIRE(hd == 64 && !kmask && !bias, EC_ERR_ARG, "ec_op_attention(bf16/fp16): hd = 64, no mask / bias");
     hipStream_t st = (hipStream_t)stream;
     const int E = H * hd;
     bf16_t *q16 = nullptr, *k16 = nullptr, *v16 = nullptr, *o16 = nullptr;
@@ -1531,21 +1593,21 @@ int ec_op_attention(const float* q, const float* k, const float* v, const uint8_
     EC_HIP(hipMalloc((void**)&k16, (size_t)B * Lk * E * 2));
     EC_HIP(hipMalloc((void**)&v16, (size_t)B * Lk * E * 2));
     EC_HIP(hipMalloc((void**)&o16, (size_t)B * Lq * E * 2));
-    int rc = f32_to_bf16(q, q16, (long)B * Lq * E, st);
-    if (!rc) rc = f32_to_bf16(k, k16, (long)B * Lk * E, st);
-    if (!rc) rc = f32_to_bf16(v, v16, (long)B * Lk * E, st);
+    int rc = f32_to_bf16(q, q16, (long)B * Lq * E, st, f16);
+    if (!rc) rc = f32_to_bf16(k, k16, (long)B * Lk * E, st, f16);
+    if (!rc) rc = f32_to_bf16(v, v16, (long)B * Lk * E, st, f16);
     AttnP a;
     a.Q = q16; a.K = k16; a.V = v16; a.O = o16;
     a.ldq = a.ldk = a.ldv = a.ldo = E;
     a.sQ = a.sO = (long)Lq * E; a.sK = a.sV = (long)Lk * E;
-    a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.hd = hd; a.bf16 = 1;
+    a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.hd = hd; a.bf16 = 1; a.f16 = f16;
     if (!rc) rc = attention(a, st);
     (void)hipStreamSynchronize(st);
     if (!rc) {
       std::vector<bf16_t> ho((size_t)B * Lq * E);
       std::vector<float> hf(ho.size());
       EC_HIP(hipMemcpy(ho.data(), o16, ho.size() * 2, hipMemcpyDeviceToHost));
-      for (size_t i = 0; i < ho.size(); ++i) hf[i] = bf2f(ho[i]);
+      for (size_t i = 0; i < ho.size(); ++i) hf[i] = f16 ? half2f_host(ho[i]) : bf2f(ho[i]);
       EC_HIP(hipMemcpy(o, hf.data(), hf.size() * 4, hipMemcpyHostToDevice));
     }
     (void)hipFree(q16); (void)hipFree(k16); (void)hipFree(v16); (void)hipFree(o16);

@@ -10,13 +10,14 @@ namespace ec {
 // Optional second output y2 (fp32) = y + table[row % period2] (encoder: `src + pos` of the NEXT layer).
 struct LnP {
   const float* x = nullptr; long ldx = 0;
-  void* y = nullptr; long ldy = 0; int y_bf16 = 0;
+  void* y = nullptr; long ldy = 0; int y_bf16 = 0;   // output format: 0 fp32, 1 bf16, 2 IEEE fp16
   const float* w = nullptr; const float* b = nullptr;
   int rows = 0, cols = 0; float eps = 1e-5f;
   int drop_period = 0;
   // optional fused residual add (bf16 backbone): x' = x + add (bf16 [rows, ldadd]); x' is written to xsum (may alias x,
   // same stride) and normalised.  Replaces the fp32 residual read-modify-write in the GEMM epilogue.
   const void* add = nullptr; long ldadd = 0;
+  int add_fmt = 0;              // 16-bit format of add / add2 (1 bf16, 2 fp16); 0 = the output's format (bf16 for fp32 output)
   const void* add2 = nullptr;   // optional second branch (same stride): x' = (x + add) + add2
   float* xsum = nullptr;        // null with add set: x' is normalised but not written back
 };
@@ -31,7 +32,7 @@ int mean_over(float* dst, const float* src, long stride, int n, long count, hipS
 // dst[o][b][0..row) = src[o][idx[b]][0..row) for b < n_rows, o < n_outer (outer strides in floats)
 int gather_rows(float* dst, const float* src, const int32_t* idx_dev, long row, int n_rows, int n_outer, long src_os, long dst_os,
                 hipStream_t st);
-int f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t st);
+int f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t st, int f16 = 0);   // f16: IEEE fp16 instead of bf16
 // src [B][L][E] fp32 -> dst [B][E][Lp] bf16 (columns >= L zeroed); test helper for the bf16 attention kernel
 int transpose_pad_bf16(const float* src, bf16_t* dst, int B, int L, int E, int Lp, hipStream_t st);
 int im2col14(const float* img, void* patches, int out_bf16, int n_img, int H, int g, int Kp, hipStream_t st);

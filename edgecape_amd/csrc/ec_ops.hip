@@ -11,8 +11,11 @@ namespace {
 // LayerNorm: one wave per row, float4 loads, values kept in registers (cols <= 1024).
 // Reference: DINOv2 norm1/norm2/norm (eps 1e-6), head LayerNorms (eps 1e-5, encoder_decoder.py:450-451,566-576).
 // ------------------------------------------------------------------------------------------------
-template <bool OUT_BF16, bool ADD>
+// OUT: 0 = fp32 output, 1 = bf16, 2 = IEEE fp16 (the fused branch inputs `add` / `add2` are in the same 16-bit format)
+template <int OUT, bool ADD, bool ADD_F16 = (OUT == 2)>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnP p) {
+  constexpr bool OUT_BF16 = OUT != 0;
+  constexpr bool F16 = OUT == 2;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.rows) return;
@@ -33,11 +36,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnP p) {
       if (ADD) {   // residual add fused in front of the norm: x <- x + branch (bf16 branch output of the previous GEMM)
         const bf16x4 a = *(const bf16x4*)((const bf16_t*)p.add + (long)row * p.ldadd + c);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[i][e] += bf2f((bf16_t)a[e]);
+        for (int e = 0; e < 4; ++e) v[i][e] += h2f<ADD_F16>((bf16_t)a[e]);
         if (p.add2) {   // a second pending branch: x <- (x + add) + add2, the same two fp32 additions as two separate passes
           const bf16x4 a2 = *(const bf16x4*)((const bf16_t*)p.add2 + (long)row * p.ldadd + c);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[i][e] += bf2f((bf16_t)a2[e]);
+          for (int e = 0; e < 4; ++e) v[i][e] += h2f<ADD_F16>((bf16_t)a2[e]);
         }
         if (p.xsum) *(f32x4*)(p.xsum + (long)row * p.ldx + c) = v[i];   // null: the sum is only normalised, x stays as it was
       }
@@ -69,10 +72,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnP p) {
       for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * w[e] + b[e];
       if (OUT_BF16) {
         bf16_t* y = (bf16_t*)p.y + orow * p.ldy + c;
-        bf16x4 h;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) h[e] = (short)f2bf(o[e]);
-        *(bf16x4*)y = h;
+        *(u32x2_t*)y = pack4_h<F16>(o);
       } else {
         *(f32x4*)((float*)p.y + orow * p.ldy + c) = o;
       }
@@ -119,9 +119,10 @@ __global__ void mean_over_kernel(float* dst, const float* src, long stride, int 
   dst[i] = s / (float)n;
 }
 
+template <bool F16>
 __global__ void f32_to_bf16_kernel(const float* src, bf16_t* dst, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = f2bf(src[i]);
+  if (i < n) dst[i] = f2h<F16>(src[i]);
 }
 
 __global__ void transpose_pad_bf16_kernel(const float* src, bf16_t* dst, int L, int E, int Lp) {
@@ -134,7 +135,7 @@ __global__ void transpose_pad_bf16_kernel(const float* src, bf16_t* dst, int L, 
 
 // im2col for Conv2d(3, C, k=14, s=14) (DINOv2 PatchEmbed): patches[(n*g+py)*g+px][c*196+ky*14+kx],
 // row length Kp >= 588 (zero padded) so the GEMM K is a multiple of 128 bytes.
-template <bool OUT_BF16>
+template <int OUT>   // 0 fp32, 1 bf16, 2 fp16
 __global__ void im2col14_kernel(const float* img, void* out, int H, int g, int Kp) {
   // output rows are TOKEN rows: image n owns rows n*(g*g+1) .. ; row 0 of each image (the cls token) is zero-filled so the
   // patch embedding is ONE GEMM over M = n_img * T contiguous rows (its cls rows are overwritten by set_cls_rows)
@@ -150,7 +151,7 @@ __global__ void im2col14_kernel(const float* img, void* out, int H, int g, int K
       const int c = k / 196, r = k % 196, ky = r / 14, kx = r % 14;
       v = src[((long)c * H + (py * 14 + ky)) * H + px * 14 + kx];
     }
-    if (OUT_BF16) ((bf16_t*)out)[orow * Kp + k] = f2bf(v);
+    if (OUT != 0) ((bf16_t*)out)[orow * Kp + k] = f2h<OUT == 2>(v);
     else ((float*)out)[orow * Kp + k] = v;
   }
 }
@@ -656,12 +657,18 @@ int layernorm(const LnP& p, hipStream_t st) {
   EC_REQUIRE(!p.add || p.ldadd % 4 == 0, -1, "layernorm: fused residual add needs a 4-aligned stride");
   EC_REQUIRE(!p.add2 || p.add, -1, "layernorm: add2 without add");
   const dim3 grid(cdiv(p.rows, 4));
+  // y_bf16: 0 fp32, 1 bf16, 2 fp16 output; a fused branch add is 16-bit in add_fmt's format (defaults to the output's, bf16 if fp32)
+  const int afmt = p.add_fmt ? p.add_fmt : (p.y_bf16 ? p.y_bf16 : 1);
+  EC_REQUIRE(!p.add || p.y_bf16 == 0 || afmt == p.y_bf16, -1, "layernorm: fused add and output must share the 16-bit format");
   if (p.add) {
-    if (p.y_bf16) hipLaunchKernelGGL((layernorm_kernel<true, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((layernorm_kernel<false, true>), grid, dim3(256), 0, st, p);
+    if (p.y_bf16 == 2) hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, dim3(256), 0, st, p);
+    else if (p.y_bf16 == 1) hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, dim3(256), 0, st, p);
+    else if (afmt == 2) hipLaunchKernelGGL((layernorm_kernel<0, true, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((layernorm_kernel<0, true, false>), grid, dim3(256), 0, st, p);
   } else {
-    if (p.y_bf16) hipLaunchKernelGGL((layernorm_kernel<true, false>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((layernorm_kernel<false, false>), grid, dim3(256), 0, st, p);
+    if (p.y_bf16 == 2) hipLaunchKernelGGL((layernorm_kernel<2, false>), grid, dim3(256), 0, st, p);
+    else if (p.y_bf16 == 1) hipLaunchKernelGGL((layernorm_kernel<1, false>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((layernorm_kernel<0, false>), grid, dim3(256), 0, st, p);
   }
   EC_LAUNCH_CHECK();
   return 0;
@@ -779,8 +786,9 @@ int mean_over(float* dst, const float* src, long stride, int n, long count, hipS
   return 0;
 }
 
-int f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t st) {
-  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, src, dst, n);
+int f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t st, int f16) {
+  if (f16) hipLaunchKernelGGL(f32_to_bf16_kernel<true>, dim3(cdiv(n, 256)), dim3(256), 0, st, src, dst, n);
+  else hipLaunchKernelGGL(f32_to_bf16_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, st, src, dst, n);
   EC_LAUNCH_CHECK();
   return 0;
 }
@@ -792,8 +800,9 @@ int transpose_pad_bf16(const float* src, bf16_t* dst, int B, int L, int E, int L
 }
 
 int im2col14(const float* img, void* patches, int out_bf16, int n_img, int H, int g, int Kp, hipStream_t st) {
-  if (out_bf16) hipLaunchKernelGGL(im2col14_kernel<true>, dim3(n_img * (g * g + 1)), dim3(256), 0, st, img, patches, H, g, Kp);
-  else hipLaunchKernelGGL(im2col14_kernel<false>, dim3(n_img * (g * g + 1)), dim3(256), 0, st, img, patches, H, g, Kp);
+  if (out_bf16 == 2) hipLaunchKernelGGL(im2col14_kernel<2>, dim3(n_img * (g * g + 1)), dim3(256), 0, st, img, patches, H, g, Kp);
+  else if (out_bf16) hipLaunchKernelGGL(im2col14_kernel<1>, dim3(n_img * (g * g + 1)), dim3(256), 0, st, img, patches, H, g, Kp);
+  else hipLaunchKernelGGL(im2col14_kernel<0>, dim3(n_img * (g * g + 1)), dim3(256), 0, st, img, patches, H, g, Kp);
   EC_LAUNCH_CHECK();
   return 0;
 }

@@ -33,7 +33,8 @@ class EdgeCape:
         self.backbone_precision, self.head_precision = backbone_precision, head_precision
         self._max_batch = max_batch
         self._state_dict = None
-        self._engines = {}
+        self._engines = {}          # (image_size, max_batch, shots, K) -> HipEngine, least recently used first
+        self.max_engines = 4
         self.training = False
 
     # ---- nn.Module-like surface used by the reference's callers -------------------------------------
@@ -82,7 +83,12 @@ class EdgeCape:
             raise RuntimeError("no weights loaded: call load_state_dict() / load_checkpoint() first")
         for key, eng in self._engines.items():
             if key[0] == image_size and key[3] == K and key[1] >= bs and key[2] >= shots:
+                self._engines[key] = self._engines.pop(key)      # most recently used goes last
                 return eng
+        # every engine owns a private copy of the weights and its workspace on the GPU: keep at most `max_engines` of them
+        # (K is dynamic in the demo path - one engine per clicked-point count would otherwise grow without bound)
+        while len(self._engines) >= self.max_engines:
+            self._engines.pop(next(iter(self._engines)))          # least recently used; its __del__ frees the device memory
         mb = max(bs, self._max_batch or 0)
         th = self.keypoint_head_module.transformer
         eng = HipEngine(self._state_dict, arch=self.pretrained, image_size=image_size, max_batch=mb, max_shots=shots,
@@ -118,57 +124,41 @@ class EdgeCape:
 
     def forward_test(self, img_s, target_s, target_weight_s, img_q, target_q=None, target_weight_q=None, img_metas=None,
                      vis_offset=True, **kwargs):
-        """EdgeCape.forward_test (EdgeCape.py:131-163)."""
-        batch_size, _, img_height, img_width = img_q.shape
+        """EdgeCape.forward_test (EdgeCape.py:131-163): same result dict (preds / boxes / image_paths / bbox_ids, points,
+        sample_image_file, skeleton).  The three device results the dict needs leave the GPU as three asynchronous copies
+        behind ONE stream synchronisation (the reference synchronises three times through .cpu())."""
+        height, width = img_q.shape[-2:]
         output, initial_proposals, similarity_map, mask_s, _, adj = self.predict(img_s, target_s, target_weight_s, img_q, img_metas)
-        predicted_pose = output[-1].cpu().numpy()             # device -> host boundary (EdgeCape.py:150)
-        result = {}
-        result.update(self.decode(img_metas, predicted_pose, img_size=[img_width, img_height]))
+        host = [t.to("cpu", non_blocking=True) for t in (output, initial_proposals, adj[0])]
+        torch.cuda.current_stream().synchronize()                 # device -> host boundary (EdgeCape.py:150)
+        layers, proposals, skeleton = (h.numpy() for h in host)
+        result = self.decode(img_metas, layers[-1], img_size=[width, height])
         if vis_offset:
-            result.update({"points": torch.cat((initial_proposals[None], output)).cpu().numpy()})
-        result.update({"sample_image_file": [img_metas[i]["sample_image_file"] for i in range(len(img_metas))]})
-        result.update({"skeleton": adj[0].cpu().numpy()})
+            result["points"] = np.concatenate((proposals[None], layers), 0)
+        result["sample_image_file"] = [m["sample_image_file"] for m in img_metas]
+        result["skeleton"] = skeleton
         return result
 
     def decode(self, img_metas, output, img_size, **kwargs):
-        """TwoStageHead.decode + transform_preds (head.py:324-387, post_transforms.py:150-194), host numpy."""
-        batch_size = len(img_metas)
-        W, H = img_size
-        output = output * np.array([W, H])[None, None, :]
-        bbox_ids = []
-        c = np.zeros((batch_size, 2), dtype=np.float32)
-        s = np.zeros((batch_size, 2), dtype=np.float32)
-        image_paths = []
-        score = np.ones(batch_size)
-        for i in range(batch_size):
-            c[i, :] = img_metas[i]["query_center"]
-            s[i, :] = img_metas[i]["query_scale"]
-            image_paths.append(img_metas[i]["query_image_file"])
-            if "query_bbox_score" in img_metas[i]:
-                score[i] = float(np.array(img_metas[i]["query_bbox_score"]).reshape(-1)[0])
-            if "bbox_id" in img_metas[i]:
-                bbox_ids.append(img_metas[i]["bbox_id"])
-            elif "query_bbox_id" in img_metas[i]:
-                bbox_ids.append(img_metas[i]["query_bbox_id"])
-        preds = np.zeros(output.shape)
-        use_udp = self.test_cfg.get("use_udp", False)
-        for idx in range(output.shape[0]):
-            scale = s[idx] * 200.0
-            if use_udp:
-                sx, sy = scale[0] / (W - 1.0), scale[1] / (H - 1.0)
-            else:
-                sx, sy = scale[0] / W, scale[1] / H
-            preds[idx, :, 0] = output[idx, :, 0] * sx + c[idx, 0] - scale[0] * 0.5
-            preds[idx, :, 1] = output[idx, :, 1] * sy + c[idx, 1] - scale[1] * 0.5
-        all_preds = np.zeros((batch_size, preds.shape[1], 3), dtype=np.float32)
-        all_boxes = np.zeros((batch_size, 6), dtype=np.float32)
-        all_preds[:, :, 0:2] = preds[:, :, 0:2]
-        all_preds[:, :, 2:3] = 1.0
-        all_boxes[:, 0:2] = c[:, 0:2]
-        all_boxes[:, 2:4] = s[:, 0:2]
-        all_boxes[:, 4] = np.prod(s * 200.0, axis=1)
-        all_boxes[:, 5] = score
-        return dict(preds=all_preds, boxes=all_boxes, image_paths=image_paths, bbox_ids=bbox_ids)
+        """TwoStageHead.decode + transform_preds (head.py:324-387, post_transforms.py:150-194) for the whole batch at once:
+        normalised [bs,K,2] coordinates -> pixels of the model input -> pixels of the source image through each query's
+        (center, scale) box.  dtypes follow the reference (float32 box, float64 coordinates) so `boxes` is bit-identical."""
+        n = len(img_metas)
+        size = np.asarray(img_size, np.float64)                                         # [W, H]
+        center = np.array([m["query_center"] for m in img_metas], np.float32).reshape(n, 2)
+        scale = np.array([m["query_scale"] for m in img_metas], np.float32).reshape(n, 2)
+        score = np.array([float(np.asarray(m["query_bbox_score"]).reshape(-1)[0]) if "query_bbox_score" in m else 1.0
+                          for m in img_metas], np.float32)
+        box = scale * np.float32(200.0)                                                 # bbox side lengths in source pixels
+        denom = (size - 1.0) if self.test_cfg.get("use_udp", False) else size
+        per_px = box / denom.astype(np.float32)                                         # source pixels per model-input pixel
+        xy = np.asarray(output, np.float64) * size                                      # model-input pixels
+        xy = xy * per_px[:, None, :] + center[:, None, :] - (box * np.float32(0.5))[:, None, :]
+        preds = np.ones((n, xy.shape[1], 3), np.float32)
+        preds[:, :, :2] = xy
+        boxes = np.concatenate([center, scale, np.prod(box, axis=1, keepdims=True), score[:, None]], 1).astype(np.float32)
+        ids = [m["bbox_id"] if "bbox_id" in m else m["query_bbox_id"] for m in img_metas if "bbox_id" in m or "query_bbox_id" in m]
+        return dict(preds=preds, boxes=boxes, image_paths=[m["query_image_file"] for m in img_metas], bbox_ids=ids)
 
 
 from .checkpoint import load_checkpoint  # noqa: E402,F401  (mmcv.runner.load_checkpoint stand-in, test.py:124)

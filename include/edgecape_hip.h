@@ -51,7 +51,9 @@ enum ec_status {
 enum ec_precision {
   EC_F32 = 0,     /* fp32 operands, exact products (v_mfma_f32_32x32x2_f32) */
   EC_BF16 = 1,    /* bf16 operands, fp32 accumulate */
-  EC_BF16X3 = 2   /* fp32 data, each operand split into hi+lo bf16, 3 bf16 MFMAs per product: ~2^-17 relative (head only) */
+  EC_BF16X3 = 2,  /* fp32 data, each operand split into hi+lo bf16, 3 bf16 MFMAs per product: ~2^-17 relative (head only) */
+  EC_F16 = 3      /* IEEE fp16 operands (11 significand bits, same MFMA rate as bf16), fp32 accumulate: the backbone mode that
+                     keeps output_kpts inside the 1e-3 tolerance at bf16 speed (backbone only) */
 };
 enum ec_dtype { EC_DT_F32 = 0, EC_DT_F16 = 1, EC_DT_BF16 = 2, EC_DT_F64 = 3 };
 enum ec_layout { EC_LAYOUT_TOKENS = 0, EC_LAYOUT_NCHW = 1 };
@@ -88,7 +90,12 @@ typedef struct ec_outputs {
 } ec_outputs;
 
 const char* ec_last_error(void);
+/* ABI version of the library (EC_ABI_VERSION of the header it was built from): bumped whenever a struct layout, an enum value
+   or a signature changes, so a binding can refuse a stale prebuilt library instead of calling it with mismatched layouts. */
+#define EC_ABI_VERSION 2
 int ec_version(void);
+/* sizeof(ec_config) / sizeof(ec_outputs) as the library was compiled: a binding compares them with its own mirrors. */
+int ec_abi_sizes(int* config_bytes, int* outputs_bytes);
 
 int ec_create(const ec_config* cfg, ec_handle* out);
 int ec_destroy(ec_handle h);

@@ -292,3 +292,95 @@ def test_bgemm(lib, batch, M, N, K, transB):
     torch.cuda.synchronize()
     err = (Cd.cpu() - ref).abs().max().item()
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+# ---- IEEE fp16 operand format (backbone_precision = "fp16": 11 significand bits at the bf16 MFMA rate) --------------------
+@pytest.mark.parametrize("M,N,K", [(650, 1152, 384), (1300, 768, 768), (4099, 2304, 768), (1024, 256, 3072), (5000, 1536, 128)])
+def test_linear_fp16(lib, M, N, K):
+    """fp16-operand GEMM (v_mfma_f32_16x16x32_f16 in the 8-phase kernel, 32x32x16 in the small-shape kernels) vs exact
+    products of the fp16-rounded operands."""
+    g = torch.Generator().manual_seed(2)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    ref = (A.half().double() @ W.half().double().T + b.double()).float()
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
+    Cd = torch.empty(M, N, device="cuda")
+    _chk(lib, lib.ec_op_linear(_p(Ad), _p(Wd), _p(bd), None, None, _p(Cd), M, N, K, 0, 3, None))
+    torch.cuda.synchronize()
+    err = (Cd.cpu() - ref).abs().max().item()
+    assert err < 2e-4, err   # fp32 accumulation-order noise only
+
+
+@pytest.mark.parametrize("act", [0, 2])
+def test_linear_fp16_epilogue(lib, act):
+    M, N, K = 2500, 768, 256
+    g = torch.Generator().manual_seed(17 + act)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    gam = torch.rand(N, generator=g) + 0.5
+    R = torch.randn(M, N, generator=g)
+    ref = A.half().double() @ W.half().double().T + b.double()
+    ref = {0: ref, 2: torch.nn.functional.gelu(ref)}[act]
+    ref = (ref * gam.double() + R.double()).float()
+    Ad, Wd, bd, gd, Rd = (x.cuda() for x in (A, W, b, gam, R))
+    Cd = torch.empty(M, N, device="cuda")
+    _chk(lib, lib.ec_op_linear(_p(Ad), _p(Wd), _p(bd), _p(gd), _p(Rd), _p(Cd), M, N, K, act, 3, None))
+    torch.cuda.synchronize()
+    err = (Cd.cpu() - ref).abs().max().item()
+    assert err < 2e-4, err
+
+
+def test_linear_fp16_conversion_edge_values(lib):
+    """Device conversion (v_cvt_pk_f16_f32, RNE) on values around the fp16 subnormal / overflow boundaries, through a GEMM with
+    an identity weight: C = fp16(A) exactly."""
+    K = 128
+    vals = torch.tensor([0.0, 1.0, -1.0, 65504.0, 65519.0, 6.1e-5, 5.96e-8, 2.98e-8, 3.1e-8, 1.0 + 2 ** -11, 1.0 + 3 * 2 ** -11,
+                         0.1, -0.3333333, 1e-3, 123.456, 2049.0])
+    A = vals.repeat(1024 * K // vals.numel()).reshape(1024, K).contiguous()
+    W = torch.eye(K).repeat(2, 1)                                       # N = 256 rows: [I; I]
+    Cd = torch.empty(1024, 256, device="cuda")
+    Ad, Wd = A.cuda(), W.cuda()                                          # keep the device tensors alive across the call
+    _chk(lib, lib.ec_op_linear(_p(Ad), _p(Wd), None, None, None, _p(Cd), 1024, 256, K, 0, 3, None))
+    torch.cuda.synchronize()
+    assert torch.equal(Cd.cpu()[:, :K], A.half().float())
+    assert torch.equal(Cd.cpu()[:, K:], A.half().float())
+
+
+@pytest.mark.parametrize("B,H,L", [(2, 12, 325), (1, 16, 730), (2, 6, 257), (1, 6, 33)])
+def test_attention_fp16(lib, B, H, L):
+    """fp16 MFMA attention (backbone shape) vs fp64 math on the fp16-rounded operands: ~8x tighter than the bf16 form."""
+    hd = 64
+    g = torch.Generator().manual_seed(L + 1)
+    q = torch.randn(B, L, H * hd, generator=g)
+    k = torch.randn(B, L, H * hd, generator=g)
+    v = torch.randn(B, L, H * hd, generator=g)
+    r16 = lambda x: x.half().float()
+    ref = _attn_ref(r16(q), r16(k), r16(v), H, hd, None, None)
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    od = torch.empty(B, L, H * hd, device="cuda")
+    _chk(lib, lib.ec_op_attention(_p(qd), _p(kd), _p(vd), None, None, _p(od), B, H, L, L, hd, 3, None))
+    torch.cuda.synchronize()
+    err = (od.cpu() - ref).abs().max().item()
+    assert err < 3e-3, err            # P and O rounded to fp16 (11 significand bits)
+    assert (od.cpu() - ref).abs().mean().item() < 3e-4
+
+
+def test_attention_fp16_large_logits(lib):
+    """Scores far apart (|q.k| up to ~60 after scaling): the lazy running maximum keeps P <= 2^8, inside the fp16 range, and the
+    rescale branch is exercised by a key row that dominates only in a late tile."""
+    B, H, L, hd = 1, 6, 325, 64
+    g = torch.Generator().manual_seed(9)
+    q = torch.randn(B, L, H * hd, generator=g) * 2.0
+    k = torch.randn(B, L, H * hd, generator=g) * 2.0
+    v = torch.randn(B, L, H * hd, generator=g)
+    k[:, 300] = q[:, 5] * 1.5             # key 300 (last tile) dominates query 5 -> forces a late rescale
+    r16 = lambda x: x.half().float()
+    ref = _attn_ref(r16(q), r16(k), r16(v), H, hd, None, None)
+    od = torch.empty(B, L, H * hd, device="cuda")
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    _chk(lib, lib.ec_op_attention(_p(qd), _p(kd), _p(vd), None, None, _p(od), B, H, L, L, hd, 3, None))
+    torch.cuda.synchronize()
+    assert torch.isfinite(od).all()
+    assert (od.cpu() - ref).abs().max().item() < 5e-3
