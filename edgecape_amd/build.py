@@ -49,12 +49,18 @@ def needs_build():
         return f.read().strip() != source_hash()
 
 
-def build(force=False, verbose=True):
+def build_lab(verbose=True):
+    """Kernel-lab build (tools/g8_lab.py): the same sources with -DEC_G8_LAB (ablated instantiations of the 8-phase GEMM and their
+    timing entry point) into libedgecape_hip_lab.so.  Never loaded by the product path."""
+    return build(force=True, verbose=verbose, lab=True)
+
+
+def build(force=False, verbose=True, lab=False):
     """Compile every .hip source for gfx950 and link the C-ABI shared library. Returns its path."""
-    if not force and not needs_build():
+    if not force and not lab and not needs_build():
         return LIB
     cc = hipcc_path()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build", "lab") if lab else os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
@@ -62,16 +68,21 @@ def build(force=False, verbose=True):
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         cmd = [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-c", s, "-o", o]
+        if lab:
+            cmd.insert(1, "-DEC_G8_LAB")
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for cmd, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + out)
-    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
+    out = LIB.replace(".so", "_lab.so") if lab else LIB
+    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out + ".tmp"] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed: " + " ".join(cmd) + "\n" + r.stdout)
-    os.replace(LIB + ".tmp", LIB)
+    os.replace(out + ".tmp", out)
+    if lab:
+        return out
     with open(STAMP, "w") as f:
         f.write(source_hash() + "\n")
     if verbose:
@@ -80,4 +91,7 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--lab" in sys.argv:
+        print(build_lab())
+    else:
+        build(force="--force" in sys.argv)

@@ -598,6 +598,33 @@ int gemm_nt(const GemmP& p, hipStream_t st) {
   }
 }
 
+#ifdef EC_G8_LAB
+// Lab build only: time one fixed configuration of gemm_nt_kernel (bf16) - cfg 0: 256x256, 8 waves (2x4); cfg 1: 256x256, 4 waves (2x2,
+// 128x128 per wave, one wave per SIMD)
+extern "C" int ec_lab_gemm_nt(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int cfg, int iters,
+                              void* stream, float* ms) {
+  GemmP p;
+  p.A = A; p.B = W; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N; p.ab_bf16 = 1; p.c_bf16 = 1;
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  EC_HIP(hipEventCreate(&e0));
+  EC_HIP(hipEventCreate(&e1));
+  for (int i = 0; i <= iters; ++i) {
+    if (i == 1) EC_HIP(hipEventRecord(e0, st));
+    int rc = cfg == 1 ? launch_cfg<GM_BF16, 256, 256, 2, 2, 2>(p, st, 1) : launch_cfg<GM_BF16, 256, 256, 2, 4, 2>(p, st, 1);
+    if (rc) return rc;
+  }
+  EC_HIP(hipEventRecord(e1, st));
+  EC_HIP(hipEventSynchronize(e1));
+  float t = 0.f;
+  EC_HIP(hipEventElapsedTime(&t, e0, e1));
+  *ms = t / (float)iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return 0;
+}
+#endif
+
 void split_pack_weights(const float* W, long n_rows, long K, float* out) {
   for (long r = 0; r < n_rows; ++r)
     for (long kb = 0; kb < K / 32; ++kb) {

@@ -8,8 +8,9 @@
 // Structure (MI355X-first; cdna_hip_programming.md §5 "256² 8-phase"):
 //   * 256x256 output tile, K step 64, one 512-thread workgroup per CU (8 waves = 2 (M) x 4 (N), 128x64 per wave,
 //     v_mfma_f32_16x16x32_bf16, 128 fp32 accumulator registers per lane), persistent over an XCD-contiguous tile range.
-//   * operands go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip) as HALF-TILES of 128 rows x 128 B;
-//     a K-tile is four half-tiles (A-h0, B-h0, B-h1, A-h1), LDS holds two K-tiles (128 KiB) + one 16 KiB dummy slot.
+//   * operands go HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, no VGPR round trip) as HALF-TILES of 128 rows x 128 B;
+//     a K-tile is four half-tiles (A-h0, B-h0, B-h1, A-h1), LDS holds two K-tiles (128 KiB), the per-wave output staging
+//     slots (16 KiB) and the bias / LayerScale slices of two tiles (8 KiB).
 //     The LDS image is [16 rows][64 B] sub-tiles, 32-byte XOR-swizzled for rows 8..15 (conflict-free ds_read_b128); since
 //     LDS-DMA writes lane-linear, the swizzle is applied to the per-lane SOURCE address and undone by the readers.
 //   * the K loop is a sequence of PHASES, one accumulator quadrant (64x32, 16 MFMAs) each:
@@ -24,8 +25,8 @@
 //     WAR: a slot is re-staged >= 3 phases after its last ds_read.
 //   * 16x16x32 MFMAs, not 32x32x16: 32x32 variants of this kernel measured 8-9 % slower (1245-1265 vs 1360-1375 TFLOP/s at
 //     8192^3, with one quadrant per phase and with two) although the 32x32 form has the higher isolated rate.  Phase
-//     timestamps (EC_G8_TRACE, tools/g8_trace.py): a 16-MFMA block issues in ~320 cycles (20 per MFMA = the 16x16 form's
-//     own rate), barrier-to-barrier ~450; two 32-MFMA phases per K-tile (EC_G8_2PH=1) gain 2 % at 8192^3, nothing at K = 768.
+//     timestamps (round 1): a 16-MFMA block issues in ~320 cycles (20 per MFMA = the 16x16 form's own rate), barrier-to-barrier
+//     ~450; two 32-MFMA phases per K-tile gain 2 % at 8192^3, nothing at K = 768.
 //   * MFMA roles are swapped (A-operand <- weight rows n, B-operand <- activation rows m) so an accumulator lane holds one
 //     output row and 4 consecutive columns: the epilogue (bias / pos-table / GELU / LayerScale / residual / bf16 pack)
 //     works on 16-byte row segments.
@@ -36,6 +37,7 @@
 namespace ec {
 namespace {
 
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
@@ -44,8 +46,10 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16v4;
 
 constexpr int G8_HALF = 16384;            // half-tile: 128 rows x 128 B
 constexpr int G8_KT = 4 * G8_HALF;        // K-tile: A-h0 | B-h0 | B-h1 | A-h1
-constexpr int G8_STAGE = 2 * G8_KT;       // 8 x 4 KiB: per-wave output staging; also the dummy target of the stream's tail
-constexpr int G8_LDS = 2 * G8_KT + 8 * 4096;   // 160 KiB, the whole CU
+constexpr int G8_STAGE = 2 * G8_KT;       // 8 x 2 KiB: per-wave output staging (one 16-row x 64-column piece at a time)
+constexpr int G8_BIAS = G8_STAGE + 8 * 2048;    // 2 tile parities x 8 waves x 256 B: this wave's 64 bias values (LDS-DMA, one tile ahead)
+constexpr int G8_GAMMA = G8_BIAS + 2 * 8 * 256;  // same for the LayerScale vector
+constexpr int G8_LDS = G8_GAMMA + 2 * 8 * 256;   // 152 KiB
 constexpr int G8_AHEAD = 5;               // half-tiles the load stream runs ahead
 
 #define G8_SB() __builtin_amdgcn_sched_barrier(0)
@@ -80,116 +84,121 @@ __device__ __forceinline__ float gelu_fast8(float x) {
   return x * __builtin_amdgcn_rcpf(1.f + e);
 }
 
-// acc[mi][ni] (f32x4) of lane l: row m = m0 + wr*128 + (mi>>2)*64 + (mi&3)*16 + (l&15),
+// acc[mi][ni] (f32x4) of lane l: row m = m0 + wr*128 + mi*16 + (l&15),
 //                                cols n = n0 + wc*64 + (ni>>1)*32 + (ni&1)*16 + (l>>4)*4 .. +3
-template <int KIND, bool FULL, bool F16>
-__device__ __forceinline__ void g8_epilogue(const GemmP& p, f32x4 (&acc)[8][4], char* smem, int m0, int n0, int wr, int wc, int lane) {
+// GENERIC epilogue (fp32 output, residual, positional table, any activation): the patch embedding and the op-level tests.  It
+// runs at the end of the tile behind a full drain of the load stream (its bias / table / residual loads retire in order behind
+// the LDS-DMA half-tiles) - the seam the pipelined epilogue below removes for the backbone's block GEMMs.
+template <bool F16>
+__device__ __forceinline__ void g8_epilogue_generic(const GemmP& p, f32x4 (&acc)[8][4], int m0, int n0, int wr, int wc, int lane) {
   const int ncol = n0 + wc * 64 + (lane >> 4) * 4;
   const int mrow = m0 + wr * 128 + (lane & 15);
-  if constexpr (KIND == G8_GENERIC) {
-    f32x4 bias4[4], gam4[4];
+  f32x4 bias4[4], gam4[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int n = ncol + (ni >> 1) * 32 + (ni & 1) * 16;
+    const bool nok = n < p.N;
+    bias4[ni] = (p.bias && nok) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    gam4[ni] = (p.gamma && nok) ? *(const f32x4*)(p.gamma + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile-seam drain, after the bias loads were issued
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int m = mrow + mi * 16;
+    if (m >= p.M) continue;
+    const float* trow = p.table ? p.table + (long)(m % p.period) * p.ldt : nullptr;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int n = ncol + (ni >> 1) * 32 + (ni & 1) * 16;
-      const bool nok = n < p.N;
-      bias4[ni] = (p.bias && nok) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-      gam4[ni] = (p.gamma && nok) ? *(const f32x4*)(p.gamma + n) : f32x4{1.f, 1.f, 1.f, 1.f};
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile-seam drain (see the kernel), after the bias loads were issued
+      if (n >= p.N) continue;
+      f32x4 v = acc[mi][ni] + bias4[ni];
+      if (trow) v += *(const f32x4*)(trow + n);
+      if (p.act == ACT_RELU) {
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-      const int m = mrow + (mi >> 2) * 64 + (mi & 3) * 16;
-      if (m >= p.M) continue;
-      const float* trow = p.table ? p.table + (long)(m % p.period) * p.ldt : nullptr;
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (p.act == ACT_GELU) {
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int n = ncol + (ni >> 1) * 32 + (ni & 1) * 16;
-        if (n >= p.N) continue;
-        f32x4 v = acc[mi][ni] + bias4[ni];
-        if (trow) v += *(const f32x4*)(trow + n);
-        if (p.act == ACT_RELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (p.act == ACT_GELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = p.c_bf16 ? gelu_fast8<F16>(v[e]) : gelu_erf(v[e]);
-        }
-        v *= gam4[ni];
-        if (p.resid) v += *(const f32x4*)(p.resid + (long)m * p.ldr + n);
-        if (p.c_bf16) {
-          *(u32x2*)((char*)p.C + ((long)m * p.ldc + n) * 2) = pack4_h<F16>(v);
-        } else {
-          *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = v;
-        }
+        for (int e = 0; e < 4; ++e) v[e] = p.c_bf16 ? gelu_fast8<F16>(v[e]) : gelu_erf(v[e]);
       }
-    }
-  } else {
-    // bf16 output, bias (+ LayerScale gamma | GELU): no runtime branches, 32-bit offsets from a uniform base,
-    // immediate column offsets.  (host checks M * ldc * 2 < 2^31)
-    f32x4 bias4[4], gam4[4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int n = ncol + (ni >> 1) * 32 + (ni & 1) * 16;
-      const bool nok = FULL || n < p.N;
-      bias4[ni] = nok ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (KIND == G8_SCALE_BF16) gam4[ni] = nok ? *(const f32x4*)(p.gamma + n) : f32x4{1.f, 1.f, 1.f, 1.f};
-    }
-    // tile-seam drain: one wait covers the bias loads just issued AND every LDS-DMA half-tile still in flight
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // Stores go through a per-wave 4 KiB LDS staging slot: a piece = 32 rows x 64 columns of bf16 (two m-fragments) is
-    // written fragment-wise (8 x ds_write_b64, 16-byte chunks XOR-swizzled by row) and read back row-wise
-    // (4 x ds_read_b128), so every global store instruction writes 8 full 128-byte lines (16 B per lane) instead of 16
-    // quarter lines (8 B per lane): the dwordx2 form is store-issue bound at ~7 B/clk/CU (MI355X_MICROARCH.md).
-    char* const Cb = (char*)p.C;
-    const unsigned ldc2 = (unsigned)p.ldc * 2u;
-    const int wave = wr * 4 + wc;
-    char* const stg = smem + G8_STAGE + wave * 4096;
-    const int wrow = lane & 15, wq = lane >> 4;                       // writer: fragment row, column quad
-    const int rrow = lane >> 3, rch = lane & 7;                       // reader: row within 8, 16-byte chunk
-    const unsigned goff0 = (unsigned)(m0 + wr * 128 + rrow) * ldc2 + (unsigned)(n0 + wc * 64) * 2u + (unsigned)rch * 16u;
-#pragma unroll
-    for (int pc = 0; pc < 4; ++pc) {
-#pragma unroll
-      for (int mm = 0; mm < 2; ++mm) {
-        const int mi = pc * 2 + mm;
-        const int row = mm * 16 + wrow;
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          f32x4 v = acc[mi][ni] + bias4[ni];
-          if constexpr (KIND == G8_GELU_BF16) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_fast8<F16>(v[e]);
-          }
-          if constexpr (KIND == G8_SCALE_BF16) v *= gam4[ni];
-          const u32x2 o = pack4_h<F16>(v);   // 2 x v_cvt_pk_{bf16,f16}_f32 (RNE)
-          const int chunk = (ni >> 1) * 4 + (ni & 1) * 2 + (wq >> 1);
-          *(u32x2*)(stg + row * 128 + ((chunk ^ (row & 7)) << 4) + (wq & 1) * 8) = o;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = j * 8 + rrow;
-        const u32x4 o = *(const u32x4*)(stg + row * 128 + ((rch ^ (row & 7)) << 4));
-        const int mloc = pc * 32 + row;                                // row inside the wave's 128
-        const bool ok = FULL || ((m0 + wr * 128 + mloc < p.M) && (n0 + wc * 64 + rch * 8 < p.N));
-        if (ok) *(u32x4*)(Cb + goff0 + (unsigned)(pc * 32 + j * 8) * ldc2) = o;
+      v *= gam4[ni];
+      if (p.resid) v += *(const f32x4*)(p.resid + (long)m * p.ldr + n);
+      if (p.c_bf16) {
+        *(u32x2*)((char*)p.C + ((long)m * p.ldc + n) * 2) = pack4_h<F16>(v);
+      } else {
+        *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = v;
       }
     }
   }
 }
 
-// TRACE (debug instantiation only, EC_G8_TRACE=1): lane 0 of every wave of workgroup 0 stamps s_memtime at five points of
-// every phase of one K-tile pair into its LDS staging slot; dumped to p.aux after the first tile (tools/g8_trace.py).
-// ONEBAR (EC_G8_1BAR=1, A/B only - measured SLOWER: 8192^3 1300 vs 1355 TFLOP/s, QKV 1029 vs 1111-1139): one barrier per phase instead of two.  Group 0 keeps only the barrier AFTER its MFMA block, group 1 only the one BEFORE
-// its MFMA block, so physical barrier #p is {group 0 done with M_p, group 1 done with R_p}: inside one barrier interval group 0
-// runs R_p then M_p while group 1 runs M_(p-1) then R_p - the same matrix-pipe / memory-pipe alternation on every SIMD with half
-// the barrier releases.  RAW: half-tile i is waited for (vmcnt) in every wave's R_(i-2), barrier #(i-2) follows that wait in
-// both groups and precedes every read of it (R_(i-1) at the earliest).  WAR: slot of half-tile i-8 is re-staged in R_(i-5);
-// its last reads (R_(<=i-8)) were retired before barrier #(i-7) in both groups.
-template <int KIND, int TAG, bool F16 = false, bool TRACE = false>
+// One PIECE of the pipelined epilogue (16-bit output kinds): the m-fragment `a` = acc[mi][0..3] of this lane's wave, i.e. 16
+// rows x 64 columns.  bias (+ GELU | LayerScale) from this wave's LDS slices, 16-bit pack (RNE), transposition through the wave's
+// 2 KiB staging slot (fragment-wise ds_write_b64, 16-byte chunks XOR-swizzled by row; row-wise ds_read_b128), then TWO global
+// stores of 16 B per lane = 8 full 128-byte lines each (fragment-wise 8-byte stores would be quarter lines and twice the
+// instructions: global stores issue at ~70 cycles per wave-instruction per CU whatever their width).  The accumulators are
+// zeroed on the way out: the next tile accumulates into them.
+//   goff: byte offset in C of (row m0 + wr*128 + mi*16 + (lane>>3), column n0 + wc*64 + (lane&7)*8); rows_ok: valid rows of the
+//   piece (M edge); col_ok: this lane's 8 columns are inside N.
+template <int KIND, bool F16, int LAB>
+__device__ __forceinline__ void g8_piece(f32x4 (&a)[4], char* Cb, unsigned goff, unsigned ldc2, int rows_ok, bool col_ok, char* stg,
+                                         const char* bias_lds, const char* gam_lds, int lane) {
+  const int wrow = lane & 15, wq = lane >> 4;                       // writer: fragment row, column quad
+  const int rrow = lane >> 3, rch = lane & 7;                       // reader: row within 8, 16-byte chunk
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int c0 = (ni >> 1) * 32 + (ni & 1) * 16 + wq * 4;         // first of this lane's 4 columns inside the wave's 64
+    f32x4 v = a[ni] + *(const f32x4*)(bias_lds + c0 * 4);
+    if constexpr (KIND == G8_GELU_BF16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_fast8<F16>(v[e]);
+    }
+    if constexpr (KIND == G8_SCALE_BF16) v *= *(const f32x4*)(gam_lds + c0 * 4);
+    const int chunk = (ni >> 1) * 4 + (ni & 1) * 2 + (wq >> 1);
+    *(u32x2*)(stg + wrow * 128 + ((chunk ^ (wrow & 7)) << 4) + (wq & 1) * 8) = pack4_h<F16>(v);   // 2 x v_cvt_pk (RNE)
+    a[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = j * 8 + rrow;
+    const u32x4 o = *(const u32x4*)(stg + row * 128 + ((rch ^ (row & 7)) << 4));
+    if constexpr (LAB & 1) { asm volatile("" ::"v"(o)); continue; }   // lab build only: epilogue without the global stores
+    if (col_ok && row < rows_ok) *(u32x4*)(Cb + goff + (unsigned)(j * 8) * ldc2) = o;
+  }
+}
+
+// Lane id recomputed in place (two VALU, no live range): values derived from the kernel's `lane` and kept across the K loop get
+// spilled at 256 VGPRs, and a spill reload is a VMEM load whose wait drains the LDS-DMA stream.
+__device__ __forceinline__ int g8_lane_now() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
+template <int N> __device__ __forceinline__ void g8_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// LAB (0 in the shipped library; other values are only instantiated under -DEC_G8_LAB by tools/g8_lab.py): ablations for
+// locating the bottleneck - 1 no global stores, 2 every tile loads tile 0's operands (L2-resident), 4 no LDS-DMA in the steady
+// state, 8 no MFMAs, 32 no epilogue at all, 64 the load stream is drained at the tile seam (the round-1 seam, for A/B).
+//
+// Tile seam of the 16-bit output kinds (KIND != GENERIC): the epilogue runs at the END of the tile, both wave groups at once
+// (all four SIMDs convert and store), and NOTHING is drained: the bias / LayerScale slices come from LDS (one small LDS-DMA per
+// wave, issued a whole tile ahead), the next tile's operand stream keeps running 5 half-tiles ahead through the epilogue, and
+// the counted waits of the next tile's first three phases are widened by the 16 stores per wave that sit between the half-tiles
+// in the in-order VM queue:
+//     after issuing stream index q+5 in phase q, index q+2 (issued in phase q-3) must have landed; everything younger may stay in
+//     flight: the 6 LDS-DMA pieces of q+3..q+5, the 16 stores if they were issued after phase q-3, the bias pieces after theirs.
+// Measured against this (tools/g8_lab.py, same process, QKV shape): the seam with a drain 64-65 us; this epilogue PIPELINED into
+// the memory segments of the last / first K-tile's phases (two pieces per phase, partner group in its MFMA block) 74-76 us (fc1 +
+// GELU 117 vs 101 us): work moved into one wave's memory segment stretches that barrier interval for the partner's MFMA block too
+// (MI355X_MICROARCH.md "Two waves per SIMD", item 3), so it was removed.  Also rejected in round 1: one barrier per phase with the
+// groups half a phase apart (8192^3 1300 vs 1355 TFLOP/s) and two 32-MFMA phases per K-tile (+2 % at 8192^3, 0 at K = 768).
+template <int KIND, int TAG, bool F16 = false, int LAB = 0>
 __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
-  constexpr bool TWOPH = false, ONEBAR = false;   // rejected schedules (see the header comment), kept out of the build
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool FAST = KIND != G8_GENERIC && !(LAB & 32);   // bias from LDS, epilogue pieces through the staging slot
+  constexpr bool NODRAIN = FAST && !(LAB & 64);              // the load stream is not drained at the seam
+  constexpr int NB = KIND == G8_SCALE_BF16 ? 2 : 1;          // LDS-DMA pieces of one bias (+ LayerScale) slice
+  constexpr int NST = 16;                                    // global stores of one tile's epilogue per wave
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -212,142 +221,108 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   // ---- load stream (LDS-DMA) state -------------------------------------------------------------------------------
   // wave w stages row-group w (16 rows) of every half-tile, both 64-byte K halves (2 wave-instructions of 1 KiB).
   // lane -> row r = lane>>2 of the row-group, physical 16-B chunk lane&3 which holds logical chunk (lane&3) ^ 2*(r>=8).
-  const int ld_r = lane >> 2;
-  const int ld_c = ((lane & 3) ^ ((lane >> 5) << 1)) << 4;
-  const char* rp0; const char* rp1; const char* rp2; const char* rp3;   // A-h0, B-h0, B-h1, A-h1 row pointers (+ chunk)
+  // The stream uses buffer loads to LDS (buffer_load_dwordx4 ... lds): one 128-bit descriptor per operand in SGPRs, a 32-bit
+  // per-lane byte offset of the lane's row + chunk (fixed for a whole output tile) and the K position as the scalar offset -
+  // four offset VGPRs instead of four 64-bit row pointers, no per-issue address arithmetic.
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, -1, 0x00020000);   // (host: operand bytes < 4 GiB)
+  unsigned vo0, vo1, vo2, vo3;                       // A-h0, B-h0, B-h1, A-h1: byte offset of this lane's row (+ chunk)
   int ls_kt = 0, ls_tile = t_first;
-  bool ls_live = true;
   auto set_rows = [&](int t) {
-    const int m0 = (t / ntn) << 8, n0 = (t % ntn) << 8;
-    const int ra = m0 + (wave >> 2) * 128 + (wave & 3) * 16 + ld_r;     // A-h0 row; A-h1 = +64
-    const int rb = n0 + (wave >> 1) * 64 + (wave & 1) * 16 + ld_r;      // B-h0 row; B-h1 = +32
-    const char* A = (const char*)p.A + ld_c;
-    const char* B = (const char*)p.B + ld_c;
-    rp0 = A + (long)min(ra, p.M - 1) * lda_b;
-    rp3 = A + (long)min(ra + 64, p.M - 1) * lda_b;
-    rp1 = B + (long)min(rb, p.N - 1) * ldb_b;
-    rp2 = B + (long)min(rb + 32, p.N - 1) * ldb_b;
+    const int m0 = (LAB & 2) ? 0 : (t / ntn) << 8, n0 = (LAB & 2) ? 0 : (t % ntn) << 8;
+    // everything per-lane is recomputed from the lane id here (once per tile, a dozen VALU): kept live across the K loop these
+    // values get spilled, and their reload (scratch is VMEM) would drain the whole load stream at every tile change
+    const int l = g8_lane_now();
+    const int r = l >> 2, c = ((l & 3) ^ ((l >> 5) << 1)) << 4;
+    const int ra = m0 + (wave >> 2) * 128 + (wave & 3) * 16 + r;        // A-h0 row; A-h1 = +64
+    const int rb = n0 + (wave >> 1) * 64 + (wave & 1) * 16 + r;         // B-h0 row; B-h1 = +32
+    vo0 = (unsigned)min(ra, p.M - 1) * (unsigned)lda_b + (unsigned)c;   // rows past the edge: clamped, computed, never stored
+    vo3 = (unsigned)min(ra + 64, p.M - 1) * (unsigned)lda_b + (unsigned)c;
+    vo1 = (unsigned)min(rb, p.N - 1) * (unsigned)ldb_b + (unsigned)c;
+    vo2 = (unsigned)min(rb + 32, p.N - 1) * (unsigned)ldb_b + (unsigned)c;
   };
-  auto issue = [&](const char* rp, int half) {
-    const char* src = rp + (long)ls_kt * 128;
-    // (dead stream: each wave's dummy loads land in its OWN staging slot, which it only uses after draining its own loads)
-    char* dst = smem + (ls_live ? ((ls_kt & 1) * G8_KT + half * G8_HALF + wave * 2048) : (G8_STAGE + wave * 4096));
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(src + 64), (lptr_t)(dst + 1024), 16, 0, 0);
+  bool lab_steady = false;
+  // Past the workgroup's last tile the stream keeps issuing (same rows again, valid addresses) into the ring position the live
+  // stream would use - free by the same WAR argument and never read - so the counted waits stay uniform to the end.
+  auto issue = [&](const __amdgpu_buffer_rsrc_t rs, unsigned vo, int half) {
+    if constexpr (LAB & 4) { if (lab_steady) return; }
+    char* dst = smem + (ls_kt & 1) * G8_KT + half * G8_HALF + wave * 2048;
+    // (the K position and the second piece's +64 B go into the SCALAR offset: the instruction's immediate offset would be added to
+    // the LDS address as well as to the memory address)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)dst, 16, vo, ls_kt * 128, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + 1024), 16, vo, ls_kt * 128 + 64, 0, 0);
   };
   auto advance = [&]() {
     if (++ls_kt == nk) {
       ls_kt = 0;
       ls_tile += nslot;
       if (ls_tile < t_end) set_rows(ls_tile);
-      else ls_live = false;                      // stream exhausted: keep issuing (valid addresses) into the dummy slot
+    }
+  };
+  // bias / LayerScale slice of output tile t for this wave's 64 columns -> LDS (parity = tile counter & 1): 64 lanes x 4 B;
+  // columns past N read as zero (buffer range check) and are never stored
+  auto stage_bias = [&](int t, int parity) {
+    if constexpr (FAST) {
+      const unsigned vo = (unsigned)(((t % ntn) << 8) + wc * 64 + g8_lane_now()) * 4u;
+      const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.N * 4, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lptr_t)(smem + G8_BIAS + (parity * 8 + wave) * 256), 4, vo, 0, 0, 0);
+      if constexpr (KIND == G8_SCALE_BF16) {
+        const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gamma), 0, p.N * 4, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg_, (lptr_t)(smem + G8_GAMMA + (parity * 8 + wave) * 256), 4, vo, 0, 0, 0);
+      }
     }
   };
   set_rows(t_first);
-  issue(rp0, 0); issue(rp1, 1); issue(rp2, 2); issue(rp3, 3);
+  stage_bias(t_first, 0);
+  issue(rsA, vo0, 0); issue(rsB, vo1, 1); issue(rsB, vo2, 2); issue(rsA, vo3, 3);
   advance();
-  issue(rp0, 0);
-  if constexpr (TWOPH) issue(rp1, 1);                // two-phase schedule: the stream runs 6 half-tiles ahead
+  issue(rsA, vo0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue half-tiles have landed (this wave's part)
+  lab_steady = true;
   G8_BAR();
-  if constexpr (!ONEBAR) {
-    if (wr == 1) G8_BAR();                           // stagger: group 1 runs one barrier behind group 0
-  }
-#define G8_BAR_A() do { if constexpr (ONEBAR) { if (wr == 1) G8_BAR(); } else G8_BAR(); } while (0)   /* before the MFMA block */
-#define G8_BAR_B() do { if constexpr (ONEBAR) { if (wr == 0) G8_BAR(); } else G8_BAR(); } while (0)   /* after the MFMA block */
+  if (wr == 1) G8_BAR();                             // stagger: group 1 runs one barrier behind group 0
 
   // ---- fragment read addresses ------------------------------------------------------------------------------------
   // reader lane: row r = lane&15 of the 16-row sub-tile, logical chunk lane>>4 at physical chunk (lane>>4) ^ 2*(r>=8)
   const int rd_off = ((lane & 15) << 6) + ((((lane >> 4) ^ (((lane & 15) >> 3) << 1))) << 4);
   const char* a_base = smem + rd_off + wr * 8192;                // row-groups 4*wr.. of the A halves
   const char* b_base = smem + rd_off + wc * 4096 + G8_HALF;      // row-groups 2*wc.. of the B halves (B-h0 is slot 1)
+  char* const stg = smem + G8_STAGE + wave * 2048;
 
-#define G8_STAMP(slot)                                                                                   \
-  do {                                                                                                    \
-    if constexpr (TRACE) {                                                                                \
-      if (trace_on) {                                                                                     \
-        const unsigned ts_ = (unsigned)__builtin_amdgcn_s_memtime();                                      \
-        if (lane == 0) ((unsigned*)(smem + G8_STAGE + wave * 4096))[slot] = ts_;                          \
-      }                                                                                                   \
-    }                                                                                                     \
-  } while (0)
-  for (int t = t_first; t < t_end; t += nslot) {
-    f32x4 acc[8][4];
+  f32x4 acc[8][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 af[4][2], b0[2][2], b1[2][2];
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[4][2], b0[2][2], b1[2][2];
 
+  const unsigned ldc2 = (unsigned)p.ldc * 2u;
+  auto pieces = [&](int mi0, int m0, int n0, int par) {   // pieces mi0, mi0 + 1 of tile (m0, n0)
+    if constexpr (FAST) {
+      char* const Cb = (char*)p.C;
+      const int lane = g8_lane_now();                      // (shadows the kernel's: see g8_lane_now)
+      const bool col_ok = n0 + wc * 64 + (lane & 7) * 8 < p.N;
+      const char* bl = smem + G8_BIAS + (par * 8 + wave) * 256;
+      const char* gl = smem + G8_GAMMA + (par * 8 + wave) * 256;
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const int r0 = m0 + wr * 128 + (mi0 + d) * 16;
+        const unsigned goff = (unsigned)(r0 + (lane >> 3)) * ldc2 + (unsigned)(n0 + wc * 64) * 2u + (unsigned)(lane & 7) * 16u;
+        g8_piece<KIND == G8_GENERIC ? G8_BIAS_BF16 : KIND, F16, LAB>(acc[mi0 + d], Cb, goff, ldc2, p.M - r0, col_ok, stg, bl, gl, lane);
+      }
+    }
+  };
+
+  int it = 0;                                          // tile counter of this workgroup (bias parity)
+  for (int t = t_first; t < t_end; t += nslot, ++it) {
+    const int m0 = (t / ntn) << 8, n0 = (t % ntn) << 8;
     for (int kt2 = 0; kt2 < nk; kt2 += 2) {
-      const bool trace_on = TRACE && blockIdx.x == 0 && t == t_first && kt2 == 4;
 #pragma unroll
       for (int buf = 0; buf < 2; ++buf) {
         const char* ab = a_base + buf * G8_KT;
         const char* bb = b_base + buf * G8_KT;
-        G8_STAMP(buf * 20 + 0);
-        if constexpr (TWOPH) {
-          // ---- two phases per K-tile (32 MFMAs each: half as many barrier transitions per MFMA).  Stream 6 half-tiles ahead:
-          //      phase A issues B-h1/A-h1 of K-tile +1 and waits vmcnt(8) (A-h1 of this K-tile has landed);
-          //      phase B issues A-h0/B-h0 of K-tile +2 and waits vmcnt(6) (A-h0, B-h0, B-h1 of K-tile +1 have landed).
-#pragma unroll
-          for (int f = 0; f < 2; ++f)
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh) {
-              b0[f][kh] = *(const bf16x8*)(bb + f * 2048 + kh * 1024);
-              b1[f][kh] = *(const bf16x8*)(bb + G8_HALF + f * 2048 + kh * 1024);
-            }
-#pragma unroll
-          for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh) af[fi][kh] = *(const bf16x8*)(ab + fi * 2048 + kh * 1024);
-          issue(rp2, 2);
-          issue(rp3, 3);
-          if (buf == 1 || kt2 > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // first K-tile after a seam: already drained
-          G8_BAR();
-          __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-          for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-            for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-              for (int f = 0; f < 2; ++f)
-                acc[fi][f] = mfma16x16x32_h<F16>(b0[f][kh], af[fi][kh], acc[fi][f]);
-#pragma unroll
-          for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-            for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-              for (int f = 0; f < 2; ++f)
-                acc[fi][2 + f] = mfma16x16x32_h<F16>(b1[f][kh], af[fi][kh], acc[fi][2 + f]);
-          __builtin_amdgcn_s_setprio(0);
-          G8_BAR();
-#pragma unroll
-          for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh) af[fi][kh] = *(const bf16x8*)(ab + 3 * G8_HALF + fi * 2048 + kh * 1024);
-          advance();
-          issue(rp0, 0);
-          issue(rp1, 1);
-          asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-          G8_BAR();
-          __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-          for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-            for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-              for (int f = 0; f < 2; ++f)
-                acc[4 + fi][2 + f] = mfma16x16x32_h<F16>(b1[f][kh], af[fi][kh], acc[4 + fi][2 + f]);
-#pragma unroll
-          for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-            for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-              for (int f = 0; f < 2; ++f)
-                acc[4 + fi][f] = mfma16x16x32_h<F16>(b0[f][kh], af[fi][kh], acc[4 + fi][f]);
-          __builtin_amdgcn_s_setprio(0);
-        } else {
+        const bool head = buf == 0 && kt2 == 0;                        // first K-tile of the tile
+        const bool seam = NODRAIN && head && it > 0;                   // ... with the previous tile's stores in the VM queue
         // ---------------- phase 0: quadrant (m-half 0, n-half 0)
 #pragma unroll
         for (int f = 0; f < 2; ++f)
@@ -357,13 +332,13 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
         for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
           for (int kh = 0; kh < 2; ++kh) af[fi][kh] = *(const bf16x8*)(ab + fi * 2048 + kh * 1024);
-        G8_STAMP(40 + buf * 8 + 0);
-        issue(rp1, 1);
-        G8_STAMP(40 + buf * 8 + 1);
-        if (buf == 1 || kt2 > 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // see "tile seam" below
-        G8_STAMP(buf * 20 + 1);
-        G8_BAR_A();
-        G8_STAMP(buf * 20 + 2);
+        issue(rsB, vo1, 1);
+        if constexpr (NODRAIN) {
+          if (seam) g8_wait_vm<6 + NST>(); else g8_wait_vm<6>();
+        } else {
+          if (!head) g8_wait_vm<6>();                    // first K-tile after a drained seam: nothing to wait for
+        }
+        G8_BAR();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
@@ -371,24 +346,21 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
           for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
             for (int f = 0; f < 2; ++f)
-              acc[fi][f] = mfma16x16x32_h<F16>(b0[f][kh], af[fi][kh], acc[fi][f]);
+              if constexpr (LAB & 8) asm volatile("" ::"v"(b0[f][kh]), "v"(af[fi][kh])); else acc[fi][f] = mfma16x16x32_h<F16>(b0[f][kh], af[fi][kh], acc[fi][f]);
         __builtin_amdgcn_s_setprio(0);
-        G8_STAMP(buf * 20 + 3);
-        G8_BAR_B();
-        G8_STAMP(buf * 20 + 4);
-        G8_STAMP(buf * 20 + 5);
+        G8_BAR();
         // ---------------- phase 1: quadrant (0, 1)
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
           for (int kh = 0; kh < 2; ++kh) b1[f][kh] = *(const bf16x8*)(bb + G8_HALF + f * 2048 + kh * 1024);
-        G8_STAMP(40 + buf * 8 + 2);
-        issue(rp2, 2);
-        G8_STAMP(40 + buf * 8 + 3);
-        if (buf == 1 || kt2 > 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // see "tile seam" below
-        G8_STAMP(buf * 20 + 6);
-        G8_BAR_A();
-        G8_STAMP(buf * 20 + 7);
+        issue(rsB, vo2, 2);
+        if constexpr (NODRAIN) {
+          if (seam) g8_wait_vm<6 + NST>(); else g8_wait_vm<6>();
+        } else {
+          if (!head) g8_wait_vm<6>();
+        }
+        G8_BAR();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
@@ -396,90 +368,73 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
           for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
             for (int f = 0; f < 2; ++f)
-              acc[fi][2 + f] = mfma16x16x32_h<F16>(b1[f][kh], af[fi][kh], acc[fi][2 + f]);
+              if constexpr (LAB & 8) asm volatile("" ::"v"(b1[f][kh]), "v"(af[fi][kh])); else acc[fi][2 + f] = mfma16x16x32_h<F16>(b1[f][kh], af[fi][kh], acc[fi][2 + f]);
         __builtin_amdgcn_s_setprio(0);
-        G8_STAMP(buf * 20 + 8);
-        G8_BAR_B();
-        G8_STAMP(buf * 20 + 9);
-        G8_STAMP(buf * 20 + 10);
+        G8_BAR();
         // ---------------- phase 2: quadrant (1, 1)
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
           for (int kh = 0; kh < 2; ++kh) af[fi][kh] = *(const bf16x8*)(ab + 3 * G8_HALF + fi * 2048 + kh * 1024);
-        G8_STAMP(40 + buf * 8 + 4);
-        issue(rp3, 3);
-        G8_STAMP(40 + buf * 8 + 5);
-        if (buf == 1 || kt2 > 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // see "tile seam" below
-        G8_STAMP(buf * 20 + 11);
-        G8_BAR_A();
-        G8_STAMP(buf * 20 + 12);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-          for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-            for (int f = 0; f < 2; ++f)
-              acc[4 + fi][2 + f] = mfma16x16x32_h<F16>(b1[f][kh], af[fi][kh], acc[4 + fi][2 + f]);
-        __builtin_amdgcn_s_setprio(0);
-        G8_STAMP(buf * 20 + 13);
-        G8_BAR_B();
-        G8_STAMP(buf * 20 + 14);
-        G8_STAMP(buf * 20 + 15);
-        // ---------------- phase 3: quadrant (1, 0); the load stream moves on to the next K-tile
-        G8_STAMP(40 + buf * 8 + 6);
-        advance();
-        issue(rp0, 0);
-        G8_STAMP(40 + buf * 8 + 7);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        G8_STAMP(buf * 20 + 16);
-        G8_BAR_A();
-        G8_STAMP(buf * 20 + 17);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-          for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-            for (int f = 0; f < 2; ++f)
-              acc[4 + fi][f] = mfma16x16x32_h<F16>(b0[f][kh], af[fi][kh], acc[4 + fi][f]);
-        __builtin_amdgcn_s_setprio(0);
-        }
-        G8_STAMP(buf * 20 + 18);
-        if constexpr (ONEBAR) {
-          G8_BAR_B();
+        issue(rsA, vo3, 3);
+        if constexpr (FAST) {
+          if (head) {                                                              // third phase of a tile
+            // the NEXT tile's bias slice, a whole tile ahead (unconditional so that the counts below are uniform: past the last
+            // tile the current slice is staged again into the other parity)
+            stage_bias(t + nslot < t_end ? t + nslot : t, (it + 1) & 1);
+            if constexpr (NODRAIN) { if (seam) g8_wait_vm<6 + NST + NB>(); else g8_wait_vm<6 + NB>(); }
+          } else g8_wait_vm<6>();
         } else {
-          if (buf == 0 || kt2 + 2 < nk) G8_BAR();
+          if (!head) g8_wait_vm<6>();
         }
-        G8_STAMP(buf * 20 + 19);   // the tile's last barrier is placed around the epilogue below
+        G8_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+          for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+              if constexpr (LAB & 8) asm volatile("" ::"v"(b1[f][kh]), "v"(af[fi][kh])); else acc[4 + fi][2 + f] = mfma16x16x32_h<F16>(b1[f][kh], af[fi][kh], acc[4 + fi][2 + f]);
+        __builtin_amdgcn_s_setprio(0);
+        G8_BAR();
+        // ---------------- phase 3: quadrant (1, 0); the load stream moves on to the next K-tile
+        advance();
+        issue(rsA, vo0, 0);
+        if constexpr (FAST) {
+          if (head) g8_wait_vm<6 + NB>(); else g8_wait_vm<6>();    // (the seam's stores are older than the piece this waits for)
+        } else {
+          g8_wait_vm<6>();
+        }
+        G8_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+          for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+              if constexpr (LAB & 8) asm volatile("" ::"v"(b0[f][kh]), "v"(af[fi][kh])); else acc[4 + fi][f] = mfma16x16x32_h<F16>(b0[f][kh], af[fi][kh], acc[4 + fi][f]);
+        __builtin_amdgcn_s_setprio(0);
+        if (buf == 0 || kt2 + 2 < nk) G8_BAR();   // the tile's last barrier is placed around its epilogue
       }
     }
-
-    // ---- epilogue.  Both groups run it concurrently: group 0 passes the tile's last barrier first, group 1 after.
-    // Tile seam: every half-tile issued so far (stream indices up to 4 of the NEXT tile) is drained at the top of the
-    // epilogue (g8_epilogue, right after its bias loads are issued), before any store is issued, so the first three phases of the next tile need no wait; from its phase 3 on, vmcnt(6) covers
-    // loads issued after this point (loads retire in order among themselves; the epilogue's stores, also counted by
-    // vmcnt, can only make that wait stricter) while the stores drain in the background under the next tile's MFMAs.
-    if constexpr (TRACE) {
-      if (blockIdx.x == 0 && t == t_first && lane < 56)
-        ((unsigned*)p.aux)[wave * 64 + lane] = ((const unsigned*)(smem + G8_STAGE + wave * 4096))[lane];
+    // ---- epilogue at the end of the tile.  Both groups run it concurrently: group 0 passes the tile's last barrier first.
+    if (wr == 0) G8_BAR();
+    if constexpr (KIND == G8_GENERIC) {
+      g8_epilogue_generic<F16>(p, acc, m0, n0, wr, wc, lane);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else if constexpr (FAST) {
+      if constexpr (!NODRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // lab only: the round-1 seam
+      pieces(0, m0, n0, it & 1); pieces(2, m0, n0, it & 1); pieces(4, m0, n0, it & 1); pieces(6, m0, n0, it & 1);
     }
-    if constexpr (!ONEBAR) {
-      if (wr == 0) G8_BAR();
-    }
-    {
-      const int m0 = (t / ntn) << 8, n0 = (t % ntn) << 8;
-      if (KIND != G8_GENERIC && m0 + 256 <= p.M && n0 + 256 <= p.N) g8_epilogue<KIND, true, F16>(p, acc, smem, m0, n0, wr, wc, lane);
-      else g8_epilogue<KIND, false, F16>(p, acc, smem, m0, n0, wr, wc, lane);
-    }
-    if constexpr (!ONEBAR) {
-      if (wr == 1) G8_BAR();
-    }
+    if (wr == 1) G8_BAR();
   }
-  if constexpr (!ONEBAR) {
-    if (wr == 0) G8_BAR();   // balances group 1's extra barrier at the start
-  }
+  if (wr == 0) G8_BAR();   // balances group 1's extra barrier at the start
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stream's tail pieces must land before the LDS is released
 }
 
 
@@ -488,7 +443,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
 // Per-device launch state: the 160 KiB dynamic-LDS attribute is a per-device function attribute and the CU count differs per
 // device, so a process that drives several GPUs (one engine per device) gets both for every device it touches.
 namespace {
-struct G8Dev { bool attr_done = false; bool trace_attr = false; int ncu = 0; };
+struct G8Dev { bool attr_done = false; int ncu = 0; };
 G8Dev g8_dev[64];
 }  // namespace
 
@@ -498,6 +453,7 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
   if (disable) return 0;
   if (!p.ab_bf16 || p.batch != 1 || p.act == ACT_TANHGATE) return 0;
   if (p.K % 128 != 0 || p.N % 16 != 0 || p.M < 1024 || p.N < 256) return 0;
+  if ((long)p.M * p.lda * 2 >= (1l << 32) - (1l << 20) || (long)p.N * p.ldb * 2 >= (1l << 32) - (1l << 20)) return 0;   // 32-bit buffer offsets
   typedef void (*kern_t)(GemmP);
   // epilogue kind from the options; TAG only names the symbol for rocprof (1 qkv, 2 proj, 3 fc1, 4 fc2)
   int kind = G8_GENERIC;
@@ -528,19 +484,60 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
   const long ntiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   long grid = ds.ncu;
   if (ntiles < grid) grid = ntiles;
-  static const bool trace = getenv("EC_G8_TRACE") != nullptr;
-  if (trace && kind == G8_BIAS_BF16 && !p.h_f16 && p.aux) {   // debug: p.aux = device buffer of 8 x 64 uint32 timestamps
-    if (!ds.trace_attr) {
-      EC_HIP(hipFuncSetAttribute((const void*)gemm8_bf16_kernel<1, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));
-      ds.trace_attr = true;
-    }
-    hipLaunchKernelGGL((gemm8_bf16_kernel<1, 0, false, true>), dim3((unsigned)grid), dim3(512), G8_LDS, st, p);
-    EC_LAUNCH_CHECK();
-    return 1;
-  }
   hipLaunchKernelGGL(table[p.h_f16 ? 1 : 0][kind][p.tag], dim3((unsigned)grid), dim3(512), G8_LDS, st, p);
   EC_LAUNCH_CHECK();
   return 1;
 }
+
+#ifdef EC_G8_LAB
+// Lab build only (tools/g8_lab.py, libedgecape_hip_lab.so): time an ablated instantiation of the QKV-kind kernel.
+extern "C" int ec_lab_gemm8(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lab, int iters,
+                            void* stream, float* ms) {
+  typedef void (*kern_t)(GemmP);
+  kern_t k = nullptr;
+  switch (lab) {
+    case 0: k = gemm8_bf16_kernel<1, 1, false, 0>; break;
+    case 1: k = gemm8_bf16_kernel<1, 1, false, 1>; break;
+    case 2: k = gemm8_bf16_kernel<1, 1, false, 2>; break;
+    case 3: k = gemm8_bf16_kernel<1, 1, false, 3>; break;
+    case 4: k = gemm8_bf16_kernel<1, 1, false, 4>; break;
+    case 5: k = gemm8_bf16_kernel<1, 1, false, 5>; break;
+    case 8: k = gemm8_bf16_kernel<1, 1, false, 8>; break;
+    case 9: k = gemm8_bf16_kernel<1, 1, false, 9>; break;
+    case 32: k = gemm8_bf16_kernel<1, 1, false, 32>; break;
+    case 34: k = gemm8_bf16_kernel<1, 1, false, 34>; break;
+    case 36: k = gemm8_bf16_kernel<1, 1, false, 36>; break;
+    case 40: k = gemm8_bf16_kernel<1, 1, false, 40>; break;
+    case 64: k = gemm8_bf16_kernel<1, 1, false, 64>; break;
+    case 65: k = gemm8_bf16_kernel<1, 1, false, 65>; break;
+    case 100: k = gemm8_bf16_kernel<3, 3, false, 0>; break;     // fc1 + GELU, pipelined
+    case 164: k = gemm8_bf16_kernel<3, 3, false, 64>; break;    // fc1 + GELU, epilogue at the end of the tile
+    default: set_error("ec_lab_gemm8: variant not instantiated"); return -1;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  EC_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));
+  GemmP p;
+  p.A = A; p.B = W; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N; p.ab_bf16 = 1; p.c_bf16 = 1;
+  int dev = 0, ncu = 0;
+  EC_HIP(hipGetDevice(&dev));
+  EC_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+  const long ntiles = (long)((M + 255) / 256) * ((N + 255) / 256);
+  const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);
+  hipEvent_t e0, e1;
+  EC_HIP(hipEventCreate(&e0));
+  EC_HIP(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), G8_LDS, st, p);
+  EC_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(512), G8_LDS, st, p);
+  EC_HIP(hipEventRecord(e1, st));
+  EC_HIP(hipEventSynchronize(e1));
+  float t = 0.f;
+  EC_HIP(hipEventElapsedTime(&t, e0, e1));
+  *ms = t / (float)iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return 0;
+}
+#endif
 
 }  // namespace ec

@@ -1530,12 +1530,6 @@ int ec_op_gemm_bench(const void* A, const void* W, const float* bias, void* C, i
   p.A = A; p.B = W; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N;
   p.ab_bf16 = precision == EC_BF16 || precision == EC_F16; p.c_bf16 = p.ab_bf16; p.h_f16 = precision == EC_F16;
   p.split = precision == EC_BF16X3;   // timing only: W is interpreted as an already split-packed buffer
-  float* trace_buf = nullptr;
-  if (getenv("EC_G8_TRACE")) {        // debug: phase timestamps of the 8-phase kernel (tools/g8_trace.py)
-    EC_HIP(hipMalloc((void**)&trace_buf, 512 * 4));
-    EC_HIP(hipMemset(trace_buf, 0, 512 * 4));
-    p.aux = trace_buf;
-  }
   hipEvent_t e0, e1;
   EC_HIP(hipEventCreate(&e0));
   EC_HIP(hipEventCreate(&e1));
@@ -1547,19 +1541,6 @@ int ec_op_gemm_bench(const void* A, const void* W, const float* bias, void* C, i
   float t = 0.f;
   EC_HIP(hipEventElapsedTime(&t, e0, e1));
   *ms = t / (float)iters;
-  if (trace_buf) {
-    unsigned h[512];
-    EC_HIP(hipMemcpy(h, trace_buf, sizeof(h), hipMemcpyDeviceToHost));
-    FILE* f = fopen("/tmp/g8_trace.txt", "w");
-    if (f) {
-      for (int w = 0; w < 8; ++w) {
-        for (int i = 0; i < 56; ++i) fprintf(f, "%u ", h[w * 64 + i]);
-        fprintf(f, "\n");
-      }
-      fclose(f);
-    }
-    (void)hipFree(trace_buf);
-  }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return EC_OK;

@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Kernel lab for the 8-phase GEMM: times ablated instantiations (ec_gemm8.hip LAB bits) from libedgecape_hip_lab.so
+(`python -m edgecape_amd.build --lab`, built with -DEC_G8_LAB; the shipped library has none of them).
+
+    LAB bits: 1 no global stores | 2 every tile loads tile 0's operands | 4 no LDS-DMA in the steady state | 8 no MFMAs | 32 no epilogue
+    SHAPES="name:M:N:K,..."  VARIANTS="0,1,2,..."  python tools/g8_lab.py
+"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from edgecape_amd import build
+
+NAMES = {0: "full", 1: "nostore", 2: "alias", 3: "alias+nostore", 4: "noload", 5: "noload+nostore", 8: "nomfma", 9: "nomfma+nostore",
+         32: "noepi", 34: "alias+noepi", 36: "noload+noepi", 40: "nomfma+noepi"}
+
+
+def main():
+    path = build.LIB.replace(".so", "_lab.so")
+    if not os.path.exists(path):
+        build.build_lab()
+    lib = C.CDLL(path)
+    vp, ci = C.c_void_p, C.c_int
+    lib.ec_lab_gemm8.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, C.POINTER(C.c_float)]
+    lib.ec_last_error.restype = C.c_char_p
+    lib.ec_lab_gemm_nt.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, C.POINTER(C.c_float)]
+    nt_cfgs = [int(v) for v in os.environ.get("NT", "").split(",") if v]
+    shapes = [("qkv", 20800, 2304, 768)]
+    if os.environ.get("SHAPES"):
+        shapes = [(n, int(m), int(nn), int(k)) for n, m, nn, k in (x.split(":") for x in os.environ["SHAPES"].split(","))]
+    variants = [int(v) for v in os.environ.get("VARIANTS", "0,1,2,3,4,8,32,34,36,40").split(",")]
+    iters = int(os.environ.get("ITERS", 30))
+    for name, M, N, K in shapes:
+        A = torch.randn(M, K, device="cuda").bfloat16()
+        W = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
+        b = torch.randn(N, device="cuda")
+        Cd = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        for rep in range(int(os.environ.get("REPS", 2))):
+            row = []
+            for v in variants:
+                ms = C.c_float()
+                rc = lib.ec_lab_gemm8(A.data_ptr(), W.data_ptr(), b.data_ptr(), Cd.data_ptr(), M, N, K, v, iters, None, C.byref(ms))
+                assert rc == 0, lib.ec_last_error().decode()
+                row.append(f"{NAMES.get(v, v)} {ms.value * 1e3:.1f}us ({2.0 * M * N * K / (ms.value * 1e-3) / 1e12:.0f})")
+            for c in nt_cfgs:
+                ms = C.c_float()
+                rc = lib.ec_lab_gemm_nt(A.data_ptr(), W.data_ptr(), b.data_ptr(), Cd.data_ptr(), M, N, K, c, iters, None, C.byref(ms))
+                assert rc == 0, lib.ec_last_error().decode()
+                row.append(f"nt{c} {ms.value * 1e3:.1f}us ({2.0 * M * N * K / (ms.value * 1e-3) / 1e12:.0f})")
+            print(f"{name} M={M} N={N} K={K}: " + " | ".join(row), flush=True)
+
+
+if __name__ == "__main__":
+    main()
