@@ -20,7 +20,7 @@ EC_LAYOUT_TOKENS, EC_LAYOUT_NCHW = 0, 1
 
 EXPORTS = ["ec_last_error", "ec_version", "ec_create", "ec_destroy", "ec_load_tensor", "ec_set_pos_embed", "ec_finalize",
            "ec_backbone", "ec_head", "ec_forward", "ec_support_create", "ec_support_destroy", "ec_support_encode", "ec_forward_cached", "ec_preprocess_images", "ec_msra_targets", "ec_debug_read", "ec_profile", "ec_profile_read", "ec_op_linear", "ec_op_gemm_bench", "ec_op_bgemm", "ec_op_layernorm",
-           "ec_op_attention", "ec_abi_sizes"]
+           "ec_op_attention", "ec_op_chain", "ec_abi_sizes"]
 
 
 class EcConfig(C.Structure):
@@ -95,6 +95,7 @@ def load():
     lib.ec_op_bgemm.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, vp]
     lib.ec_op_layernorm.argtypes = [vp, vp, vp, vp, ci, ci, cf, vp]
     lib.ec_op_attention.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+    lib.ec_op_chain.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp]
     for n in EXPORTS:
         if n not in ("ec_last_error", "ec_version", "ec_abi_sizes"):
             getattr(lib, n).restype = ci

@@ -1,0 +1,44 @@
+// Row-chain kernel (ec_chain.hip): a sequence of Linear (+ bias / table / activation / residual / LayerNorm) stages applied to
+// 32-row slabs, intermediate activations resident in LDS.  Internal.
+#pragma once
+#include "ec_common.h"
+
+namespace ec {
+
+constexpr int CH_BM = 32;          // rows per workgroup
+constexpr int CH_MAX_STAGES = 4;
+constexpr int CH_LDS0 = 4096;      // first byte of the activation buffers (the LayerNorm scratch sits in front)
+
+// One stage: Y[32, N] = epilogue(X[32, K] @ W[N, K]^T).
+//   X: k columns [0, k1) from the LDS operand buffer at a_off, [k1, K) from the one at b_off (row pitch = columns*4 + 16 bytes;
+//      split hi/lo bf16 planes).  An operand buffer is filled either by an earlier stage (s_off) or, right before this stage, from
+//      global memory (g_in: fp32 [rows, g_k] -> buffer at g_off).
+//   epilogue: v = acc + bias[n] + table[row % period][n]; v = act(v); v += resid[row][n]; v += kept tile; v = LayerNorm(v)
+//      (N = 256 only); then any of: global fp32 store, split write into the LDS buffer at s_off, register copy (keep) for a later
+//      stage's residual.
+struct ChainStage {
+  const void* W = nullptr;       // pack_chain_weights image of W [N, K]
+  const float* bias = nullptr;
+  int N = 0, K = 0;
+  int a_off = 0, k1 = 0, b_off = 0;
+  const float* g_in = nullptr; long ld_in = 0; int g_k = 0; int g_off = 0;
+  int act = ACT_NONE;
+  const float* table = nullptr; long ldt = 0; int period = 1;
+  const float* resid = nullptr; long ldr = 0;
+  int resid_keep = 0;
+  const float* ln_w = nullptr; const float* ln_b = nullptr; float eps = 1e-5f;
+  float* out = nullptr; long ldo = 0;
+  int s_off = -1;
+  int keep = 0;
+};
+struct ChainP {
+  int rows = 0, n_stages = 0, lds_bytes = 0;
+  ChainStage st[CH_MAX_STAGES];
+};
+
+int chain_layout_bytes(int k);   // bytes of an operand buffer of k columns (32 rows)
+int run_chain(const ChainP& p, hipStream_t st);
+// host: W [N, K] fp32 -> fragment-major split packing, N*K*4 bytes (N % 16 == 0, K % 32 == 0)
+void pack_chain_weights(const float* W, long N, long K, void* out);
+
+}  // namespace ec

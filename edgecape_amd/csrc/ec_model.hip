@@ -18,6 +18,7 @@
 
 #include "../../include/edgecape_hip.h"
 #include "ec_common.h"
+#include "ec_chain.h"
 #include "ec_ops.h"
 
 namespace ec {
@@ -41,6 +42,7 @@ struct Lin {  // a Linear layer view: W [N,K] (+ optional bf16 copy), bias [N]
   const float* w = nullptr;
   const bf16_t* w16 = nullptr;
   const float* ws = nullptr;   // bf16x3 split-packed copy (head_precision = EC_BF16X3), same byte size as w
+  const void* wc = nullptr;    // ... and its fragment-major packing for the row-chain kernel (ec_chain.hip), head only
   const float* b = nullptr;
   int N = 0, K = 0;
   bool w16_is_f16 = false;     // w16 holds IEEE fp16 (EC_F16 backbone) instead of bf16
@@ -77,6 +79,7 @@ struct ec_model {
   bool bbf16 = false;        // ... in IEEE fp16 (EC_F16) instead of bf16 (EC_BF16)
   bool bb_split = false;     // EC_BF16X3 backbone: fp32 activations, every MFMA operand split hi+lo bf16 (3 MFMAs per product)
   bool head_split = false;   // head GEMMs in bf16x3 (ec_gemm.hip GM_SPLIT)
+  bool head_chain = false;   // ... and the row-wise stretches of every head layer as row-chain launches (ec_chain.hip); EC_CHAIN=0: off
   // the support half of the head (pooling + SkeletonPredictor) has no query input: it runs on a side stream, concurrently
   // with input_proj / encoder / proposal generator on the caller's stream (both are small-grid, latency-bound kernels)
   hipStream_t side = nullptr;
@@ -193,6 +196,16 @@ static int upload_split(ec_model* m, const float* W, long rows, long K, const fl
   split_pack_weights(W, rows, K, packed.data());
   return upload(m, packed, out);
 }
+// fragment-major split packing for the row-chain kernel; shapes the kernel cannot take simply get no such copy
+static int upload_chain(ec_model* m, const float* W, long rows, long K, const void** out) {
+  if (rows % 32 != 0 || K % 128 != 0) return 0;
+  std::vector<float> packed((size_t)rows * K);
+  pack_chain_weights(W, rows, K, packed.data());
+  const float* dev = nullptr;
+  int rc = upload(m, packed, &dev);
+  *out = dev;
+  return rc;
+}
 
 static const Tensor* find(ec_model* m, const std::string& name) {
   auto it = m->tensors.find(name);
@@ -220,6 +233,7 @@ static int make_lin(ec_model* m, const std::string& wname, const std::string& bn
   } else if ((m->head_split && name_is_head(wname)) || (m->bb_split && !name_is_head(wname))) {
     int rc = upload_split(m, w->host.data(), out->N, out->K, &out->ws);
     if (rc) return rc;
+    if (m->head_chain && name_is_head(wname) && (rc = upload_chain(m, w->host.data(), out->N, out->K, &out->wc))) return rc;
   }
   return 0;
 }
@@ -228,6 +242,7 @@ static int make_lin_host(ec_model* m, const std::vector<float>& W, const std::ve
   int rc = upload(m, W, &out->w);
   if (rc) return rc;
   if (m->head_split && (rc = upload_split(m, W.data(), N, K, &out->ws))) return rc;   // make_lin_host is only used by the head
+  if (m->head_chain && (rc = upload_chain(m, W.data(), N, K, &out->wc))) return rc;
   if (!b.empty()) rc = upload(m, b, &out->b);
   return rc;
 }
@@ -485,6 +500,10 @@ struct LayerIO {
   hipEvent_t wait_ca[2] = {nullptr, nullptr};
   hipEvent_t wait_kv = nullptr;   // pre-projected K|V ready: waited for AFTER the query projection, right before the cross attention
   hipEvent_t wait_sa = nullptr;   // adjacency / attention bias ready: waited for after the self-attention input projection
+  // row-chain mode (ec_chain.hip): the layer's last chain (ffn2 + norm3) also produces what the NEXT consumers of x need
+  bool qkv_ready = false;          // this layer's self-attention input projection was produced by the previous layer's last chain
+  const Lin* next_sa_in = nullptr; // next layer's self-attention input projection -> qkv
+  bool kvk_in_chain = false;       // two-way layers: K|V of the image->token attention (i2t_kv(x)) -> kvk
 };
 
 // K|V of the image tokens for a layer's token->image cross attention, one batch entry per sample (mem may be a strided view):
@@ -506,10 +525,10 @@ static int image_update_q(ec_model* m, const DecLayer& L, const float* mem, int 
   return linear(mem, m->d, false, L.i2t_q, qimg, m->E, false, nb * m->HW, ACT_NONE, st, nullptr, nullptr, 0, L.i2t_q_table, m->E, m->HW);
 }
 static int image_update(ec_model* m, const DecLayer& L, const float* x, long ldx, float* mem, int nb, const float* qimg, float* kvk,
-                        float* attimg, float* tmpimg, hipStream_t st, hipEvent_t x_read) {
+                        float* attimg, float* tmpimg, hipStream_t st, hipEvent_t x_read, bool kvk_ready = false) {
   const int d = m->d, E = m->E, K = m->K, HW = m->HW, nh = m->cfg.nhead;
   const int Mi = nb * HW, Mk = nb * K;
-  RUN(linear(x, ldx, false, L.i2t_kv, kvk, 2 * E, false, Mk, ACT_NONE, st));
+  if (!kvk_ready) RUN(linear(x, ldx, false, L.i2t_kv, kvk, 2 * E, false, Mk, ACT_NONE, st));   // (else: the layer's last chain wrote it)
   if (x_read) EC_HIP(hipEventRecord(x_read, st));
   AttnP a;
   a.Q = qimg; a.K = kvk; a.V = kvk + E; a.O = attimg;
@@ -522,13 +541,44 @@ static int image_update(ec_model* m, const DecLayer& L, const float* x, long ldx
   return ln(tmpimg, d, mem, d, false, L.n4, Mi, d, 1e-5f, st);
 }
 
+// ---- row chains of a decoder / two-way layer (ec_chain.hip).  LDS operand buffers are laid out by a bump allocator.
+struct ChainBuild {
+  ChainP p;
+  int top = CH_LDS0;
+  int buf(int k) { const int o = top; top += chain_layout_bytes(k); return o; }
+  ChainStage& add() { return p.st[p.n_stages++]; }
+  int run(int rows, hipStream_t st) { p.rows = rows; p.lds_bytes = top; return run_chain(p, st); }
+};
+static void chain_lin(ChainStage& S, const Lin& W) { S.W = W.wc; S.bias = W.b; S.N = W.N; S.K = W.K; S.k1 = W.K; }
+static bool chain_ok(const Lin& W) { return W.wc != nullptr; }
+
+// x <- LayerNorm(x + in @ W^T + b): the residual branch shared by the three chains of a layer.  Returns the LDS buffer with x.
+static int chain_resid_ln(ChainBuild& cb, const float* in, long ld_in, const Lin& W, const Norm& n, float* x, long ldx, bool to_lds) {
+  ChainStage& S = cb.add();
+  chain_lin(S, W);
+  S.g_in = in; S.ld_in = ld_in; S.g_k = W.K; S.g_off = cb.buf(W.K); S.a_off = S.g_off;
+  S.resid = x; S.ldr = ldx; S.ln_w = n.w; S.ln_b = n.b; S.eps = 1e-5f;
+  S.out = x; S.ldo = ldx;
+  if (to_lds) S.s_off = cb.buf(W.N);
+  return S.s_off;
+}
+
+// does this layer run as row chains?  (the callers use the same predicate to hand the next in-proj / i2t K|V to the last chain)
+static bool layer_chains(const ec_model* m, const DecLayer& L) {
+  const int lds_ffn2 = CH_LDS0 + chain_layout_bytes(L.ffn2.K) + chain_layout_bytes(m->d);   // the widest operand: z [32, F]
+  return m->head_chain && chain_ok(L.sa_out) && chain_ok(L.ca_q) && chain_ok(L.ca_fold) && chain_ok(L.ffn1) && chain_ok(L.ffn2) &&
+         (L.ca_q.K == m->d || L.ca_q.K == 2 * m->d) && lds_ffn2 <= 160 * 1024;   // (ViT-L skeleton layers, F = 1024: separate launches)
+}
+
 static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool biased, bool two_way, float* qkv, float* att,
                          float* tmp, float* qc, float* kv, float* y, float* z, float* qimg, float* kvk, float* attimg,
                          float* tmpimg, int F, hipStream_t st) {
   const int d = m->d, E = m->E, K = m->K, HW = m->HW, nh = m->cfg.nhead;
   const int Mk = io.nb * K;
+  const bool chain = layer_chains(m, L);
+  EC_REQUIRE(chain || (!io.qkv_ready && !io.next_sa_in && !io.kvk_in_chain), EC_ERR_STATE, "chain hand-offs on a layer that does not chain");
   // ---- self attention over the K keypoint tokens (hd = d/nh = 32)
-  RUN(linear(io.x, io.ldx, false, L.sa_in, qkv, 3 * d, false, Mk, ACT_NONE, st));
+  if (!io.qkv_ready) RUN(linear(io.x, io.ldx, false, L.sa_in, qkv, 3 * d, false, Mk, ACT_NONE, st));
   {
     AttnP a;
     a.Q = qkv; a.K = qkv + d; a.V = qkv + 2 * d; a.O = att;
@@ -541,13 +591,30 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
     if (io.wait_sa) EC_HIP(hipStreamWaitEvent(st, io.wait_sa, 0));
     RUN(attention(a, st));
   }
-  RUN(linear(att, d, false, L.sa_out, tmp, d, false, Mk, ACT_NONE, st, nullptr, io.x, io.ldx));
-  if (io.wait_x) EC_HIP(hipStreamWaitEvent(st, io.wait_x, 0));
-  RUN(ln(tmp, d, io.x, io.ldx, false, L.n1, Mk, d, 1e-5f, st));
-  for (hipEvent_t e : io.wait_ca)
-    if (e) EC_HIP(hipStreamWaitEvent(st, e, 0));
-  // ---- cross attention tokens -> image (hd = E/nh = 64); Q input is [x | init_pos] (K = 2d) in the main decoder
-  RUN(linear(io.x, io.ldx, false, L.ca_q, qc, E, false, Mk, ACT_NONE, st));
+  if (chain) {
+    // x = norm1(x + out_proj(att)); qc = q_proj([x | qpe]) - one launch (encoder_decoder.py:596-611)
+    if (io.wait_x) EC_HIP(hipStreamWaitEvent(st, io.wait_x, 0));
+    for (hipEvent_t e : io.wait_ca)
+      if (e) EC_HIP(hipStreamWaitEvent(st, e, 0));
+    ChainBuild cb;
+    const int bx = chain_resid_ln(cb, att, d, L.sa_out, L.n1, io.x, io.ldx, true);
+    ChainStage& Q = cb.add();
+    chain_lin(Q, L.ca_q);
+    Q.a_off = bx; Q.k1 = d;
+    if (L.ca_q.K == 2 * d) {   // main decoder: the positional half of the query sits beside x in the token rows
+      Q.g_in = io.x + d; Q.ld_in = io.ldx; Q.g_k = d; Q.g_off = cb.p.st[0].g_off; Q.b_off = Q.g_off;   // (att's buffer is free again)
+    }
+    Q.out = qc; Q.ldo = E;
+    RUN(cb.run(Mk, st));
+  } else {
+    RUN(linear(att, d, false, L.sa_out, tmp, d, false, Mk, ACT_NONE, st, nullptr, io.x, io.ldx));
+    if (io.wait_x) EC_HIP(hipStreamWaitEvent(st, io.wait_x, 0));
+    RUN(ln(tmp, d, io.x, io.ldx, false, L.n1, Mk, d, 1e-5f, st));
+    for (hipEvent_t e : io.wait_ca)
+      if (e) EC_HIP(hipStreamWaitEvent(st, e, 0));
+    // ---- cross attention tokens -> image (hd = E/nh = 64); Q input is [x | init_pos] (K = 2d) in the main decoder
+    RUN(linear(io.x, io.ldx, false, L.ca_q, qc, E, false, Mk, ACT_NONE, st));
+  }
   {
     const float* kvp = io.kv_pre;
     long ldkv = io.ld_kv_pre;
@@ -564,11 +631,21 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
     a.split = m->head_split ? 1 : 0;   // head throughput mode: bf16x3 MFMAs
     RUN(attention(a, st));
   }
-  RUN(linear(att, E, false, L.ca_fold, tmp, d, false, Mk, ACT_NONE, st, nullptr, io.x, io.ldx));
-  RUN(ln(tmp, d, io.x, io.ldx, false, L.n2, Mk, d, 1e-5f, st));
   // ---- GCN feed-forward (encoder_decoder.py:508-524,634-637): y = conv1d(x) -> [.., 2F];
   //      z = relu(valid * y[:, :F] + adj1 @ y[:, F:]);  x = LN3(x + ffn2(z))
-  RUN(linear(io.x, io.ldx, false, L.ffn1, y, 2 * F, false, Mk, ACT_NONE, st));
+  if (chain) {
+    ChainBuild cb;   // x = norm2(x + choker(out_proj(att))); y = ffn1(x)
+    const int bx = chain_resid_ln(cb, att, E, L.ca_fold, L.n2, io.x, io.ldx, true);
+    ChainStage& Y = cb.add();
+    chain_lin(Y, L.ffn1);
+    Y.a_off = bx;
+    Y.out = y; Y.ldo = 2 * F;
+    RUN(cb.run(Mk, st));
+  } else {
+    RUN(linear(att, E, false, L.ca_fold, tmp, d, false, Mk, ACT_NONE, st, nullptr, io.x, io.ldx));
+    RUN(ln(tmp, d, io.x, io.ldx, false, L.n2, Mk, d, 1e-5f, st));
+    RUN(linear(io.x, io.ldx, false, L.ffn1, y, 2 * F, false, Mk, ACT_NONE, st));
+  }
   {
     BgemmP p;
     p.A = io.adj1; p.lda = K; p.sA = (long)K * K; p.modA = io.bs;
@@ -578,8 +655,27 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
     p.self = y; p.ld_self = 2 * F; p.s_self = (long)K * 2 * F; p.rowscale = io.valid; p.mod_rs = io.bs; p.relu = 1;
     RUN(bgemm_small(p, st));
   }
-  RUN(linear(z, F, false, L.ffn2, tmp, d, false, Mk, ACT_NONE, st, nullptr, io.x, io.ldx));
-  RUN(ln(tmp, d, io.x, io.ldx, false, L.n3, Mk, d, 1e-5f, st));
+  if (chain) {
+    ChainBuild cb;   // x = norm3(x + ffn2(z)) (-> next layer's self-attention in-proj) (-> image->token K|V)
+    const bool more = (io.next_sa_in && chain_ok(*io.next_sa_in)) || (io.kvk_in_chain && chain_ok(L.i2t_kv));
+    const int bx = chain_resid_ln(cb, z, F, L.ffn2, L.n3, io.x, io.ldx, more);
+    if (io.next_sa_in && chain_ok(*io.next_sa_in)) {
+      ChainStage& S = cb.add();
+      chain_lin(S, *io.next_sa_in);
+      S.a_off = bx;
+      S.out = qkv; S.ldo = 3 * d;
+    }
+    if (io.kvk_in_chain && chain_ok(L.i2t_kv)) {
+      ChainStage& S = cb.add();
+      chain_lin(S, L.i2t_kv);
+      S.a_off = bx;
+      S.out = kvk; S.ldo = 2 * E;
+    }
+    RUN(cb.run(Mk, st));
+  } else {
+    RUN(linear(z, F, false, L.ffn2, tmp, d, false, Mk, ACT_NONE, st, nullptr, io.x, io.ldx));
+    RUN(ln(tmp, d, io.x, io.ldx, false, L.n3, Mk, d, 1e-5f, st));
+  }
   if (two_way && io.update_mem) {
     RUN(image_update_q(m, L, io.mem, io.nb, qimg, st));
     RUN(image_update(m, L, io.x, io.ldx, io.mem, io.nb, qimg, kvk, attimg, tmpimg, st, nullptr));
@@ -682,6 +778,10 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
       io.wait_x = i > 0 ? ev_xr : nullptr;
       io.wait_kv = ev_kv;
     }
+    const bool ch = layer_chains(m, m->skel[i]);
+    io.qkv_ready = i > 0 && ch && layer_chains(m, m->skel[i - 1]) && chain_ok(m->skel[i].sa_in);
+    if (ch && i + 1 < nsk && layer_chains(m, m->skel[i + 1]) && chain_ok(m->skel[i + 1].sa_in)) io.next_sa_in = &m->skel[i + 1].sa_in;
+    io.kvk_in_chain = ch && i + 1 < nsk && chain_ok(m->skel[i].i2t_kv);
     RUN(run_dec_layer(m, m->skel[i], io, false, true, m->s_qkv, m->s_att, m->s_tmp, m->s_qc, m->s_kv, m->s_y, m->s_z, m->s_qimg,
                       m->s_kvk, m->s_attimg, m->s_tmpimg, Fs, st));
     RUN(tl_mark(m, i == 0 ? "S.skel0" : i == 1 ? "S.skel1" : "S.skel2", st));
@@ -690,7 +790,8 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
         EC_HIP(hipEventRecord(ev_x, st));
         EC_HIP(hipStreamWaitEvent(s2, ev_x, 0));
       }
-      RUN(image_update(m, m->skel[i], m->s_x, d, m->s_mem, nb, m->s_qimg, m->s_kvk, m->s_attimg, m->s_tmpimg, s2, ov2 ? ev_xr : nullptr));
+      RUN(image_update(m, m->skel[i], m->s_x, d, m->s_mem, nb, m->s_qimg, m->s_kvk, m->s_attimg, m->s_tmpimg, s2, ov2 ? ev_xr : nullptr,
+                       io.kvk_in_chain));
       RUN(project_image_kv(m, m->skel[i + 1], m->s_mem, (long)HW * d, nb, m->s_kv, s2));
       if (ov2) EC_HIP(hipEventRecord(ev_kv, s2));
       RUN(tl_mark(m, i == 0 ? "I.kv1" : "I.kv2", s2));
@@ -897,6 +998,9 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
       io.wait_ca[0] = ev_qpe;
       io.wait_kv = li == 0 ? ev_kv : nullptr;
     }
+    const bool ch = layer_chains(m, Ld);
+    io.qkv_ready = li > 0 && ch && layer_chains(m, m->dec[li - 1]) && chain_ok(Ld.sa_in);
+    if (ch && li + 1 < nL && layer_chains(m, m->dec[li + 1]) && chain_ok(m->dec[li + 1].sa_in)) io.next_sa_in = &m->dec[li + 1].sa_in;
     RUN(run_dec_layer(m, Ld, io, true, false, m->d_qkv, m->d_att, m->d_tmp, m->d_qc, m->d_kv, m->d_y, m->d_z, nullptr, nullptr,
                       nullptr, nullptr, Fd, st));
     RUN(tl_mark(m, li == 0 ? "Q.dec0" : li == 1 ? "Q.dec1" : "Q.dec2", st));
@@ -1061,6 +1165,7 @@ int ec_create(const ec_config* cfg, ec_handle* out) {
   m->bb16 = cfg->backbone_precision == EC_BF16 || cfg->backbone_precision == EC_F16;
   m->bbf16 = cfg->backbone_precision == EC_F16;
   m->head_split = cfg->head_precision == EC_BF16X3;
+  m->head_chain = m->head_split && !(getenv("EC_CHAIN") && atoi(getenv("EC_CHAIN")) == 0);
   EC_REQUIRE(m->g >= 2 && m->g <= 32, EC_ERR_ARG, "token grid must be within 2..32");
   *out = m;
   return EC_OK;
@@ -1559,6 +1664,62 @@ int ec_op_layernorm(const float* x, const float* w, const float* b, float* y, in
   LnP p;
   p.x = x; p.ldx = cols; p.y = y; p.ldy = cols; p.w = w; p.b = b; p.rows = rows; p.cols = cols; p.eps = eps;
   return layernorm(p, (hipStream_t)stream);
+}
+
+int ec_op_chain(const float* X, int K1, const float* W1, const float* b1, const float* resid, const float* ln1_w, const float* ln1_b,
+                float* x1_out, const float* cat, int Kcat, const float* W2, const float* b2, int N2, int act2, const float* table,
+                int period, float* out2, const float* W3, const float* b3, const float* ln3_w, const float* ln3_b, float* x3_out,
+                int rows, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  EC_REQUIRE(X && W1 && ln1_w && ln1_b && x1_out && W2 && out2 && rows > 0, EC_ERR_ARG, "ec_op_chain: missing argument");
+  EC_REQUIRE(K1 % 128 == 0 && Kcat % 128 == 0 && N2 % 128 == 0 && (Kcat == 0 || cat), EC_ERR_ARG, "ec_op_chain: shapes");
+  std::vector<void*> tmp;
+  auto pack = [&](const float* Wd, int N, int K, const void** out) -> int {   // device fp32 [N,K] -> chain packing on device
+    std::vector<float> h((size_t)N * K), pk((size_t)N * K);
+    EC_HIP(hipMemcpy(h.data(), Wd, h.size() * 4, hipMemcpyDeviceToHost));
+    pack_chain_weights(h.data(), N, K, pk.data());
+    void* d = nullptr;
+    EC_HIP(hipMalloc(&d, pk.size() * 4));
+    tmp.push_back(d);
+    EC_HIP(hipMemcpy(d, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+    *out = d;
+    return 0;
+  };
+  EC_HIP(hipStreamSynchronize(st));
+  ChainP p;
+  int top = CH_LDS0;
+  auto buf = [&](int k) { const int o = top; top += chain_layout_bytes(k); return o; };
+  int rc = 0;
+  {
+    ChainStage& S = p.st[p.n_stages++];
+    rc = pack(W1, 256, K1, &S.W);
+    S.bias = b1; S.N = 256; S.K = K1; S.k1 = K1;
+    S.g_in = X; S.ld_in = K1; S.g_k = K1; S.g_off = buf(K1); S.a_off = S.g_off;
+    S.resid = resid; S.ldr = 256; S.ln_w = ln1_w; S.ln_b = ln1_b;
+    S.out = x1_out; S.ldo = 256; S.s_off = buf(256); S.keep = W3 ? 1 : 0;
+  }
+  if (!rc) {
+    ChainStage& S = p.st[p.n_stages++];
+    rc = pack(W2, N2, 256 + Kcat, &S.W);
+    S.bias = b2; S.N = N2; S.K = 256 + Kcat; S.k1 = 256; S.a_off = p.st[0].s_off;
+    if (Kcat) { S.g_in = cat; S.ld_in = Kcat; S.g_k = Kcat; S.g_off = Kcat <= K1 ? p.st[0].g_off : buf(Kcat); S.b_off = S.g_off; }
+    S.act = act2; S.table = table; S.ldt = N2; S.period = period > 0 ? period : 1;
+    S.out = out2; S.ldo = N2;
+    if (W3) S.s_off = buf(N2);
+  }
+  if (!rc && W3) {
+    EC_REQUIRE(ln3_w && ln3_b && x3_out, EC_ERR_ARG, "ec_op_chain: third stage arguments");
+    ChainStage& S = p.st[p.n_stages++];
+    rc = pack(W3, 256, N2, &S.W);
+    S.bias = b3; S.N = 256; S.K = N2; S.k1 = N2; S.a_off = p.st[1].s_off;
+    S.resid_keep = 1; S.ln_w = ln3_w; S.ln_b = ln3_b;
+    S.out = x3_out; S.ldo = 256;
+  }
+  p.rows = rows; p.lds_bytes = top;
+  if (!rc) rc = run_chain(p, st);
+  (void)hipStreamSynchronize(st);
+  for (void* d : tmp) (void)hipFree(d);
+  return rc;
 }
 
 int ec_op_attention(const float* q, const float* k, const float* v, const uint8_t* kmask, const float* bias, float* o, int B, int H,

@@ -179,6 +179,17 @@ int ec_op_gemm_bench(const void* A_dev, const void* W_dev, const float* bias_dev
 int ec_op_bgemm(const float* A_dev, const float* B_dev, float* C_dev, int batch, int M, int N, int K, int transB, void* stream);
 int ec_op_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev, int rows, int cols,
                     float eps, void* stream);
+/* Row-chain kernel of the head (ec_chain.hip; bf16x3 arithmetic), up to three stages over `rows` token rows in ONE launch:
+ *     x1   = LayerNorm_1(resid + X @ W1^T + b1)                              X [rows,K1], W1 [256,K1]  -> x1_out [rows,256]
+ *     out2 = act2([x1 | cat] @ W2^T + b2 + table[row % period])              W2 [N2, 256 + Kcat]       -> out2 [rows,N2]
+ *     x3   = LayerNorm_3(x1 + out2 @ W3^T + b3)                              W3 [256, N2]              -> x3_out [rows,256]
+ * (transformer.py-style residual blocks: EdgeCape/models/keypoint_heads/encoder_decoder.py:461-483, 596-649).  Weights are plain
+ * fp32 [N,K] device arrays (packed inside).  cat / table / the whole third stage (W3 = NULL) are optional; resid may alias x1_out;
+ * LayerNorm eps = 1e-5; act2: 0 none, 1 relu, 2 gelu(erf).  K1, Kcat, N2 multiples of 128. */
+int ec_op_chain(const float* X_dev, int K1, const float* W1_dev, const float* b1_dev, const float* resid_dev, const float* ln1_w_dev,
+                const float* ln1_b_dev, float* x1_out_dev, const float* cat_dev, int Kcat, const float* W2_dev, const float* b2_dev,
+                int N2, int act2, const float* table_dev, int period, float* out2_dev, const float* W3_dev, const float* b3_dev,
+                const float* ln3_w_dev, const float* ln3_b_dev, float* x3_out_dev, int rows, void* stream);
 /* softmax(q k^T * hd^-0.5 + bias, key mask) v ; q [B,Lq,H*hd], k,v [B,Lk,H*hd]; kmask [B,Lk] uint8 (1 = masked) or NULL;
  * bias [B,H,Lq,Lk] or NULL. */
 int ec_op_attention(const float* q_dev, const float* k_dev, const float* v_dev, const uint8_t* kmask_dev,

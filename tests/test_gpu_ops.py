@@ -384,3 +384,54 @@ def test_attention_fp16_large_logits(lib):
     torch.cuda.synchronize()
     assert torch.isfinite(od).all()
     assert (od.cpu() - ref).abs().max().item() < 5e-3
+
+
+@pytest.mark.parametrize("rows,K1,Kcat,N2,act2,period,third", [
+    (3200, 256, 256, 512, 0, 0, False),     # decoder: out_proj + norm1 -> q_proj([x | qpe])
+    (3200, 512, 0, 768, 0, 0, False),       # decoder: fold + norm2 -> ffn1
+    (3200, 768, 0, 768, 0, 0, False),       # skeleton: ffn2 + norm3 -> next in_proj
+    (1000, 256, 0, 384, 1, 0, True),        # encoder: out_proj + norm1 -> linear1 + ReLU -> linear2 + norm2
+    (77, 384, 128, 1536, 2, 0, False),      # ragged slab, GELU, wide second stage (six passes)
+    (648, 512, 0, 1024, 0, 324, False),     # image lane: fold + norm4 -> K|V projection + positional table
+    (31, 256, 0, 256, 0, 0, True),          # fewer rows than one slab
+])
+def test_row_chain(lib, rows, K1, Kcat, N2, act2, period, third):
+    """Row-chain kernel (ec_chain.hip, bf16x3) vs fp64 math of the same residual blocks."""
+    g = torch.Generator().manual_seed(rows + K1 + N2)
+    X = torch.randn(rows, K1, generator=g)
+    W1 = torch.randn(256, K1, generator=g) / K1 ** 0.5
+    b1 = torch.randn(256, generator=g)
+    R = torch.randn(rows, 256, generator=g)
+    g1, be1 = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+    cat = torch.randn(rows, Kcat, generator=g) if Kcat else None
+    K2 = 256 + Kcat
+    W2 = torch.randn(N2, K2, generator=g) / K2 ** 0.5
+    b2 = torch.randn(N2, generator=g)
+    table = torch.randn(period, N2, generator=g) if period else None
+    W3 = torch.randn(256, N2, generator=g) / N2 ** 0.5 if third else None
+    b3 = torch.randn(256, generator=g) if third else None
+    g3, be3 = (torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)) if third else (None, None)
+
+    ln = lambda v, w, b: torch.nn.functional.layer_norm(v, (256,), w.double(), b.double(), 1e-5)
+    x1 = ln(R.double() + X.double() @ W1.double().T + b1.double(), g1, be1)
+    x2in = torch.cat([x1, cat.double()], 1) if Kcat else x1
+    o2 = x2in @ W2.double().T + b2.double()
+    if period:
+        o2 = o2 + table.double()[torch.arange(rows) % period]
+    o2 = {0: o2, 1: o2.relu(), 2: torch.nn.functional.gelu(o2)}[act2]
+    x3 = ln(x1 + o2 @ W3.double().T + b3.double(), g3, be3) if third else None
+
+    dev = lambda t: t.cuda() if t is not None else None
+    Xd, W1d, b1d, Rd, g1d, be1d, catd, W2d, b2d, td, W3d, b3d, g3d, be3d = map(dev, (X, W1, b1, R, g1, be1, cat, W2, b2, table, W3, b3, g3, be3))
+    x1d = Rd.clone()                                   # residual aliased with the output, as the head uses it
+    o2d = torch.full((rows, N2), float("nan"), device="cuda")
+    x3d = torch.full((rows, 256), float("nan"), device="cuda") if third else None
+    _chk(lib, lib.ec_op_chain(_p(Xd), K1, _p(W1d), _p(b1d), _p(x1d), _p(g1d), _p(be1d), _p(x1d), _p(catd), Kcat, _p(W2d), _p(b2d), N2,
+                              act2, _p(td), period, _p(o2d), _p(W3d), _p(b3d), _p(g3d), _p(be3d), _p(x3d), rows, None))
+    torch.cuda.synchronize()
+    e1 = (x1d.cpu().double() - x1).abs().max().item()
+    e2 = (o2d.cpu().double() - o2).abs().max().item()
+    assert e1 < 5e-5 and e2 < 1e-4, (e1, e2)           # bf16x3: ~2^-17 relative per operand, |values| of a few units
+    if third:
+        e3 = (x3d.cpu().double() - x3).abs().max().item()
+        assert e3 < 1e-4, e3
