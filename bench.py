@@ -41,33 +41,31 @@ def parse():
     ap.add_argument("--shots", type=int, default=1)
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--arch", default="dinov2_vitb14")
-    ap.add_argument("--precision", default=os.environ.get("EC_BENCH_PRECISION", "bf16"), choices=["bf16", "fp16", "bf16x3", "fp32"],
-                    help="backbone MFMA operand type (fp32 accumulate)")
+    ap.add_argument("--precision", default=os.environ.get("EC_BENCH_PRECISION", "fp16"), choices=["bf16", "fp16", "bf16x3", "fp32"],
+                    help="backbone MFMA operand type (fp32 accumulate).  Default fp16: same MFMA rate as bf16, 8x smaller rounding - the "
+                         "fastest mode whose keypoints stay inside the 1e-3 tolerance (tests/test_gpu_precision_modes.py)")
     ap.add_argument("--head-precision", default=os.environ.get("EC_BENCH_HEAD_PRECISION", "bf16x3"), choices=["fp32", "bf16x3"],
                     help="head GEMMs: exact fp32 MFMA, or split-bf16 (hi+lo, 3 MFMAs per product; fp32-class accuracy)")
-    ap.add_argument("--cpu-sample", type=int, default=4, help="pairs in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-batches", default="2,32", help="batch sizes of the CPU-baseline protocol (BASELINE.md §4)")
+    ap.add_argument("--cpu-runs", type=int, default=5, help="timed CPU forwards per batch size (after 2 warm-ups)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-episode", action="store_true", help="skip the auxiliary episode-cached measurement")
+    ap.add_argument("--no-alt", action="store_true", help="skip the short bf16 comparison run")
     return ap.parse_args()
 
 
 def main():
     args = parse()
     import torch
-    import torch.distributed as dist
     from edgecape_amd import synth
     from edgecape_amd.engine import HipEngine
     from edgecape_amd.evaluation import pck_counts, pck_from_counts
-    from edgecape_amd import apis, _lib
+    from edgecape_amd import apis, _lib, build
 
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    # one process per GPU; the same helpers the world-size-2 gloo tests drive (tests/test_dist_gloo.py)
+    rank, world, local_rank = apis.init_distributed("nccl")
     if world != args.gpus and rank == 0:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
 
     bs, S, H, arch = args.batch, args.shots, args.image_size, args.arch
     a = synth.ARCHS[arch]
@@ -75,8 +73,6 @@ def main():
     g = H // 14
     T = g * g + 1
     sd = synth.make_weights(arch, seed=0)
-    eng = HipEngine(sd, arch=arch, image_size=H, max_batch=bs, max_shots=S, backbone_precision=args.precision,
-                    head_precision=args.head_precision)
 
     # this rank's shard: global pair indices rank*bs .. rank*bs+bs-1 (fixed per-GPU work => weak scaling)
     batch = synth.make_pairs(bs, S, H, seed=1000, first_index=rank * bs, fixed_n_kp=False)
@@ -88,49 +84,35 @@ def main():
     for tw in batch["target_weight_s"]:
         mask = mask * tw
     ms = dev(mask.reshape(bs, -1))
-    edges, off = eng._edges([m["sample_skeleton"][0] for m in batch["img_metas"]], bs)
-    outputs = eng._outputs(bs)
 
-    def step():
-        eng.forward_resident(iq, is_, ts, ms, edges, off, outputs)
+    def timed_run(precision, steps, warmup, profile):
+        """`warmup` + `steps` passes of the hot path in `precision`; returns (engine, outputs, seconds (max over ranks), mean QKV launch ms)."""
+        eng = HipEngine(sd, arch=arch, image_size=H, max_batch=bs, max_shots=S, backbone_precision=precision,
+                        head_precision=args.head_precision)
+        edges, off = eng._edges([m["sample_skeleton"][0] for m in batch["img_metas"]], bs)
+        outputs = eng._outputs(bs)
+        step = lambda: eng.forward_resident(iq, is_, ts, ms, edges, off, outputs)
+        arm = (lambda: _lib.check(eng.lib.ec_profile(eng.h, 1, steps * depth))) if profile else None
+        # the only cross-GPU exchange of the job: the PCK counters (their values are computed after the timed region from the
+        # last step's outputs; the collective itself sits inside the timed region so its cost is charged)
+        dt = apis.timed_steps(step, steps, warmup, collective=lambda: apis.allreduce_counts(np.zeros(6)), before_timed=arm)
+        qkv_ms = 0.0
+        if profile:
+            import ctypes as Ct
+            tot_ms, nl = Ct.c_float(), Ct.c_int()
+            _lib.check(eng.lib.ec_profile_read(eng.h, Ct.byref(tot_ms), Ct.byref(nl)))
+            _lib.check(eng.lib.ec_profile(eng.h, 0, 0))
+            qkv_ms = tot_ms.value / max(nl.value, 1)
+        return eng, outputs, dt, qkv_ms
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    n_launch = args.steps * depth
-    _lib.check(eng.lib.ec_profile(eng.h, 1, n_launch))
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    # the only cross-GPU exchange of the job: PCK counters (computed after the timed region from the last step's
-    # outputs; the collective itself is inside the timed region so its cost is charged)
-    if world > 1:
-        token = torch.zeros(6, dtype=torch.float64, device="cuda")
-        dist.all_reduce(token)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
-    import ctypes as Ct
-    tot_ms, nl = Ct.c_float(), Ct.c_int()
-    _lib.check(eng.lib.ec_profile_read(eng.h, Ct.byref(tot_ms), Ct.byref(nl)))
-    _lib.check(eng.lib.ec_profile(eng.h, 0, 0))
-    qkv_ms = tot_ms.value / max(nl.value, 1)
+    eng, outputs, dt, qkv_ms = timed_run(args.precision, args.steps, args.warmup, True)
     Mq, Kq, Nq = (1 + S) * bs * T, C, 3 * C
     qkv_flops = 2.0 * Mq * Kq * Nq
     achieved = qkv_flops / (qkv_ms * 1e-3) / 1e12 if qkv_ms > 0 else 0.0
     peak = PEAK_TFLOPS[args.precision]
 
-    # ---- accuracy bookkeeping on this rank's last outputs: PCK vs the synthetic ground truth
+    # ---- accuracy bookkeeping on this rank's last outputs: PCK vs the synthetic ground truth (random weights: chance level; the
+    # meaningful agreement figures are in `parity_sample`: HIP predictions against the oracle's on the same pairs)
     out_k = outputs[0]["output_kpts"][-1].cpu().numpy()            # [bs,K,2] normalised
     scale200 = np.stack([m["query_scale"] for m in batch["img_metas"]]) * 200.0
     center = np.stack([m["query_center"] for m in batch["img_metas"]])
@@ -144,40 +126,61 @@ def main():
     result = None
     if rank == 0:
         value = world * bs * args.steps / dt
+        dname = {"bf16": "bf16", "fp16": "f16", "bf16x3": "bf16x3", "fp32": "f32"}
         result = {
             "metric": "query images/sec (1-shot, 256x256, DINOv2 ViT-B/14 + EdgeCape head, forward_test)",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"bf16": "bf16", "fp16": "f16", "bf16x3": "bf16x3", "fp32": "f32"}[args.precision], "data": "synthetic",
+            "vs_baseline": None, "dtype": dname[args.precision], "data": "synthetic",
             "config": {"workload": f"{S}-shot split1-style synthetic pairs, batch={bs}/GPU, {H}x{H}, {arch}, K=100 padded keypoints, "
                                    f"backbone {args.precision} MFMA / fp32 accumulate, head {args.head_precision}",
                        "global_batch": world * bs, "parallelism": f"dp{world} (independent pair shards, one all-reduce of PCK counters)"},
             "roofline": {"bound": "mfma", "kernel": f"backbone QKV GEMM M={Mq} K={Kq} N={Nq} ({args.precision})",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "flops_per_launch": qkv_flops, "avg_launch_ms": round(qkv_ms, 5), "launches_timed": nl.value,
-                         **pmc_traffic(args, bs, S, H, arch)},
+                         "flops_per_launch": qkv_flops, "avg_launch_ms": round(qkv_ms, 5), "launches_timed": args.steps * depth,
+                         **pmc_traffic(args, bs, S, H, arch, build.source_hash())},
             "pck_vs_synthetic_gt": {k: round(v, 4) for k, v in pck.items()},
+            # every switch that changes what the library runs (README "Runtime switches"): none set = the shipped defaults
+            "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("EC_")},
+            "library_source_hash": build.source_hash()[:16],
         }
         if world == 1 and not args.no_episode:
             result["episode_cached"] = episode_mode(args, eng, synth, batch, bs, S, H)
-        if not args.no_cpu_baseline and args.cpu_sample > 0 and world == 1:
+        if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"], result["parity_sample"] = cpu_baseline(args, sd, eng, synth)
+    if world == 1 and not args.no_alt and args.precision != "bf16":
+        # the same step with bf16 operands (north_star's wording): same kernels and rate, 8x coarser rounding - measured beside the
+        # headline so both precisions come from one process on one box; it does NOT meet the 1e-3 gate (test_bf16_mode_cfg2_bounded)
+        del eng, outputs
+        torch.cuda.empty_cache()
+        _, _, dt_b, qkv_b = timed_run("bf16", max(5, args.steps // 2), args.warmup, True)
+        n_b = max(5, args.steps // 2)
+        result["bf16_mode"] = {"value": round(bs * n_b / dt_b, 2), "unit": "images/s", "ms_per_step": round(dt_b / n_b * 1e3, 3),
+                               "qkv_launch_ms": round(qkv_b, 5), "qkv_frac": round(qkv_flops / (qkv_b * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"], 4) if qkv_b > 0 else None,
+                               "note": "bf16 backbone operands; outside the 1e-3 tolerance (max 2.2e-3 on flip-free samples, 0.5 % argmax flips)"}
+    if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    apis.finalize_distributed()
     return result
 
 
-def pmc_traffic(args, bs, S, H, arch):
-    """`traffic` cannot be measured from inside the process: it comes from the committed rocprofv3 --pmc summary of THIS
-    command (profiles/r01_qkv_gemm_pmc.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction,
-    MI355X_MICROARCH.md §HBM) and is only reported for the workload that summary was collected on."""
-    path = os.path.join(ROOT, "profiles", "r01_qkv_gemm_pmc.json")
-    if not (os.path.exists(path) and args.precision == "bf16" and (bs, S, H, arch) == (32, 1, 256, "dinov2_vitb14")):
-        return {"traffic": None}
+def pmc_traffic(args, bs, S, H, arch, source_hash):
+    """`traffic` cannot be measured from inside the process: it comes from the committed rocprofv3 --pmc summary of THIS command
+    (profiles/qkv_gemm_pmc.json, written by tools/refresh_pmc.py on the GPU box: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2
+    read correction, MI355X_MICROARCH.md §HBM).  It is only reported when that summary was collected on this workload AND on this
+    library: the summary carries the sha256 of the kernel sources it measured (edgecape_amd.build.source_hash); any edit of a
+    kernel makes it stale and `traffic` null until tools/refresh_pmc.py is run again."""
+    path = os.path.join(ROOT, "profiles", "qkv_gemm_pmc.json")
+    if not os.path.exists(path):
+        return {"traffic": None, "traffic_note": "no PMC summary (tools/refresh_pmc.py)"}
     d = json.load(open(path))
+    if d.get("source_hash") != source_hash:
+        return {"traffic": None, "traffic_note": f"stale PMC summary: collected on library {str(d.get('source_hash'))[:16]}, this is {source_hash[:16]}"}
+    if d.get("workload") != [bs, S, H, arch, args.precision]:
+        return {"traffic": None, "traffic_note": f"PMC summary is for workload {d.get('workload')}"}
     return {"traffic": d["traffic_bytes_per_launch"], "traffic_unit": "bytes/launch (L2 miss traffic incl. Infinity-Cache hits)",
-            "algorithmic_bytes": d["algorithmic_bytes_per_launch"], "mfma_util_pmc": d["mfma_util"], "traffic_source": "profiles/r01_qkv_gemm_pmc.json"}
+            "algorithmic_bytes": d["algorithmic_bytes_per_launch"], "traffic_over_algorithmic": round(d["traffic_bytes_per_launch"] / d["algorithmic_bytes_per_launch"], 3),
+            "mfma_util_pmc": d.get("mfma_util"), "traffic_source": "profiles/qkv_gemm_pmc.json"}
 
 
 def episode_mode(args, eng, synth, batch, bs, S, H, steps=5):
@@ -210,34 +213,59 @@ def episode_mode(args, eng, synth, batch, bs, S, H, steps=5):
             "ms_per_step": round(dt * 1e3, 3), "note": "support side encoded once per episode (SURVEY §8f rank 1); not the headline metric"}
 
 
+def physical_cores():
+    """Physical cores this process may run on (one per set of SMT siblings inside the affinity mask)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except Exception:
+        allowed = list(range(os.cpu_count() or 1))
+    seen = set()
+    for c in allowed:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+        except Exception:
+            sib = str(c)
+        seen.add(sib)
+    return max(1, len(seen)), len(allowed)
+
+
 def cpu_baseline(args, sd, eng, synth):
-    """Time the CPU oracle (torch fp32 eager restatement of the reference, kind="port") on a bounded sample of the
-    same workload and use the same sample as an on-box parity check of the HIP path."""
+    """Time the CPU oracle (torch fp32 eager restatement of the reference, kind="port") on the host cores, BASELINE.md §4
+    protocol: identical seeded pairs, 2 warm-ups + median of >= 5 timed forwards at bs = 2 and bs = 32, torch threads = physical
+    cores unless a one-off sweep at bs = 2 (recorded) finds a faster count.  The bs = 32 batch doubles as the on-box parity sample
+    of the HIP path (same pairs as rank 0's shard)."""
     import torch
     from oracle import edgecape_oracle as orc   # checker / baseline only — never the product path
-    n = args.cpu_sample
     S, H, arch = args.shots, args.image_size, args.arch
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
-    threads = min(cores, 32)   # torch CPU eager stops scaling (and degrades badly) beyond a few dozen threads on these op sizes
-    torch.set_num_threads(threads)
-    batch = synth.make_pairs(n, S, H, seed=1000, fixed_n_kp=False)
     heads = synth.ARCHS[arch]["heads"]
-    t0 = time.perf_counter()
-    res, out = orc.forward_test(sd, batch, heads)          # warm-up + reference outputs
-    t_first = time.perf_counter() - t0
-    times = []
-    budget = 25.0 - t_first
-    while len(times) < 3 and budget > t_first:
+    phys, logical = physical_cores()
+    batches = [int(x) for x in args.cpu_batches.split(",") if x]
+    small = synth.make_pairs(min(batches), S, H, seed=1000, fixed_n_kp=False)
+    # thread sweep (one warm-up + one timed forward each): eager CPU kernels of this size stop scaling well below a two-socket core count
+    sweep = {}
+    cand = sorted({t for t in (8, 16, 32, 64, 96, phys) if t <= max(phys, 8)})
+    for t in cand:
+        torch.set_num_threads(t)
+        orc.forward_test(sd, small, heads)
         t0 = time.perf_counter()
-        orc.forward_test(sd, batch, heads)
-        times.append(time.perf_counter() - t0)
-        budget -= times[-1]
-    t = float(np.median(times)) if times else t_first
-    # parity of the HIP path on the same sample (first n pairs of rank 0's shard are exactly these pairs)
+        orc.forward_test(sd, small, heads)
+        sweep[t] = round(time.perf_counter() - t0, 4)
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
+    per_bs = {}
+    out = batch = None
+    for n in batches:
+        batch = small if n == min(batches) else synth.make_pairs(n, S, H, seed=1000, fixed_n_kp=False)
+        for _ in range(2):
+            res, out = orc.forward_test(sd, batch, heads)
+        times = []
+        for _ in range(max(args.cpu_runs, 1)):
+            t0 = time.perf_counter()
+            orc.forward_test(sd, batch, heads)
+            times.append(time.perf_counter() - t0)
+        per_bs[n] = {"pairs_per_s": round(n / float(np.median(times)), 3), "median_s": round(float(np.median(times)), 4), "runs": len(times)}
+    n = batches[-1]
+    # parity of the HIP path on the last (largest) batch: the first n pairs of rank 0's shard are exactly these pairs
     mask = batch["target_weight_s"][0].copy()
     for tw in batch["target_weight_s"]:
         mask = mask * tw
@@ -248,17 +276,24 @@ def cpu_baseline(args, sd, eng, synth):
     d = np.abs(got - ref)[:, valid]
     sim_g = o["similarity_map"].cpu().numpy().reshape(n, 100, -1).argmax(-1)
     sim_r = out["similarity_map"].numpy().reshape(n, 100, -1).argmax(-1)
+    flips = (sim_g != sim_r) & valid
+    clean = ~flips.any(axis=1)                                   # samples without a proposal argmax flip (the reference's one discontinuity)
+    d_clean = np.abs(got - ref)[:, clean][:, valid[clean]] if clean.any() else np.zeros(1)
     pred_g, pred_r = got[-1] * H, ref[-1] * H
     thr = 0.2 * H
-    gt = batch["gt_q"]
-    pck_g = float((np.linalg.norm(pred_g - gt, axis=-1)[valid] < thr).mean())
-    pck_r = float((np.linalg.norm(pred_r - gt, axis=-1)[valid] < thr).mean())
-    parity = {"pairs": n, "max_abs_kpt_err_valid": float(d.max()), "median_abs_kpt_err_valid": float(np.median(d)),
-              "frac_gt_1e-3": float((d > 1e-3).mean()), "argmax_flips": int((sim_g != sim_r)[valid].sum()),
-              "pck@0.2_hip": round(pck_g, 4), "pck@0.2_oracle": round(pck_r, 4), "pck@0.2_delta": round(pck_g - pck_r, 4)}
-    base = {"value": round(n / t, 3), "unit": "images/s", "cores": threads, "host_cpus": cores, "kind": "port",
+    parity = {"pairs": n, "precision": args.precision, "head_precision": args.head_precision, "tolerance": 1e-3,
+              "max_abs_kpt_err_valid": float(d.max()), "max_abs_kpt_err_flip_free": float(d_clean.max()),
+              "p99_abs_kpt_err_valid": float(np.quantile(d, 0.99)), "median_abs_kpt_err_valid": float(np.median(d)),
+              "frac_gt_1e-3": float((d > 1e-3).mean()), "argmax_flips": int(flips.sum()), "valid_keypoints": int(valid.sum()),
+              # PCK@0.2 of the HIP predictions scored against the ORACLE's predictions (1.0 = every keypoint within 0.2 * bbox):
+              # meaningful with random weights, unlike PCK against the synthetic ground truth (chance level for both)
+              "pck@0.2_hip_vs_oracle_pred": round(float((np.linalg.norm(pred_g - pred_r, axis=-1)[valid] < thr).mean()), 4),
+              "within_tolerance": bool(d.max() < 1e-3)}
+    base = {"value": per_bs[n]["pairs_per_s"], "unit": "images/s", "cores": threads, "physical_cores": phys, "logical_cpus": logical,
+            "kind": "port", "per_batch_size": {str(k): v for k, v in per_bs.items()},
+            "thread_sweep_s_at_bs%d" % min(batches): {str(k): v for k, v in sweep.items()},
             "sample": f"{n} pairs ({S}-shot, {H}x{H}, {arch}) through oracle/edgecape_oracle.py forward_test, torch CPU fp32 eager, "
-                      f"median of {max(len(times), 1)} run(s) after 1 warm-up"}
+                      f"2 warm-ups + median of {max(args.cpu_runs, 1)} forwards, {threads} threads (fastest of the sweep; physical cores: {phys})"}
     return base, parity
 
 

@@ -93,11 +93,15 @@ def allreduce_counts(counts, device=None):
     return t.cpu().numpy()
 
 
-def timed_steps(step, steps, warmup, collective=None):
+def timed_steps(step, steps, warmup, collective=None, before_timed=None):
     """bench.py's timed region: `warmup` untimed steps, then EXACTLY `steps` steps between two barriers (device drained on both
-    sides); `collective` (the job's only cross-rank exchange) runs inside the region; returns the MAX over ranks of the wall time."""
+    sides); `collective` (the job's only cross-rank exchange) runs inside the region; `before_timed` (e.g. arming the kernel
+    timers) runs between the warm-up and the first barrier; returns the MAX over ranks of the wall time."""
     for _ in range(warmup):
         step()
+    if before_timed is not None:
+        barrier()
+        before_timed()
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):

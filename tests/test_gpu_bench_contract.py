@@ -10,7 +10,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--steps", "3", "--warmup", "1", "--batch", "4", "--arch", "dinov2_vits14", "--image-size", "224", "--no-episode",
-         "--cpu-sample", "1"]
+         "--cpu-batches", "1,4", "--cpu-runs", "1", "--no-alt"]
 REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data", "config", "roofline", "cpu_baseline"}
 
@@ -34,9 +34,15 @@ def _check(line, with_cpu):
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and 0 < r["frac"] < 1
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["launches_timed"] == 3 * 12
+    assert isinstance(d["env"], dict) and all(k.startswith("EC_") for k in d["env"]) and len(d["library_source_hash"]) == 16
+    assert "traffic" in r and (r["traffic"] is not None or "traffic_note" in r)      # never a number from another library build
     if with_cpu:
         c = d["cpu_baseline"]
-        assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+        assert c["kind"] == "port" and c["value"] > 0 and 1 <= c["cores"] <= c["logical_cpus"] and "sample" in c
+        assert set(c["per_batch_size"]) == {"1", "4"} and c["value"] == c["per_batch_size"]["4"]["pairs_per_s"]
+        ps = d["parity_sample"]                                         # fp16 backbone + bf16x3 head: inside the stated tolerance
+        assert ps["pairs"] == 4 and ps["tolerance"] == 1e-3 and ps["within_tolerance"] and ps["argmax_flips"] == 0
+        assert ps["pck@0.2_hip_vs_oracle_pred"] == 1.0
 
 
 @pytest.mark.gpu
