@@ -1,0 +1,37 @@
+"""Episode construction of the reference's evaluation (EdgeCape/datasets/datasets/mp100/test_dataset.py:86-99).
+
+The MP-100 test protocol draws, per category and episode, `num_shots` support annotations and `num_queries` query annotations and
+evaluates every (support set, query) pair: `num_queries` consecutive pairs share ONE support set.  That is what the support-side
+cache of the HIP path exploits (`ec_support_encode` once per episode, `ec_forward_cached` for its queries).
+
+`make_paired_samples` reproduces the reference's pair list exactly (same RNG protocol: `random.seed(1)`, one `random.sample` per
+category and episode); `group_episodes` turns a pair list into (unique support sets, episode index of every pair).
+"""
+import random
+
+import numpy as np
+
+
+def make_paired_samples(cat2obj, valid_class_ids, num_shots=1, num_queries=15, num_episodes=100, seed=1):
+    """cat2obj: {category id: [annotation ids]}.  Returns int array [n_pairs, num_shots + 1]: support ids then the query id."""
+    rng = random.Random(seed)          # the reference seeds the module-level generator; a private one draws the same sequence
+    pairs = []
+    for cls in valid_class_ids:
+        for _ in range(num_episodes):
+            drawn = rng.sample(cat2obj[cls], num_shots + num_queries)
+            support, queries = drawn[:num_shots], drawn[num_shots:]
+            pairs.extend(support + [q] for q in queries)
+    return np.array(pairs)
+
+
+def group_episodes(paired_samples):
+    """pairs [n, S + 1] -> (support_sets [n_ep, S], episode_of_pair [n] int32): consecutive pairs with the same support ids
+    form one episode (the order the reference's sequential sampler visits them in)."""
+    ps = np.asarray(paired_samples)
+    if ps.size == 0:
+        return ps.reshape(0, max(ps.shape[-1] - 1, 0)), np.zeros(0, np.int32)
+    sup = ps[:, :-1]
+    new = np.ones(len(ps), bool)
+    new[1:] = (sup[1:] != sup[:-1]).any(axis=1)
+    ep = np.cumsum(new).astype(np.int32) - 1
+    return sup[new], ep

@@ -98,6 +98,22 @@ def sort_and_unique_bboxes(kpts, key="bbox_id"):
     return kpts
 
 
+def gt_from_db(joints_3d, joints_3d_visible, bbox, paired_samples):
+    """The per-pair ground truth of TestBaseDataset._report_metric (test_base_dataset.py:96-113) from database arrays:
+    joints_3d / joints_3d_visible [n_obj, K, 3], bbox [n_obj, 4] (x, y, w, h), paired_samples [n_pairs, shots + 1] (support ids, then
+    the query id).  Pair p is scored on the query's joints where the query AND every support annotation mark the keypoint
+    visible, normalised by the longer side of the query's box.  Returns {p: dict(joints, mask, bbox_thr)} for `evaluate`."""
+    J, V, B = np.asarray(joints_3d), np.asarray(joints_3d_visible), np.asarray(bbox)
+    gt = {}
+    for p, pair in enumerate(np.asarray(paired_samples)):
+        q = int(pair[-1])
+        mask = V[q][:, 0] > 0
+        for s in pair[:-1]:
+            mask &= V[int(s)][:, 0] > 0
+        gt[p] = dict(joints=J[q][:, :-1], mask=mask, bbox_thr=float(np.max(B[q][2:])))
+    return gt
+
+
 def evaluate(outputs, gt, res_folder, metric="PCK", image_id_of=None):
     """TestPoseDataset.evaluate: `outputs` = list of per-sample dicts as returned by `single_gpu_test`
     (preds [1,K,3], boxes [1,6], image_paths, bbox_ids); `gt` maps bbox_id -> dict(joints [K,2], mask [K], bbox_thr).

@@ -16,47 +16,40 @@ IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
-def rotate_point(pt, angle_rad):
-    sn, cs = np.sin(angle_rad), np.cos(angle_rad)
-    return np.array([pt[0] * cs - pt[1] * sn, pt[0] * sn + pt[1] * cs])
-
-
-def _get_3rd_point(a, b):
-    direction = a - b
-    return b + np.array([-direction[1], direction[0]], dtype=np.float32)
-
-
-def _affine_from_3_points(src, dst):
-    """cv2.getAffineTransform: the 2x3 matrix M with M @ [x, y, 1] = dst for three point pairs (float64 solve)."""
-    A = np.concatenate([np.asarray(src, np.float64), np.ones((3, 1))], 1)
-    return np.linalg.solve(A, np.asarray(dst, np.float64)).T
-
-
 def get_affine_transform(center, scale, rot, output_size, shift=(0., 0.), inv=False):
-    """post_transforms.py:197-252 (pixel_std = 200)."""
-    center, scale = np.asarray(center, np.float32), np.asarray(scale, np.float32)
-    assert len(center) == 2 and len(scale) == 2 and len(output_size) == 2 and len(shift) == 2
-    scale_tmp = scale * 200.0
-    shift = np.array(shift)
-    src_w, dst_w, dst_h = scale_tmp[0], output_size[0], output_size[1]
-    rot_rad = np.pi * rot / 180
-    src_dir = rotate_point([0., src_w * -0.5], rot_rad)
-    dst_dir = np.array([0., dst_w * -0.5])
-    src = np.zeros((3, 2), dtype=np.float32)
-    src[0, :] = center + scale_tmp * shift
-    src[1, :] = center + src_dir + scale_tmp * shift
-    src[2, :] = _get_3rd_point(src[0, :], src[1, :])
-    dst = np.zeros((3, 2), dtype=np.float32)
-    dst[0, :] = [dst_w * 0.5, dst_h * 0.5]
-    dst[1, :] = np.array([dst_w * 0.5, dst_h * 0.5]) + dst_dir
-    dst[2, :] = _get_3rd_point(dst[0, :], dst[1, :])
-    return _affine_from_3_points(dst, src) if inv else _affine_from_3_points(src, dst)
+    """The 2x3 matrix of the reference's crop warp (post_transforms.py:197-252), in closed form.
+
+    The reference builds three point pairs - the (shifted) box centre, a point half a box width "above" it rotated by `rot`, and
+    a third obtained by a quarter turn of that segment - maps them to the output centre, the point half an OUTPUT width above it
+    and its quarter turn, and lets cv2.getAffineTransform solve for the matrix.  Both triangles are right isosceles with the
+    same orientation, so the solution is the similarity
+        q = s * R(-rot) * (p - c) + d0,     s = output_w / (200 * scale_x),  c = center + 200 * scale * shift,  d0 = output / 2
+    (pixel_std = 200).  inv=True returns the inverse map p = R(rot) * (q - d0) / s + c (the reference swaps the triangles)."""
+    center, scale = np.asarray(center, np.float64), np.asarray(scale, np.float64)
+    assert center.shape == (2,) and scale.shape == (2,) and len(output_size) == 2 and len(shift) == 2
+    box = scale * 200.0
+    c = center + box * np.asarray(shift, np.float64)
+    d0 = np.array([output_size[0] * 0.5, output_size[1] * 0.5])
+    s = output_size[0] / box[0]
+    th = np.pi * rot / 180.0
+    cs, sn = np.cos(th), np.sin(th)
+    if inv:
+        L = np.array([[cs, -sn], [sn, cs]]) / s          # R(rot) / s
+        return np.concatenate([L, (c - L @ d0)[:, None]], 1)
+    L = np.array([[cs, sn], [-sn, cs]]) * s              # s * R(-rot)
+    return np.concatenate([L, (d0 - L @ c)[:, None]], 1)
+
+
+def warp_points(pts, trans_mat):
+    """Apply a 2x3 affine matrix to points [..., 2] (post_transforms.py:255-270, vectorised)."""
+    pts = np.asarray(pts, np.float64)
+    M = np.asarray(trans_mat, np.float64)
+    return pts @ M[:, :2].T + M[:, 2]
 
 
 def affine_transform(pt, trans_mat):
-    """post_transforms.py:255-270."""
     assert len(pt) == 2
-    return np.array(trans_mat) @ np.array([pt[0], pt[1], 1.])
+    return warp_points(pt, trans_mat)
 
 
 def gaussian_7x7(sigma=1):

@@ -194,7 +194,182 @@ def hf_backbone_fixture(name, arch, image_size, seed):
     save(name, arrays, meta)
 
 
+def fuse_self_attn_in_proj(sub):
+    """q/k/v_proj of every decoder self-attention -> the fused in_proj_weight / in_proj_bias keys of a checkpoint written before
+    the attention module was swapped (what BiasedMultiheadAttention._load_from_state_dict, bias_attn.py:236-265, accepts)."""
+    out = dict(sub)
+    for k in list(sub):
+        if k.endswith("self_attn.q_proj.weight"):
+            base = k[:-len("q_proj.weight")]
+            for kind, fused in (("weight", "in_proj_weight"), ("bias", "in_proj_bias")):
+                parts = [out.pop(base + f"{n}_proj.{kind}") for n in "qkv"]
+                out[base + fused] = torch.cat(parts, 0)
+    return out
+
+
+def fused_checkpoint_fixture(ns, name, C, g, shots, n_kps, skeletons, seed):
+    """the reference head loads a checkpoint with FUSED decoder in_proj keys through its own
+    _load_from_state_dict; outputs of that head are the fixture (the product loads the same file through load_checkpoint)."""
+    wseed = 7
+    sd = synth.make_head_weights(C=C, seed=wseed)
+    prefix = "keypoint_head_module."
+    sub = {k[len(prefix):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith(prefix)}
+    fused = fuse_self_attn_in_proj(sub)
+    n_fused = sum(k.endswith("in_proj_weight") and ".decoder." in k and "self_attn" in k for k in fused)
+    assert n_fused >= 3 and not any(k.endswith("self_attn.q_proj.weight") for k in fused)
+    head = build_ref_head(ns, C)
+    missing, unexpected = head.load_state_dict(fused, strict=True)
+    assert not missing and not unexpected
+    head_plain = build_ref_head(ns, C)
+    load_head_weights(head_plain, sd)
+    inp = synth.make_head_inputs(len(n_kps), shots, C, g, seed, n_kps, skeletons)
+    args = (torch.from_numpy(inp["feature_q"]), [torch.from_numpy(f) for f in inp["feature_s"]],
+            [torch.from_numpy(t) for t in inp["target_s"]], torch.from_numpy(inp["mask_s"]), inp["skeleton"])
+    with torch.no_grad():
+        out, init_prop, sim, _, adj = head(*args)
+        out_p = head_plain(*args)[0]
+    arrays = dict(output_kpts=out.numpy(), initial_proposals=init_prop.numpy(), similarity_map=sim.numpy(), adj=adj.numpy())
+    meta = dict(kind="head_fused_checkpoint", C=C, g=g, shots=shots, n_kps=n_kps, skeletons=skeletons, input_seed=seed, weight_seed=wseed,
+                fused_layers=int(n_fused), max_abs_diff_vs_unfused_load=float((out - out_p).abs().max()),
+                reference="orhir/EdgeCape TwoStageHead loaded from fused self_attn.in_proj_* keys via bias_attn.py:236-265")
+    save(name, arrays, meta)
+
+
+def _metric_fns():
+    from edgecape_amd import evaluation as ev
+    return dict(keypoint_pck_accuracy=ev.keypoint_pck_accuracy, keypoint_auc=ev.keypoint_auc, keypoint_nme=ev.keypoint_nme,
+                keypoint_epe=ev.keypoint_epe)
+
+
+def geometry_fixture(ns, name, seed=401):
+    """SURVEY §8f rank 3 (host geometry): get_affine_transform / affine_transform of post_transforms.py:197-270 on seeded boxes."""
+    rng = np.random.default_rng(seed)
+    n = 48
+    center = rng.uniform(20, 600, (n, 2)).astype(np.float32)
+    scale = rng.uniform(0.25, 4.0, (n, 2)).astype(np.float32)
+    scale[::2, 1] = scale[::2, 0]                       # the test pipeline's boxes are square; keep both kinds
+    rot = np.where(np.arange(n) % 3 == 0, 0.0, rng.uniform(-80, 80, n))
+    shift = np.where((np.arange(n) % 4 == 0)[:, None], rng.uniform(-0.15, 0.15, (n, 2)), 0.0)
+    out_size = np.array([[256, 256], [224, 224], [384, 384], [64, 64]])[np.arange(n) % 4]
+    fwd = np.stack([ns.post.get_affine_transform(center[i], scale[i], rot[i], out_size[i], shift=tuple(shift[i])) for i in range(n)])
+    inv = np.stack([ns.post.get_affine_transform(center[i], scale[i], rot[i], out_size[i], shift=tuple(shift[i]), inv=True) for i in range(n)])
+    pts = rng.uniform(0, 640, (n, 17, 2))
+    warped = np.stack([[ns.post.affine_transform(pts[i, j], fwd[i]) for j in range(17)] for i in range(n)])
+    arrays = dict(center=center, scale=scale, rot=rot.astype(np.float64), shift=shift.astype(np.float64), out_size=out_size.astype(np.int64),
+                  fwd=fwd.astype(np.float64), inv=inv.astype(np.float64), pts=pts.astype(np.float64), warped=warped.astype(np.float64))
+    arrays = {k: np.ascontiguousarray(v) for k, v in arrays.items()}
+    meta = dict(kind="geometry", seed=seed, cv2_getAffineTransform="float64 3-point solve stand-in (cv2 absent)",
+                reference="EdgeCape/models/utils/post_processing/post_transforms.py:197-270 get_affine_transform / affine_transform")
+    os.makedirs(OUT, exist_ok=True)
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)      # (float64 kept: `save` would narrow to float32)
+    print(name)
+
+
+def msra_fixture(ns, name, seed=402):
+    """Rows a33 / §8f rank 3: TopDownGenerateTargetFewShot._msra_generate_target (top_down_transform.py:113-199), sigma = 1,
+    on seeded joints that include every border case of the 3-sigma patch."""
+    gen = ns.pipe.TopDownGenerateTargetFewShot(sigma=1)
+    rng = np.random.default_rng(seed)
+    cases = []
+    for image_size, hm in ((256, 64), (224, 64), (384, 64), (256, 32)):
+        K = 40
+        j = rng.uniform(0, image_size, (K, 3))
+        j[:, 2] = 0
+        border = np.array([[-30, 10], [-11.9, 50], [-2, -2], [0, 0], [1.9, 2.1], [image_size - 0.1, image_size - 0.1], [image_size + 9, 40],
+                           [image_size + 14.1, 40], [image_size * 2, 5], [40, -13.9], [40, -14.1], [image_size / 2, image_size / 2],
+                           [image_size / hm * 7.5, image_size / hm * 8.49999], [image_size / hm * 63.49, image_size / hm * 0.5]])
+        j[:len(border), :2] = border
+        v = (rng.uniform(0, 1, (K, 1)) > 0.25).astype(np.float32) * np.where(rng.uniform(0, 1, (K, 1)) > 0.5, 2.0, 1.0)
+        v[:len(border)] = 1.0
+        vis = np.concatenate([v, v, np.zeros_like(v)], 1).astype(np.float32)
+        cfg = dict(image_size=np.array([image_size, image_size]), heatmap_size=np.array([hm, hm]), joint_weights=None,
+                   use_different_joint_weights=False)
+        target, weight = gen._msra_generate_target(cfg, j.astype(np.float32), vis, 1)
+        cases.append((image_size, hm, j.astype(np.float32), vis, target, weight))
+    arrays = {}
+    for i, (isz, hm, j, vis, t, w) in enumerate(cases):
+        arrays[f"joints_{i}"], arrays[f"visible_{i}"], arrays[f"target_{i}"], arrays[f"weight_{i}"] = j, vis, t, w
+    meta = dict(kind="msra", seed=seed, cases=[[c[0], c[1]] for c in cases], sigma=1,
+                reference="EdgeCape/datasets/pipelines/top_down_transform.py:113-199 _msra_generate_target (unbiased_encoding=False)")
+    save(name, arrays, meta)
+
+
+def dataset_fixture(ns, name, seed=403):
+    """Rows a30-a32 / §8f ranks 1 and 4: the reference's episode pairing (test_dataset.py:86-99) and its evaluate ->
+    result_keypoints.json -> _report_metric plumbing (test_dataset.py:254-319, test_base_dataset.py:71-155) on a synthetic db.
+    The mmpose metric functions inside _report_metric are edgecape_amd.evaluation's restatement (mmpose is absent): this pins the
+    plumbing - record assembly, sort/unique, masks, bbox normalisation, per-pair averaging, mPCK - not the mmpose arithmetic."""
+    import tempfile
+    TD = ns.test_dataset.TestPoseDataset
+    rng = np.random.default_rng(seed)
+    K = 100
+    n_obj = 60
+    db = []
+    for i in range(n_obj):
+        nk = int(rng.integers(3, 25))
+        j3 = np.zeros((K, 3), np.float32)
+        j3[:nk, :2] = rng.uniform(10, 500, (nk, 2))
+        v3 = np.zeros((K, 3), np.float32)
+        v3[:nk, :2] = (rng.uniform(0, 1, (nk, 1)) > 0.2).astype(np.float32)
+        w, h = rng.uniform(40, 400, 2)
+        db.append(dict(image_file=f"data/mp100/cat{i % 4}/img_{i:04d}.jpg", joints_3d=j3, joints_3d_visible=v3,
+                       bbox=np.array([rng.uniform(0, 100), rng.uniform(0, 100), w, h], np.float32), bbox_id=i, head_size=None))
+    ds = object.__new__(TD)
+    ds.db = db
+    ds.img_prefix = "data/mp100/"
+    ds.name2id = {d["image_file"][len(ds.img_prefix):]: 1000 + i for i, d in enumerate(db)}
+    ds.PCK_threshold_list = [0.05, 0.1, 0.15, 0.2, 0.25]
+    ds.num_shots, ds.num_queries, ds.num_episodes = 2, 5, 3
+    ds.valid_class_ids = [3, 7, 11, 12]
+    ds.cat2obj = {c: [i for i in range(n_obj) if i % 4 == k] for k, c in enumerate(ds.valid_class_ids)}
+    ds.make_paired_samples()
+    pairs = np.array(ds.paired_samples)
+    # synthetic model outputs per pair, batched in threes, with one duplicated record (sampler padding)
+    preds = rng.uniform(0, 500, (len(pairs), K, 3)).astype(np.float32)
+    for p, pair in enumerate(pairs):                  # make them plausible: query gt + noise on most keypoints
+        gt = db[pair[-1]]["joints_3d"][:, :2]
+        preds[p, :, :2] = gt + rng.normal(0, 12, (K, 2)).astype(np.float32)
+    boxes = rng.uniform(0, 300, (len(pairs), 6)).astype(np.float32)
+    outputs = []
+    for s in range(0, len(pairs), 3):
+        idx = list(range(s, min(s + 3, len(pairs))))
+        outputs.append(dict(preds=preds[idx], boxes=boxes[idx], image_paths=[db[pairs[i][-1]]["image_file"] for i in idx],
+                            bbox_ids=[int(i) for i in idx]))
+    outputs.append(dict(preds=preds[:1], boxes=boxes[:1], image_paths=[db[pairs[0][-1]]["image_file"]], bbox_ids=[0]))
+    with tempfile.TemporaryDirectory() as td:
+        nv = ds.evaluate(outputs, td, metric=["PCK", "AUC", "EPE", "NME"])
+        res_json = open(os.path.join(td, "result_keypoints.json")).read()
+    arrays = dict(pairs=pairs.astype(np.int64), preds=preds, boxes=boxes,
+                  joints_3d=np.stack([d["joints_3d"] for d in db]), joints_3d_visible=np.stack([d["joints_3d_visible"] for d in db]),
+                  bbox=np.stack([d["bbox"] for d in db]), metric_values=np.array(list(nv.values()), np.float64),
+                  result_json=np.frombuffer(res_json.encode(), np.uint8))
+    arrays = {k: np.ascontiguousarray(v) for k, v in arrays.items()}
+    meta = dict(kind="dataset", seed=seed, metric_names=list(nv.keys()), num_shots=2, num_queries=5, num_episodes=3,
+                valid_class_ids=ds.valid_class_ids, cat2obj={str(k): v for k, v in ds.cat2obj.items()},
+                image_files=[d["image_file"] for d in db], img_prefix=ds.img_prefix, image_id_offset=1000,
+                mmpose_metric_functions="edgecape_amd.evaluation restatement (mmpose absent): plumbing pinned, arithmetic not",
+                reference="EdgeCape/datasets/datasets/mp100/test_dataset.py:86-99,254-319; test_base_dataset.py:71-155,218-226")
+    os.makedirs(OUT, exist_ok=True)
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+    print(name)
+
+
+def round2_fixtures(ns):
+    fused_checkpoint_fixture(ns, "head_s1_c384_g16_kp17_fusedckpt", 384, 16, 1, [17, 17], "auto", 101)
+    dns = ref_stubs.install_datasets(_metric_fns())
+    geometry_fixture(dns, "pre_geometry")
+    msra_fixture(dns, "pre_msra")
+    dataset_fixture(dns, "eval_dataset")
+
+
 def main():
+    if "--round2" in sys.argv:          # only the fixtures added in round 2 (the others are unchanged)
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        round2_fixtures(ref_stubs.install())
+        return
     torch.manual_seed(0)
     torch.set_num_threads(8)
     # HF first: the torchvision stub installed for the reference import confuses transformers' import probes
@@ -205,6 +380,7 @@ def main():
         head_fixture(ns, *case)
     detector_fixture("det_vits14_224_s1", "dinov2_vits14", 224, 1, 201)
     detector_fixture("det_vits14_224_s5", "dinov2_vits14", 224, 5, 202)
+    round2_fixtures(ns)
     leaked = [os.path.join(d, x) for d, ds, _ in os.walk(ref_stubs.REF_ROOT) for x in ds if x == "__pycache__"]
     assert not leaked, f"bytecode leaked into the reference tree: {leaked}"
 

@@ -9,8 +9,8 @@ where they lie*.  Nothing from `/root/reference` is copied into this repository 
 this module is never imported by the product path, `bench.py` or the `-m gpu` tests
 (`/root/reference` does not exist on the GPU box).
 
-Used by `oracle/make_golden.py` (fixture generation) and by the optional
-`tests/test_oracle_vs_reference.py` (skipped when `/root/reference` is absent).
+Used by `oracle/make_golden.py` (fixture generation) and by the container-only
+`tests/test_reference_configs.py` (skipped when `/root/reference` is absent).
 """
 import importlib
 import os
@@ -201,6 +201,55 @@ def _namespace():
     ns.post = sys.modules["EdgeCape.models.utils.post_processing.post_transforms"]
     ns.HEADS = sys.modules["mmpose.models"].HEADS
     ns.POSENETS = sys.modules["mmpose.models.builder"].POSENETS
+    return ns
+
+
+def install_datasets(metric_fns):
+    """Import the reference's host-side data path - EdgeCape/datasets/pipelines/top_down_transform.py (MSRA targets, affine
+    warp geometry) and EdgeCape/datasets/datasets/mp100/test_dataset.py + test_base_dataset.py (episode pairing, evaluate /
+    _report_metric) - unchanged, from where they lie.  Stand-ins, all documented in the fixtures' meta:
+      * cv2.getAffineTransform: the 2x3 solution of the three point pairs in float64 (cv2 is absent; this is the ONE cv2 call
+        on the geometry path - cv2.warpAffine, the pixel path, is NOT emulated);
+      * json_tricks -> the standard json module (the reference only dumps plain lists / floats);
+      * mmpose.core.evaluation.top_down_eval: `metric_fns` (the caller passes edgecape_amd.evaluation's restatement of the
+        published mmpose 0.29 functions - mmpose itself is absent, so only the reference's PLUMBING around them is pinned);
+      * registries / Compose / DataContainer / COCO: inert placeholders (never called by the pinned functions)."""
+    import json
+    import numpy as np
+    ns = install()
+
+    def get_affine_transform_3pt(src, dst):
+        A = np.concatenate([np.asarray(src, np.float64), np.ones((3, 1))], 1)
+        return np.linalg.solve(A, np.asarray(dst, np.float64)).T
+    sys.modules["cv2"].getAffineTransform = get_affine_transform_3pt
+    PIPELINES, DATASETS = _Registry("pipeline"), _Registry("dataset")
+    _mod("mmcv.fileio")
+    sys.modules["mmcv"].fileio = sys.modules["mmcv.fileio"]
+    _mod("mmcv.parallel", DataContainer=None)
+    _mod("mmpose.datasets", DATASETS=DATASETS)
+    _mod("mmpose.datasets.builder", PIPELINES=PIPELINES, DATASETS=DATASETS)
+    _mod("mmpose.datasets.pipelines", Compose=lambda p: p)
+    pp = sys.modules["mmpose.core.post_processing"]
+    for fn in ("affine_transform", "get_affine_transform"):
+        setattr(pp, fn, getattr(ns.post, fn))
+    for fn in ("fliplr_joints", "get_warp_matrix", "warp_affine_joints"):
+        setattr(pp, fn, None)
+    _mod("mmpose.core.evaluation.top_down_eval", **metric_fns)
+    _mod("json_tricks", dump=json.dump, load=json.load, dumps=json.dumps, loads=json.loads)
+    _mod("xtcocotools")
+    _mod("xtcocotools.coco", COCO=None)
+
+    def bare(name, rel):
+        m = types.ModuleType(name)
+        m.__path__ = [os.path.join(REF_ROOT, rel)]
+        sys.modules[name] = m
+    bare("EdgeCape.datasets", "EdgeCape/datasets")
+    bare("EdgeCape.datasets.pipelines", "EdgeCape/datasets/pipelines")
+    bare("EdgeCape.datasets.datasets", "EdgeCape/datasets/datasets")
+    bare("EdgeCape.datasets.datasets.mp100", "EdgeCape/datasets/datasets/mp100")
+    ns.pipe_post = importlib.import_module("EdgeCape.datasets.pipelines.post_transforms")
+    ns.pipe = importlib.import_module("EdgeCape.datasets.pipelines.top_down_transform")
+    ns.test_dataset = importlib.import_module("EdgeCape.datasets.datasets.mp100.test_dataset")
     return ns
 
 

@@ -106,3 +106,37 @@ def test_msra_target_invariants():
     assert (mx, my) == (int(100.3 / 3.5 + 0.5), int(57.9 / 3.5 + 0.5))
     assert 0 < (t[1] > 0).sum() < 49
     assert w[2] == 0 and t[2].sum() == 0
+
+
+def test_pipeline_oracle_matches_reference_msra():
+    """oracle/pipeline_oracle.py (and the data synthesiser's synth.msra_target) vs the reference's own _msra_generate_target
+    outputs (fixture pre_msra): bit-for-bit, including the border cases and visibility values other than 0 / 1."""
+    from oracle.pipeline_oracle import msra_target_ref64
+    g, meta = load_golden("pre_msra")
+    for i, (image_size, hm) in enumerate(meta["cases"]):
+        j, v = g[f"joints_{i}"], g[f"visible_{i}"]
+        t, w = msra_target_ref64(j[:, :2], v[:, 0], image_size, heatmap_size=hm, sigma=meta["sigma"])
+        assert np.array_equal(t, g[f"target_{i}"]) and np.array_equal(w, g[f"weight_{i}"]), i
+
+
+@pytest.mark.parametrize("M,g", [(37, 16), (37, 18), (37, 27), (16, 18), (37, 37), (10, 27)])
+def test_posembed_interpolation_vs_torch(M, g):
+    """The product's numpy bicubic (edgecape_amd/posembed.py, used once at load time) vs torch's upsample_bicubic2d called the
+    way dinov2's interpolate_pos_encoding calls it (scale_factor = (g + 0.1) / M, align_corners False, antialias False)."""
+    import torch.nn.functional as F
+    from edgecape_amd.posembed import interpolate_pos_embed
+    rng = np.random.default_rng(M * 100 + g)
+    C = 24
+    pe = rng.normal(0, 0.02, (1, 1 + M * M, C)).astype(np.float32)
+    got = interpolate_pos_embed(pe, g)
+    assert got.shape == (1 + g * g, C) and got.dtype == np.float32 and np.array_equal(got[0], pe[0, 0])
+    if g == M:
+        assert np.array_equal(got, pe[0])
+        return
+    patch = torch.from_numpy(pe[0, 1:]).reshape(1, M, M, C).permute(0, 3, 1, 2)
+    s = float(g + 0.1) / M
+    ref = F.interpolate(patch, scale_factor=(s, s), mode="bicubic", antialias=False)
+    assert ref.shape[-2:] == (g, g)
+    ref = ref.permute(0, 2, 3, 1).reshape(g * g, C).numpy()
+    assert np.abs(got[1:] - ref).max() < 1e-6                                             # same 16 taps and fp32 weights; |table| ~ 0.08
+    assert np.abs(got - orc.interpolate_pos_embed(pe, g).numpy()).max() < 1e-6            # and the oracle's call of the same op

@@ -1,0 +1,74 @@
+"""CPU: host-side pieces of the path against fixtures produced by the REAL reference (oracle/make_golden.py --round2, which
+imports EdgeCape/datasets/... and EdgeCape/models/utils/post_processing/... from /root/reference with the documented stand-ins):
+crop-warp geometry, episode pairing, evaluate / result_keypoints.json / _report_metric plumbing."""
+import json
+import os
+
+import numpy as np
+
+from conftest import load_golden
+from edgecape_amd import episodes, evaluation, preprocess
+
+
+def test_affine_closed_form_vs_reference():
+    """preprocess.get_affine_transform (closed form) vs post_transforms.py:197-252 (three float32 points + 3-point solve)."""
+    g, meta = load_golden("pre_geometry")
+    n = len(g["rot"])
+    worst = 0.0
+    for i in range(n):
+        W, H = g["out_size"][i]
+        box = 200.0 * g["scale"][i][0]
+        for inv, key in ((False, "fwd"), (True, "inv")):
+            M = preprocess.get_affine_transform(g["center"][i], g["scale"][i], g["rot"][i], g["out_size"][i], shift=tuple(g["shift"][i]), inv=inv)
+            assert np.abs(M[:, :2] - g[key][i][:, :2]).max() < 2e-5 * max(1.0, np.abs(M[:, :2]).max())     # rotation / scale part
+            # the matrices as MAPS: corners of the source box (forward) / of the output image (inverse), compared in pixels.  (A raw
+            # translation entry differs by up to a few 1e-3: the reference rounds its three points to fp32, which tilts the linear part
+            # by ~2e-6 and that multiplies the offset of the origin from the box.)
+            c = g["center"][i].astype(np.float64)
+            corners = np.array([[0., 0.], [W, 0.], [0., H], [W, H]]) if inv else c + box * np.array([[-.5, -.5], [.5, -.5], [-.5, .5], [.5, .5]])
+            worst = max(worst, float(np.abs(preprocess.warp_points(corners, M) - preprocess.warp_points(corners, g[key][i])).max()))
+        w = preprocess.warp_points(g["pts"][i], g["fwd"][i])
+        assert np.abs(w - g["warped"][i]).max() < 1e-9                      # same matrix -> same points (vectorised affine_transform)
+        w2 = preprocess.warp_points(g["pts"][i], preprocess.get_affine_transform(g["center"][i], g["scale"][i], g["rot"][i], g["out_size"][i],
+                                                                                 shift=tuple(g["shift"][i])))
+        assert np.abs(w2 - g["warped"][i]).max() < 5e-3                     # a few 1e-3 px: the reference rounds its three points to fp32
+    assert worst < 2e-3, worst                                                # pixels
+    # forward and inverse are inverses of each other
+    M = preprocess.get_affine_transform([100., 80.], [1.5, 1.5], 25., (256, 256))
+    Mi = preprocess.get_affine_transform([100., 80.], [1.5, 1.5], 25., (256, 256), inv=True)
+    p = np.array([[3., 4.], [250., 17.]])
+    assert np.abs(preprocess.warp_points(preprocess.warp_points(p, M), Mi) - p).max() < 1e-9
+
+
+def test_episode_pairs_vs_reference():
+    """episodes.make_paired_samples vs TestPoseDataset.make_paired_samples (test_dataset.py:86-99): identical pair list."""
+    g, meta = load_golden("eval_dataset")
+    cat2obj = {int(k): v for k, v in meta["cat2obj"].items()}
+    pairs = episodes.make_paired_samples(cat2obj, meta["valid_class_ids"], meta["num_shots"], meta["num_queries"], meta["num_episodes"])
+    assert np.array_equal(pairs, g["pairs"])
+    sup, ep = episodes.group_episodes(pairs)
+    assert len(sup) == len(meta["valid_class_ids"]) * meta["num_episodes"] and ep.max() == len(sup) - 1
+    assert np.array_equal(sup[ep], pairs[:, :-1]) and np.all(np.bincount(ep) == meta["num_queries"])
+
+
+def test_evaluate_vs_reference(tmp_path):
+    """evaluation.evaluate vs TestPoseDataset.evaluate -> _report_metric: same result_keypoints.json (byte for byte) and the same
+    metric values.  (The mmpose metric functions inside the reference run were this package's restatement - see the fixture's
+    meta: the plumbing is pinned, the mmpose arithmetic is covered by the known-answer tests in test_eval_checkpoint.py.)"""
+    g, meta = load_golden("eval_dataset")
+    pairs, preds, boxes = g["pairs"], g["preds"], g["boxes"]
+    files = meta["image_files"]
+    outputs = []
+    for s in range(0, len(pairs), 3):
+        idx = list(range(s, min(s + 3, len(pairs))))
+        outputs.append(dict(preds=preds[idx], boxes=boxes[idx], image_paths=[files[pairs[i][-1]] for i in idx], bbox_ids=idx))
+    outputs.append(dict(preds=preds[:1], boxes=boxes[:1], image_paths=[files[pairs[0][-1]]], bbox_ids=[0]))   # sampler padding duplicate
+    name2id = {f[len(meta["img_prefix"]):]: meta["image_id_offset"] + i for i, f in enumerate(files)}
+    gt = evaluation.gt_from_db(g["joints_3d"], g["joints_3d_visible"], g["bbox"], pairs)
+    nv = evaluation.evaluate(outputs, gt, str(tmp_path), metric=["PCK", "AUC", "EPE", "NME"],
+                             image_id_of=lambda p: name2id[p[len(meta["img_prefix"]):]])
+    assert list(nv.keys()) == meta["metric_names"]
+    assert np.allclose(np.array(list(nv.values()), np.float64), g["metric_values"], rtol=0, atol=1e-12)
+    ours = open(os.path.join(str(tmp_path), "result_keypoints.json")).read()
+    assert ours == bytes(g["result_json"]).decode()
+    assert len(json.loads(ours)) == len(pairs)
