@@ -69,7 +69,10 @@ def _worker(rank, world, port, n_total, mode, q):
             ev = dict(evaluate(res, _gt(n_total), d, metric="PCK"))
     # bench.py's timed region and counter reduction, on gloo
     calls = []
-    dt = apis.timed_steps(lambda: calls.append(1), steps=3, warmup=2, collective=lambda: apis.allreduce_counts(np.ones(6)))
+    armed = []
+    dt = apis.timed_steps(lambda: calls.append(1), steps=3, warmup=2, collective=lambda: apis.allreduce_counts(np.ones(6)),
+                          before_timed=lambda: armed.append(len(calls)))      # bench.py arms the kernel timers here: after the warm-up
+    assert armed == [2]
     rng = np.random.default_rng(7)
     pred = rng.normal(size=(n_total, K, 2)) * 10
     gt = pred + rng.normal(size=(n_total, K, 2)) * 3
