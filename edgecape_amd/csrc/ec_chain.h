@@ -33,6 +33,11 @@ struct ChainStage {
 };
 struct ChainP {
   int rows = 0, n_stages = 0, lds_bytes = 0;
+  // split = 2: TWO workgroups per slab.  Stages whose output feeds a later stage (s_off / keep / LayerNorm) are computed by both
+  // (only part 0 stores them to global memory); every other stage's 256-column passes are dealt out alternately, so each
+  // workgroup streams roughly half of those stages' weights.  Needs out != resid in the shared stages (the other part may still
+  // be reading the residual): the callers ping-pong the token state between two buffers.
+  int split = 1;
   ChainStage st[CH_MAX_STAGES];
 };
 

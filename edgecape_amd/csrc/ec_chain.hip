@@ -59,7 +59,8 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int row0 = blockIdx.x * CH_BM;
+  const int slab = blockIdx.x / p.split, part = blockIdx.x - slab * p.split;
+  const int row0 = slab * CH_BM;
   const int lrow = lane & 15, lq = lane >> 4;
   float* const red = (float*)smem;
 
@@ -84,14 +85,19 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
     // memory - so the compiler's own vmcnt bookkeeping stays exact (16 loads in flight under every batch of 48 MFMAs; with the
     // prefetch inside an `if` it falls back to vmcnt(0) before every batch).
     const int nb = nkb >> 2;
-    const int npass = wave * 2 < nfr ? (nfr - wave * 2 + 15) >> 4 : 0;   // passes in which this wave has fragments
+    const int npass_all = wave * 2 < nfr ? (nfr - wave * 2 + 15) >> 4 : 0;   // passes in which this wave has fragments
+    // two workgroups per slab (p.split = 2): a stage that later stages read is computed by both, any other is dealt out by passes
+    const bool shared = S.s_off >= 0 || S.keep || ln;
+    const int pstep = shared ? 1 : p.split, p0 = shared ? 0 : part;
+    const int npass = npass_all > p0 ? (npass_all - p0 + pstep - 1) / pstep : 0;
+    const bool store_out = S.out != nullptr && (!shared || part == 0);
     const int T = npass * nb;
     // Every workgroup walks the SAME weights: started together they would all pull the same few KiB through the same L2 channels at
     // the same time, so workgroup b starts its column passes rot_p passes further on.  (The k order is NOT rotated although that
     // measured another 5 % on the chain: a row's fp32 summation order must not depend on the slab it sits in - identical tokens,
     // e.g. the padded keypoint slots of a sample, produce bit-identical outputs, as they do in the reference.)
-    const int rot_b = 0, rot_p = npass ? blockIdx.x % npass : 0;
-    auto pass_of = [&](int ps) { const int q = ps + rot_p; return q >= npass ? q - npass : q; };
+    const int rot_b = 0, rot_p = npass ? slab % npass : 0;
+    auto pass_of = [&](int ps) { const int q = ps + rot_p; return p0 + (q >= npass ? q - npass : q) * pstep; };
     auto batch_of = [&](int bb) { const int q = bb + rot_b; return q >= nb ? q - nb : q; };
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(S.W), 0, S.N * S.K * 4, 0x00020000);
     auto load_batch = [&](WBatch& b, int i) {
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           const int r = mi * 16 + lrow;
-          if (S.out && row0 + r < p.rows) *(f32x4*)(S.out + (long)(row0 + r) * S.ldo + n) = acc[mi][j];
+          if (store_out && row0 + r < p.rows) *(f32x4*)(S.out + (long)(row0 + r) * S.ldo + n) = acc[mi][j];
           if (S.s_off >= 0) {
             u32x2 hi, lo;
             split4(acc[mi][j], hi, lo);
@@ -341,6 +347,7 @@ ChDev ch_dev[64];
 
 int run_chain(const ChainP& p, hipStream_t st) {
   EC_REQUIRE(p.rows > 0 && p.n_stages >= 1 && p.n_stages <= CH_MAX_STAGES, -1, "chain: bad stage count");
+  EC_REQUIRE(p.split == 1 || p.split == 2, -1, "chain: split");
   EC_REQUIRE(p.lds_bytes >= CH_RED && p.lds_bytes <= 160 * 1024, -1, "chain: LDS layout does not fit");
   for (int s = 0; s < p.n_stages; ++s) {
     const ChainStage& S = p.st[s];
@@ -352,6 +359,8 @@ int run_chain(const ChainP& p, hipStream_t st) {
     EC_REQUIRE(S.g_k == 0 || (S.g_in && S.g_k % 32 == 0 && S.g_off >= CH_RED && S.g_off + chain_layout_bytes(S.g_k) <= p.lds_bytes), -1, "chain: staged input out of range");
     EC_REQUIRE(S.s_off < 0 || (S.s_off >= CH_RED && S.s_off + chain_layout_bytes(S.N) <= p.lds_bytes), -1, "chain: output buffer out of range");
     EC_REQUIRE(!S.table || S.period > 0, -1, "chain: table period");
+    EC_REQUIRE(p.split == 1 || !(S.s_off >= 0 || S.keep || S.ln_w) || !S.resid || !S.out || S.resid != S.out, -1,
+               "chain: split chains need out != resid in the stages both workgroups compute");
   }
   int dev = 0;
   EC_HIP(hipGetDevice(&dev));
@@ -360,7 +369,7 @@ int run_chain(const ChainP& p, hipStream_t st) {
     EC_HIP(hipFuncSetAttribute((const void*)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     ch_dev[dev].attr_done = true;
   }
-  hipLaunchKernelGGL(chain_kernel, dim3((p.rows + CH_BM - 1) / CH_BM), dim3(512), p.lds_bytes, st, p);
+  hipLaunchKernelGGL(chain_kernel, dim3(((p.rows + CH_BM - 1) / CH_BM) * p.split), dim3(512), p.lds_bytes, st, p);
   EC_LAUNCH_CHECK();
   return 0;
 }

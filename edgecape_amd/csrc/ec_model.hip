@@ -504,6 +504,12 @@ struct LayerIO {
   bool qkv_ready = false;          // this layer's self-attention input projection was produced by the previous layer's last chain
   const Lin* next_sa_in = nullptr; // next layer's self-attention input projection -> qkv
   bool kvk_in_chain = false;       // two-way layers: K|V of the image->token attention (i2t_kv(x)) -> kvk
+  // two workgroups per slab (ChainP::split): the token state ping-pongs between x and x_alt, one hop per chain, because the part
+  // that shares a residual stage may still be reading x while the other part stores the new x.  x_final / ldx_final receive the
+  // buffer the layer's output ends up in (x itself without x_alt or when the layer does not chain).
+  float* x_alt = nullptr; long ldx_alt = 0;
+  float** x_final = nullptr; long* ldx_final = nullptr;
+  const float* qpe = nullptr; long ld_qpe = 0;   // main decoder: positional half of the cross-attention query (default: x + d)
 };
 
 // K|V of the image tokens for a layer's token->image cross attention, one batch entry per sample (mem may be a strided view):
@@ -547,18 +553,25 @@ struct ChainBuild {
   int top = CH_LDS0;
   int buf(int k) { const int o = top; top += chain_layout_bytes(k); return o; }
   ChainStage& add() { return p.st[p.n_stages++]; }
-  int run(int rows, hipStream_t st) { p.rows = rows; p.lds_bytes = top; return run_chain(p, st); }
+  int run(int rows, hipStream_t st, bool may_split = false) {
+    p.rows = rows; p.lds_bytes = top;
+    // two workgroups per slab while that still fits one round of the chip and there is a stage to deal out
+    static const bool no_split = getenv("EC_CHAIN_SPLIT") && atoi(getenv("EC_CHAIN_SPLIT")) == 0;   // A/B switch
+    p.split = (may_split && !no_split && p.n_stages > 1 && ((rows + CH_BM - 1) / CH_BM) * 2 <= 256) ? 2 : 1;
+    return run_chain(p, st);
+  }
 };
 static void chain_lin(ChainStage& S, const Lin& W) { S.W = W.wc; S.bias = W.b; S.N = W.N; S.K = W.K; S.k1 = W.K; }
 static bool chain_ok(const Lin& W) { return W.wc != nullptr; }
 
 // x <- LayerNorm(x + in @ W^T + b): the residual branch shared by the three chains of a layer.  Returns the LDS buffer with x.
-static int chain_resid_ln(ChainBuild& cb, const float* in, long ld_in, const Lin& W, const Norm& n, float* x, long ldx, bool to_lds) {
+static int chain_resid_ln(ChainBuild& cb, const float* in, long ld_in, const Lin& W, const Norm& n, const float* x, long ldx,
+                         float* x_out, long ldx_out, bool to_lds) {
   ChainStage& S = cb.add();
   chain_lin(S, W);
   S.g_in = in; S.ld_in = ld_in; S.g_k = W.K; S.g_off = cb.buf(W.K); S.a_off = S.g_off;
   S.resid = x; S.ldr = ldx; S.ln_w = n.w; S.ln_b = n.b; S.eps = 1e-5f;
-  S.out = x; S.ldo = ldx;
+  S.out = x_out; S.ldo = ldx_out;
   if (to_lds) S.s_off = cb.buf(W.N);
   return S.s_off;
 }
@@ -576,6 +589,11 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
   const int d = m->d, E = m->E, K = m->K, HW = m->HW, nh = m->cfg.nhead;
   const int Mk = io.nb * K;
   const bool chain = layer_chains(m, L);
+  // current / other buffer of the token state (ping-pong only in chain mode with x_alt)
+  float* xc = io.x; long lxc = io.ldx;
+  float* xo = (chain && io.x_alt) ? io.x_alt : io.x; long lxo = (chain && io.x_alt) ? io.ldx_alt : io.ldx;
+  const bool pp = xo != xc;
+  auto hop = [&]() { std::swap(xc, xo); std::swap(lxc, lxo); };
   EC_REQUIRE(chain || (!io.qkv_ready && !io.next_sa_in && !io.kvk_in_chain), EC_ERR_STATE, "chain hand-offs on a layer that does not chain");
   // ---- self attention over the K keypoint tokens (hd = d/nh = 32)
   if (!io.qkv_ready) RUN(linear(io.x, io.ldx, false, L.sa_in, qkv, 3 * d, false, Mk, ACT_NONE, st));
@@ -597,15 +615,17 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
     for (hipEvent_t e : io.wait_ca)
       if (e) EC_HIP(hipStreamWaitEvent(st, e, 0));
     ChainBuild cb;
-    const int bx = chain_resid_ln(cb, att, d, L.sa_out, L.n1, io.x, io.ldx, true);
+    const int bx = chain_resid_ln(cb, att, d, L.sa_out, L.n1, xc, lxc, xo, lxo, true);
     ChainStage& Q = cb.add();
     chain_lin(Q, L.ca_q);
     Q.a_off = bx; Q.k1 = d;
     if (L.ca_q.K == 2 * d) {   // main decoder: the positional half of the query sits beside x in the token rows
-      Q.g_in = io.x + d; Q.ld_in = io.ldx; Q.g_k = d; Q.g_off = cb.p.st[0].g_off; Q.b_off = Q.g_off;   // (att's buffer is free again)
+      Q.g_in = io.qpe ? io.qpe : io.x + d; Q.ld_in = io.qpe ? io.ld_qpe : io.ldx;
+      Q.g_k = d; Q.g_off = cb.p.st[0].g_off; Q.b_off = Q.g_off;   // (att's buffer is free again)
     }
     Q.out = qc; Q.ldo = E;
-    RUN(cb.run(Mk, st));
+    RUN(cb.run(Mk, st, pp));
+    hop();
   } else {
     RUN(linear(att, d, false, L.sa_out, tmp, d, false, Mk, ACT_NONE, st, nullptr, io.x, io.ldx));
     if (io.wait_x) EC_HIP(hipStreamWaitEvent(st, io.wait_x, 0));
@@ -635,12 +655,13 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
   //      z = relu(valid * y[:, :F] + adj1 @ y[:, F:]);  x = LN3(x + ffn2(z))
   if (chain) {
     ChainBuild cb;   // x = norm2(x + choker(out_proj(att))); y = ffn1(x)
-    const int bx = chain_resid_ln(cb, att, E, L.ca_fold, L.n2, io.x, io.ldx, true);
+    const int bx = chain_resid_ln(cb, att, E, L.ca_fold, L.n2, xc, lxc, xo, lxo, true);
     ChainStage& Y = cb.add();
     chain_lin(Y, L.ffn1);
     Y.a_off = bx;
     Y.out = y; Y.ldo = 2 * F;
-    RUN(cb.run(Mk, st));
+    RUN(cb.run(Mk, st, pp));
+    hop();
   } else {
     RUN(linear(att, E, false, L.ca_fold, tmp, d, false, Mk, ACT_NONE, st, nullptr, io.x, io.ldx));
     RUN(ln(tmp, d, io.x, io.ldx, false, L.n2, Mk, d, 1e-5f, st));
@@ -658,7 +679,7 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
   if (chain) {
     ChainBuild cb;   // x = norm3(x + ffn2(z)) (-> next layer's self-attention in-proj) (-> image->token K|V)
     const bool more = (io.next_sa_in && chain_ok(*io.next_sa_in)) || (io.kvk_in_chain && chain_ok(L.i2t_kv));
-    const int bx = chain_resid_ln(cb, z, F, L.ffn2, L.n3, io.x, io.ldx, more);
+    const int bx = chain_resid_ln(cb, z, F, L.ffn2, L.n3, xc, lxc, xo, lxo, more);
     if (io.next_sa_in && chain_ok(*io.next_sa_in)) {
       ChainStage& S = cb.add();
       chain_lin(S, *io.next_sa_in);
@@ -671,14 +692,16 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
       S.a_off = bx;
       S.out = kvk; S.ldo = 2 * E;
     }
-    RUN(cb.run(Mk, st));
+    RUN(cb.run(Mk, st, pp));
+    hop();
   } else {
     RUN(linear(z, F, false, L.ffn2, tmp, d, false, Mk, ACT_NONE, st, nullptr, io.x, io.ldx));
     RUN(ln(tmp, d, io.x, io.ldx, false, L.n3, Mk, d, 1e-5f, st));
   }
+  if (io.x_final) { *io.x_final = xc; *io.ldx_final = lxc; }
   if (two_way && io.update_mem) {
     RUN(image_update_q(m, L, io.mem, io.nb, qimg, st));
-    RUN(image_update(m, L, io.x, io.ldx, io.mem, io.nb, qimg, kvk, attimg, tmpimg, st, nullptr));
+    RUN(image_update(m, L, xc, lxc, io.mem, io.nb, qimg, kvk, attimg, tmpimg, st, nullptr));
   }
   return 0;
 }
@@ -767,9 +790,13 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
   RUN(adj_build(m->d_edges, m->d_off, mask_s, ss.valid, ss.kmask, ss.kmask_fixed, m->binary, m->adj_r1, bs, K, st));
   if (ev_sk) EC_HIP(hipEventRecord(ev_sk, st));   // support tokens + key masks are ready: the encoder may start
   for (int s = 0; s < S; ++s) RUN(copy2d(m->s_x + (long)s * Mk * d, d, ss.sk, d, Mk, d, st));
+  float* sx = m->s_x;                         // token state: ping-pongs with s_tmp under two-workgroup row chains (LayerIO::x_alt)
+  long sx_ld = d;
   for (int i = 0; i < nsk; ++i) {
     LayerIO io;
-    io.x = m->s_x; io.ldx = d; io.mem = m->s_mem; io.s_mem = (long)HW * d;
+    io.x = sx; io.ldx = sx_ld; io.mem = m->s_mem; io.s_mem = (long)HW * d;
+    io.x_alt = sx == m->s_x ? m->s_tmp : m->s_x; io.ldx_alt = d;
+    io.x_final = &sx; io.ldx_final = &sx_ld;
     io.adj1 = m->adj_r1; io.valid = ss.valid; io.kmask_fixed = ss.kmask_fixed; io.bias = nullptr;
     io.nb = nb; io.bs = bs;
     io.update_mem = false;                       // done below, on s2
@@ -790,7 +817,7 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
         EC_HIP(hipEventRecord(ev_x, st));
         EC_HIP(hipStreamWaitEvent(s2, ev_x, 0));
       }
-      RUN(image_update(m, m->skel[i], m->s_x, d, m->s_mem, nb, m->s_qimg, m->s_kvk, m->s_attimg, m->s_tmpimg, s2, ov2 ? ev_xr : nullptr,
+      RUN(image_update(m, m->skel[i], sx, d, m->s_mem, nb, m->s_qimg, m->s_kvk, m->s_attimg, m->s_tmpimg, s2, ov2 ? ev_xr : nullptr,
                        io.kvk_in_chain));
       RUN(project_image_kv(m, m->skel[i + 1], m->s_mem, (long)HW * d, nb, m->s_kv, s2));
       if (ov2) EC_HIP(hipEventRecord(ev_kv, s2));
@@ -798,9 +825,9 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
       if (i + 2 < nsk) RUN(image_update_q(m, m->skel[i + 1], m->s_mem, nb, m->s_qimg, s2));
     }
   }
-  const float* kp_ref = m->s_x;              // mean over the shots (skeleton.py:114); one shot: the tokens themselves
+  const float* kp_ref = sx;                  // mean over the shots (skeleton.py:114); one shot: the tokens themselves
   if (S > 1) {
-    RUN(mean_over(m->kp_ref, m->s_x, (long)Mk * d, S, (long)Mk * d, st));
+    RUN(mean_over(m->kp_ref, sx, (long)Mk * d, S, (long)Mk * d, st));
     kp_ref = m->kp_ref;
   }
   m->taps["skel_kp_refined"] = {kp_ref, (long)Mk * d};
@@ -981,6 +1008,8 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
   // projection runs before the wait.  Without the precomputed bias stack the bias MLP itself reads attn_adj: wait here.
   if (wait_adj && !ss.dec_bias) EC_HIP(hipStreamWaitEvent(st, wait_adj, 0));
   RUN(tl_mark(m, "Q.adjwait", st));
+  float* dx = m->d_qin;                       // token state: left half of d_qin, ping-ponging with d_tmp under two-workgroup chains
+  long dx_ld = 2 * d;
   for (int li = 0; li < nL; ++li) {
     const DecLayer& Ld = m->dec[li];
     float* bi = pts + (long)li * Mk * 2;
@@ -988,7 +1017,10 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     if (ss.dec_bias) lbias = ss.dec_bias + li * (size_t)bs * nh * K * K;
     else RUN(bias_mlp(attn_adj, Ld.m_w1, Ld.m_b1, Ld.m_w2, Ld.m_b2, m->d_bias, hops1, m->cfg.max_hops + nh, nh, bs, K, st));
     LayerIO io;
-    io.x = m->d_qin; io.ldx = 2 * d; io.mem = mem; io.s_mem = s_tok;
+    io.x = dx; io.ldx = dx_ld; io.mem = mem; io.s_mem = s_tok;
+    if (dx == m->d_qin) { io.x_alt = m->d_tmp; io.ldx_alt = d; } else { io.x_alt = m->d_qin; io.ldx_alt = 2 * d; }
+    io.x_final = &dx; io.ldx_final = &dx_ld;
+    io.qpe = m->d_qin + d; io.ld_qpe = 2 * d;
     io.adj1 = ss.adj1; io.valid = ss.valid; io.kmask_fixed = ss.kmask_fixed; io.bias = lbias;
     io.nb = bs; io.bs = bs; io.update_mem = false;
     io.kv_pre = m->d_kv + (long)li * 2 * E; io.ld_kv_pre = (long)nL * 2 * E;
@@ -1010,10 +1042,10 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     float* bnext = pts + (long)(li + 1) * Mk * 2;
     const bool last_split = ovd && li + 1 == nL;   // after the last layer nothing is left to hide under: the two keypoint
                                                   // branches (on x and on dec_norm(x)) run side by side on st and ax
-    RUN(ln(m->d_qin, 2 * d, hs, d, false, m->dec_norm, Mk, d, 1e-5f, last_split ? st : ax));
+    RUN(ln(dx, dx_ld, hs, d, false, m->dec_norm, Mk, d, 1e-5f, last_split ? st : ax));
     // b_{l+1} = sigmoid(inverse_sigmoid(b_l) + kpt_branch[l](x))   (un-normed x, :395-402)
     const KptBranch& kb = m->kpt[li];
-    RUN(linear(m->d_qin, 2 * d, false, kb.l0, m->d_k1, d, false, Mk, ACT_GELU, ax));
+    RUN(linear(dx, dx_ld, false, kb.l0, m->d_k1, d, false, Mk, ACT_GELU, ax));
     RUN(mark(ev_x));                       // x_{l+1} has been read: layer l+1 may overwrite it
     RUN(linear(m->d_k1, d, false, kb.l2, m->d_k2, d, false, Mk, ACT_GELU, ax));
     RUN(linear(m->d_k2, d, false, kb.l4, m->d_k1, d, false, Mk, ACT_GELU, ax));
@@ -1716,6 +1748,8 @@ int ec_op_chain(const float* X, int K1, const float* W1, const float* b1, const 
     S.out = x3_out; S.ldo = 256;
   }
   p.rows = rows; p.lds_bytes = top;
+  // a residual input that is NOT the output buffer selects the two-workgroups-per-slab form (ChainP::split), as the head uses it
+  p.split = (resid && resid != x1_out && ((rows + CH_BM - 1) / CH_BM) * 2 <= 256) ? 2 : 1;
   if (!rc) rc = run_chain(p, st);
   (void)hipStreamSynchronize(st);
   for (void* d : tmp) (void)hipFree(d);

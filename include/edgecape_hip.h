@@ -184,7 +184,8 @@ int ec_op_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, 
  *     out2 = act2([x1 | cat] @ W2^T + b2 + table[row % period])              W2 [N2, 256 + Kcat]       -> out2 [rows,N2]
  *     x3   = LayerNorm_3(x1 + out2 @ W3^T + b3)                              W3 [256, N2]              -> x3_out [rows,256]
  * (transformer.py-style residual blocks: EdgeCape/models/keypoint_heads/encoder_decoder.py:461-483, 596-649).  Weights are plain
- * fp32 [N,K] device arrays (packed inside).  cat / table / the whole third stage (W3 = NULL) are optional; resid may alias x1_out;
+ * fp32 [N,K] device arrays (packed inside).  cat / table / the whole third stage (W3 = NULL) are optional; resid may alias x1_out (one workgroup per 32-row slab; a separate resid buffer
+ * selects two workgroups per slab that deal the column passes of stage 2 out between them);
  * LayerNorm eps = 1e-5; act2: 0 none, 1 relu, 2 gelu(erf).  K1, Kcat, N2 multiples of 128. */
 int ec_op_chain(const float* X_dev, int K1, const float* W1_dev, const float* b1_dev, const float* resid_dev, const float* ln1_w_dev,
                 const float* ln1_b_dev, float* x1_out_dev, const float* cat_dev, int Kcat, const float* W2_dev, const float* b2_dev,

@@ -386,6 +386,7 @@ def test_attention_fp16_large_logits(lib):
     assert (od.cpu() - ref).abs().max().item() < 5e-3
 
 
+@pytest.mark.parametrize("alias", [True, False])
 @pytest.mark.parametrize("rows,K1,Kcat,N2,act2,period,third", [
     (3200, 256, 256, 512, 0, 0, False),     # decoder: out_proj + norm1 -> q_proj([x | qpe])
     (3200, 512, 0, 768, 0, 0, False),       # decoder: fold + norm2 -> ffn1
@@ -395,8 +396,9 @@ def test_attention_fp16_large_logits(lib):
     (648, 512, 0, 1024, 0, 324, False),     # image lane: fold + norm4 -> K|V projection + positional table
     (31, 256, 0, 256, 0, 0, True),          # fewer rows than one slab
 ])
-def test_row_chain(lib, rows, K1, Kcat, N2, act2, period, third):
-    """Row-chain kernel (ec_chain.hip, bf16x3) vs fp64 math of the same residual blocks."""
+def test_row_chain(lib, rows, K1, Kcat, N2, act2, period, third, alias):
+    """Row-chain kernel (ec_chain.hip, bf16x3) vs fp64 math of the same residual blocks.  alias: the residual is updated in place
+    (one workgroup per slab); otherwise it is a separate buffer and two workgroups per slab share the work (ChainP::split)."""
     g = torch.Generator().manual_seed(rows + K1 + N2)
     X = torch.randn(rows, K1, generator=g)
     W1 = torch.randn(256, K1, generator=g) / K1 ** 0.5
@@ -423,10 +425,11 @@ def test_row_chain(lib, rows, K1, Kcat, N2, act2, period, third):
 
     dev = lambda t: t.cuda() if t is not None else None
     Xd, W1d, b1d, Rd, g1d, be1d, catd, W2d, b2d, td, W3d, b3d, g3d, be3d = map(dev, (X, W1, b1, R, g1, be1, cat, W2, b2, table, W3, b3, g3, be3))
-    x1d = Rd.clone()                                   # residual aliased with the output, as the head uses it
+    x1d = Rd if alias else torch.full((rows, 256), float("nan"), device="cuda")
+    Rd = x1d if alias else Rd
     o2d = torch.full((rows, N2), float("nan"), device="cuda")
     x3d = torch.full((rows, 256), float("nan"), device="cuda") if third else None
-    _chk(lib, lib.ec_op_chain(_p(Xd), K1, _p(W1d), _p(b1d), _p(x1d), _p(g1d), _p(be1d), _p(x1d), _p(catd), Kcat, _p(W2d), _p(b2d), N2,
+    _chk(lib, lib.ec_op_chain(_p(Xd), K1, _p(W1d), _p(b1d), _p(Rd), _p(g1d), _p(be1d), _p(x1d), _p(catd), Kcat, _p(W2d), _p(b2d), N2,
                               act2, _p(td), period, _p(o2d), _p(W3d), _p(b3d), _p(g3d), _p(be3d), _p(x3d), rows, None))
     torch.cuda.synchronize()
     e1 = (x1d.cpu().double() - x1).abs().max().item()
