@@ -11,8 +11,12 @@
 //   * operands go HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, no VGPR round trip) as HALF-TILES of 128 rows x 128 B;
 //     a K-tile is four half-tiles (A-h0, B-h0, B-h1, A-h1), LDS holds two K-tiles (128 KiB), the per-wave output staging
 //     slots (16 KiB) and the bias / LayerScale slices of two tiles (8 KiB).
-//     The LDS image is [16 rows][64 B] sub-tiles, 32-byte XOR-swizzled for rows 8..15 (conflict-free ds_read_b128); since
-//     LDS-DMA writes lane-linear, the swizzle is applied to the per-lane SOURCE address and undone by the readers.
+//     One wave-instruction of the stream (a PIECE, 1 KiB) covers 8 rows x 128 B = eight WHOLE cache lines: lanes 0-31 the first
+//     64 bytes of the rows, lanes 32-63 the second (round 2; tools/dma_probe.hip: the stream of the QKV problem alone runs in 29 us
+//     with whole-line pieces and in 42 us with the 16 rows x 64 B pieces of round 1, which fetched every line in two halves).
+//     LDS image of a 16-row group (2 KiB): [8-row octet][k half][8 rows][64 B]; the 16-byte chunk index of rows 8..15 is XORed with 2
+//     (conflict-free ds_read_b128 of a 16-row x 32-k fragment); since LDS-DMA writes lane-linear, the swizzle is applied to the
+//     per-lane SOURCE address and undone by the readers.
 //   * the K loop is a sequence of PHASES, one accumulator quadrant (64x32, 16 MFMAs) each:
 //         R: ds_read the fragments this phase needs, issue ONE half-tile of the load stream, s_waitcnt vmcnt(6)
 //         barrier;  M: 16 MFMAs;  barrier
@@ -137,10 +141,10 @@ __device__ __forceinline__ void g8_epilogue_generic(const GemmP& p, f32x4 (&acc)
 // stores of 16 B per lane = 8 full 128-byte lines each (fragment-wise 8-byte stores would be quarter lines and twice the
 // instructions: global stores issue at ~70 cycles per wave-instruction per CU whatever their width).  The accumulators are
 // zeroed on the way out: the next tile accumulates into them.
-//   goff: byte offset in C of (row m0 + wr*128 + mi*16 + (lane>>3), column n0 + wc*64 + (lane&7)*8); rows_ok: valid rows of the
-//   piece (M edge); col_ok: this lane's 8 columns are inside N.
+//   rsC: buffer descriptor of C with num_records = M * ldc bytes (rows past M are dropped by its range check); goff: byte offset in C of
+//   (row m0 + wr*128 + mi*16 + (lane>>3), column n0 + wc*64 + (lane&7)*8); col_ok: this lane's 8 columns are inside N.
 template <int KIND, bool F16, int LAB>
-__device__ __forceinline__ void g8_piece(f32x4 (&a)[4], char* Cb, unsigned goff, unsigned ldc2, int rows_ok, bool col_ok, char* stg,
+__device__ __forceinline__ void g8_piece(f32x4 (&a)[4], const __amdgpu_buffer_rsrc_t rsC, unsigned goff, unsigned ldc2, bool col_ok, char* stg,
                                          const char* bias_lds, const char* gam_lds, int lane) {
   const int wrow = lane & 15, wq = lane >> 4;                       // writer: fragment row, column quad
   const int rrow = lane >> 3, rch = lane & 7;                       // reader: row within 8, 16-byte chunk
@@ -162,7 +166,45 @@ __device__ __forceinline__ void g8_piece(f32x4 (&a)[4], char* Cb, unsigned goff,
     const int row = j * 8 + rrow;
     const u32x4 o = *(const u32x4*)(stg + row * 128 + ((rch ^ (row & 7)) << 4));
     if constexpr (LAB & 1) { asm volatile("" ::"v"(o)); continue; }   // lab build only: epilogue without the global stores
-    if (col_ok && row < rows_ok) *(u32x4*)(Cb + goff + (unsigned)(j * 8) * ldc2) = o;
+    // ALWAYS issued (the seam's counted vmcnt waits assume 16 stores per wave and tile): rows past M fall outside the descriptor's
+    // range, lanes whose columns lie past N get an out-of-range offset - the hardware drops both
+    __builtin_amdgcn_raw_buffer_store_b128(o, rsC, col_ok ? goff + (unsigned)(j * 8) * ldc2 : 0xFFFFFFF0u, 0, 0);
+  }
+}
+
+// The same piece WITHOUT the LDS round trip (round 2): lanes (r, q) = (lane & 15, lane >> 4) hold row r and the columns q*4 .. q*4+3 of
+// each of the four 16-column blocks.  One v_permlane16_swap per packed dword between the two blocks of a pair (16-lane row 1 <-> row 0,
+// row 3 <-> row 2) leaves every lane with 8 CONSECUTIVE columns of its row - lane rows 0, 2, 1, 3 hold columns 0-7, 8-15, 16-23, 24-31 of
+// the pair - i.e. one 16-byte store per lane and pair, 16 rows x 64 B per wave-instruction (tools/store_probe.hip: within 6 % of the
+// 8 rows x 128 B form), and no ds_write / lgkmcnt / ds_read chain per piece (the staged form spent ~5 800 cycles per tile in it).
+//   rsC: buffer descriptor of C with num_records = M * ldc bytes; goff: byte offset in C of (row m0 + wr*128 + mi*16 + (lane & 15),
+//   column n0 + wc*64 + (lane >> 4 & 1) * 16 + (lane >> 5) * 8); col_ok0 / col_ok1: the lane's 8 columns of pair 0 / 1 are inside N.
+template <int KIND, bool F16, int LAB>
+__device__ __forceinline__ void g8_piece_reg(f32x4 (&a)[4], const __amdgpu_buffer_rsrc_t rsC, unsigned goff, bool col_ok0, bool col_ok1,
+                                             const char* bias_lds, const char* gam_lds, int lane) {
+  const int wq = lane >> 4;
+  u32x2 pk[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int c0 = (ni >> 1) * 32 + (ni & 1) * 16 + wq * 4;
+    f32x4 v = a[ni] + *(const f32x4*)(bias_lds + c0 * 4);
+    if constexpr (KIND == G8_GELU_BF16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_fast8<F16>(v[e]);
+    }
+    if constexpr (KIND == G8_SCALE_BF16) v *= *(const f32x4*)(gam_lds + c0 * 4);
+    pk[ni] = pack4_h<F16>(v);
+    a[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pk[2 * pr][0], pk[2 * pr + 1][0], false, false);
+    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pk[2 * pr][1], pk[2 * pr + 1][1], false, false);
+    const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+    if constexpr (LAB & 1) { asm volatile("" ::"v"(o)); continue; }
+    // ALWAYS issued (the tile seam's counted vmcnt waits assume 16 stores per wave and tile): rows past M fall outside the buffer
+    // descriptor's range, columns past N get an out-of-range offset - the hardware drops both
+    __builtin_amdgcn_raw_buffer_store_b128(o, rsC, (pr ? col_ok1 : col_ok0) ? goff + (unsigned)(pr * 64) : 0xFFFFFFF0u, 0, 0);
   }
 }
 
@@ -194,6 +236,9 @@ template <int N> __device__ __forceinline__ void g8_wait_vm() { asm volatile("s_
 // groups half a phase apart (8192^3 1300 vs 1355 TFLOP/s) and two 32-MFMA phases per K-tile (+2 % at 8192^3, 0 at K = 768).
 template <int KIND, int TAG, bool F16 = false, int LAB = 0>
 __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
+  // Epilogue pieces by lane swaps (no LDS round trip: fc1 + GELU, VALU-bound, 101 -> 95 us) or through the LDS staging slot (whole
+  // 128-byte lines per store: the bias / LayerScale kinds are bound by the stores themselves, QKV 64.6 vs 66.4 us); LAB & 128 flips it.
+  constexpr bool REGEPI = (KIND == G8_GELU_BF16) != ((LAB & 128) != 0);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool FAST = KIND != G8_GENERIC && !(LAB & 32);   // bias from LDS, epilogue pieces through the staging slot
   constexpr bool NODRAIN = FAST && !(LAB & 64);              // the load stream is not drained at the seam
@@ -208,6 +253,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   const int ntiles = ntm * ntn;
   const int nk = p.K >> 6;                       // K-tiles per output tile (even: checked on the host)
   const long lda_b = p.lda * 2, ldb_b = p.ldb * 2;
+  const unsigned lda8 = (unsigned)lda_b * 8u, ldb8 = (unsigned)ldb_b * 8u;
 
   // XCD-aware persistent schedule: workgroup b runs on XCD b % 8 (observed, speed only); XCD x walks the contiguous tile
   // range [x*chunk, (x+1)*chunk) (row-major, n fastest) so the tiles in flight on one L2 share operand panels.
@@ -219,13 +265,15 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   if (t_first >= t_end) return;                 // whole workgroup leaves: no barrier has been executed yet
 
   // ---- load stream (LDS-DMA) state -------------------------------------------------------------------------------
-  // wave w stages row-group w (16 rows) of every half-tile, both 64-byte K halves (2 wave-instructions of 1 KiB).
-  // lane -> row r = lane>>2 of the row-group, physical 16-B chunk lane&3 which holds logical chunk (lane&3) ^ 2*(r>=8).
+  // wave w stages row-group w (16 rows) of every half-tile as two pieces of 8 rows (2 wave-instructions of 1 KiB).
+  // lane -> k half lane>>5, row (lane>>2)&7 of the octet, physical 16-B chunk lane&3 which holds logical chunk (lane&3) ^ 2*(octet).
   // The stream uses buffer loads to LDS (buffer_load_dwordx4 ... lds): one 128-bit descriptor per operand in SGPRs, a 32-bit
   // per-lane byte offset of the lane's row + chunk (fixed for a whole output tile) and the K position as the scalar offset -
   // four offset VGPRs instead of four 64-bit row pointers, no per-issue address arithmetic.
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, -1, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, -1, 0x00020000);   // (host: operand bytes < 4 GiB)
+  // (host: operand bytes < 4 GiB.  The descriptors end with the operands' last row: the second piece of a clamped edge row group
+  // reaches up to 8 rows past it, reads zeros there - range check - and those rows / columns are never stored)
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)(((unsigned)(p.M - 1) * (unsigned)p.lda + (unsigned)p.K) * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)(((unsigned)(p.N - 1) * (unsigned)p.ldb + (unsigned)p.K) * 2u), 0x00020000);
   unsigned vo0, vo1, vo2, vo3;                       // A-h0, B-h0, B-h1, A-h1: byte offset of this lane's row (+ chunk)
   int ls_kt = 0, ls_tile = t_first;
   auto set_rows = [&](int t) {
@@ -233,7 +281,8 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
     // everything per-lane is recomputed from the lane id here (once per tile, a dozen VALU): kept live across the K loop these
     // values get spilled, and their reload (scratch is VMEM) would drain the whole load stream at every tile change
     const int l = g8_lane_now();
-    const int r = l >> 2, c = ((l & 3) ^ ((l >> 5) << 1)) << 4;
+    // first piece (rows 0..7 of the group): row, k half, chunk  (LAB & 256: the round-1 pieces of 16 rows x 64 B, for A/B)
+    const int r = (LAB & 256) ? l >> 2 : (l >> 2) & 7, c = (LAB & 256) ? ((l & 3) ^ ((l >> 5) << 1)) << 4 : ((l >> 5) << 6) + ((l & 3) << 4);
     const int ra = m0 + (wave >> 2) * 128 + (wave & 3) * 16 + r;        // A-h0 row; A-h1 = +64
     const int rb = n0 + (wave >> 1) * 64 + (wave & 1) * 16 + r;         // B-h0 row; B-h1 = +32
     vo0 = (unsigned)min(ra, p.M - 1) * (unsigned)lda_b + (unsigned)c;   // rows past the edge: clamped, computed, never stored
@@ -244,13 +293,15 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   bool lab_steady = false;
   // Past the workgroup's last tile the stream keeps issuing (same rows again, valid addresses) into the ring position the live
   // stream would use - free by the same WAR argument and never read - so the counted waits stay uniform to the end.
-  auto issue = [&](const __amdgpu_buffer_rsrc_t rs, unsigned vo, int half) {
+  auto issue = [&](const __amdgpu_buffer_rsrc_t rs, unsigned vo, unsigned ld8, int half) {
     if constexpr (LAB & 4) { if (lab_steady) return; }
     char* dst = smem + (ls_kt & 1) * G8_KT + half * G8_HALF + wave * 2048;
     // (the K position and the second piece's +64 B go into the SCALAR offset: the instruction's immediate offset would be added to
     // the LDS address as well as to the memory address)
+    // second piece: rows 8..15 of the group (+ 8 rows; their chunks are stored XOR 2: the swizzle of the reader)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)dst, 16, vo, ls_kt * 128, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + 1024), 16, vo, ls_kt * 128 + 64, 0, 0);
+    if constexpr (LAB & 256) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + 1024), 16, vo, ls_kt * 128 + 64, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + 1024), 16, (vo ^ 32u) + ld8, ls_kt * 128, 0, 0);
   };
   auto advance = [&]() {
     if (++ls_kt == nk) {
@@ -274,9 +325,9 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   };
   set_rows(t_first);
   stage_bias(t_first, 0);
-  issue(rsA, vo0, 0); issue(rsB, vo1, 1); issue(rsB, vo2, 2); issue(rsA, vo3, 3);
+  issue(rsA, vo0, lda8, 0); issue(rsB, vo1, ldb8, 1); issue(rsB, vo2, ldb8, 2); issue(rsA, vo3, lda8, 3);
   advance();
-  issue(rsA, vo0, 0);
+  issue(rsA, vo0, lda8, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue half-tiles have landed (this wave's part)
   lab_steady = true;
   G8_BAR();
@@ -284,7 +335,8 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
 
   // ---- fragment read addresses ------------------------------------------------------------------------------------
   // reader lane: row r = lane&15 of the 16-row sub-tile, logical chunk lane>>4 at physical chunk (lane>>4) ^ 2*(r>=8)
-  const int rd_off = ((lane & 15) << 6) + ((((lane >> 4) ^ (((lane & 15) >> 3) << 1))) << 4);
+  constexpr int KH = (LAB & 256) ? 1024 : 512;   // byte distance of the two k halves of a fragment
+  const int rd_off = ((LAB & 256) ? (lane & 15) << 6 : (((lane & 15) >> 3) << 10) + ((lane & 7) << 6)) + ((((lane >> 4) ^ (((lane & 15) >> 3) << 1))) << 4);
   const char* a_base = smem + rd_off + wr * 8192;                // row-groups 4*wr.. of the A halves
   const char* b_base = smem + rd_off + wc * 4096 + G8_HALF;      // row-groups 2*wc.. of the B halves (B-h0 is slot 1)
   char* const stg = smem + G8_STAGE + wave * 2048;
@@ -297,18 +349,29 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   bf16x8 af[4][2], b0[2][2], b1[2][2];
 
   const unsigned ldc2 = (unsigned)p.ldc * 2u;
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((unsigned)p.M * ldc2), 0x00020000);   // (host: < 2 GiB)
   auto pieces = [&](int mi0, int m0, int n0, int par) {   // pieces mi0, mi0 + 1 of tile (m0, n0)
     if constexpr (FAST) {
-      char* const Cb = (char*)p.C;
       const int lane = g8_lane_now();                      // (shadows the kernel's: see g8_lane_now)
-      const bool col_ok = n0 + wc * 64 + (lane & 7) * 8 < p.N;
       const char* bl = smem + G8_BIAS + (par * 8 + wave) * 256;
       const char* gl = smem + G8_GAMMA + (par * 8 + wave) * 256;
+      if constexpr (REGEPI) {
+        const int cq = ((lane >> 4) & 1) * 16 + (lane >> 5) * 8;          // first of the lane's 8 columns inside a 32-column pair
+        const bool ok0 = n0 + wc * 64 + cq < p.N, ok1 = n0 + wc * 64 + 32 + cq < p.N;
 #pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        const int r0 = m0 + wr * 128 + (mi0 + d) * 16;
-        const unsigned goff = (unsigned)(r0 + (lane >> 3)) * ldc2 + (unsigned)(n0 + wc * 64) * 2u + (unsigned)(lane & 7) * 16u;
-        g8_piece<KIND == G8_GENERIC ? G8_BIAS_BF16 : KIND, F16, LAB>(acc[mi0 + d], Cb, goff, ldc2, p.M - r0, col_ok, stg, bl, gl, lane);
+        for (int d = 0; d < 2; ++d) {
+          const int r0 = m0 + wr * 128 + (mi0 + d) * 16 + (lane & 15);
+          const unsigned goff = (unsigned)r0 * ldc2 + (unsigned)(n0 + wc * 64 + cq) * 2u;
+          g8_piece_reg<KIND == G8_GENERIC ? G8_BIAS_BF16 : KIND, F16, LAB>(acc[mi0 + d], rsC, goff, ok0, ok1, bl, gl, lane);
+        }
+      } else {
+        const bool col_ok = n0 + wc * 64 + (lane & 7) * 8 < p.N;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const int r0 = m0 + wr * 128 + (mi0 + d) * 16;
+          const unsigned goff = (unsigned)(r0 + (lane >> 3)) * ldc2 + (unsigned)(n0 + wc * 64) * 2u + (unsigned)(lane & 7) * 16u;
+          g8_piece<KIND == G8_GENERIC ? G8_BIAS_BF16 : KIND, F16, LAB>(acc[mi0 + d], rsC, goff, ldc2, col_ok, stg, bl, gl, lane);
+        }
       }
     }
   };
@@ -327,12 +390,12 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
-          for (int kh = 0; kh < 2; ++kh) b0[f][kh] = *(const bf16x8*)(bb + f * 2048 + kh * 1024);
+          for (int kh = 0; kh < 2; ++kh) b0[f][kh] = *(const bf16x8*)(bb + f * 2048 + kh * KH);
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
-          for (int kh = 0; kh < 2; ++kh) af[fi][kh] = *(const bf16x8*)(ab + fi * 2048 + kh * 1024);
-        issue(rsB, vo1, 1);
+          for (int kh = 0; kh < 2; ++kh) af[fi][kh] = *(const bf16x8*)(ab + fi * 2048 + kh * KH);
+        issue(rsB, vo1, ldb8, 1);
         if constexpr (NODRAIN) {
           if (seam) g8_wait_vm<6 + NST>(); else g8_wait_vm<6>();
         } else {
@@ -353,8 +416,8 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
-          for (int kh = 0; kh < 2; ++kh) b1[f][kh] = *(const bf16x8*)(bb + G8_HALF + f * 2048 + kh * 1024);
-        issue(rsB, vo2, 2);
+          for (int kh = 0; kh < 2; ++kh) b1[f][kh] = *(const bf16x8*)(bb + G8_HALF + f * 2048 + kh * KH);
+        issue(rsB, vo2, ldb8, 2);
         if constexpr (NODRAIN) {
           if (seam) g8_wait_vm<6 + NST>(); else g8_wait_vm<6>();
         } else {
@@ -375,8 +438,8 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
-          for (int kh = 0; kh < 2; ++kh) af[fi][kh] = *(const bf16x8*)(ab + 3 * G8_HALF + fi * 2048 + kh * 1024);
-        issue(rsA, vo3, 3);
+          for (int kh = 0; kh < 2; ++kh) af[fi][kh] = *(const bf16x8*)(ab + 3 * G8_HALF + fi * 2048 + kh * KH);
+        issue(rsA, vo3, lda8, 3);
         if constexpr (FAST) {
           if (head) {                                                              // third phase of a tile
             // the NEXT tile's bias slice, a whole tile ahead (unconditional so that the counts below are uniform: past the last
@@ -400,7 +463,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
         G8_BAR();
         // ---------------- phase 3: quadrant (1, 0); the load stream moves on to the next K-tile
         advance();
-        issue(rsA, vo0, 0);
+        issue(rsA, vo0, lda8, 0);
         if constexpr (FAST) {
           if (head) g8_wait_vm<6 + NB>(); else g8_wait_vm<6>();    // (the seam's stores are older than the piece this waits for)
         } else {
@@ -509,6 +572,11 @@ extern "C" int ec_lab_gemm8(const void* A, const void* W, const float* bias, voi
     case 36: k = gemm8_bf16_kernel<1, 1, false, 36>; break;
     case 40: k = gemm8_bf16_kernel<1, 1, false, 40>; break;
     case 64: k = gemm8_bf16_kernel<1, 1, false, 64>; break;
+    case 256: k = gemm8_bf16_kernel<1, 1, false, 256>; break;   // round-1 DMA pieces (16 rows x 64 B)
+    case 356: k = gemm8_bf16_kernel<3, 3, false, 256>; break;
+    case 128: k = gemm8_bf16_kernel<1, 1, false, 128>; break;   // epilogue through the LDS staging slot (round-1 form)
+    case 129: k = gemm8_bf16_kernel<1, 1, false, 129>; break;
+    case 228: k = gemm8_bf16_kernel<3, 3, false, 128>; break;   // fc1 + GELU, staged epilogue
     case 65: k = gemm8_bf16_kernel<1, 1, false, 65>; break;
     case 100: k = gemm8_bf16_kernel<3, 3, false, 0>; break;     // fc1 + GELU, pipelined
     case 164: k = gemm8_bf16_kernel<3, 3, false, 64>; break;    // fc1 + GELU, epilogue at the end of the tile

@@ -1659,6 +1659,27 @@ int ec_op_linear(const float* A, const float* W, const float* bias, const float*
   return gemm_nt(p, st);
 }
 
+int ec_op_linear_h16(const float* A, const float* W, const float* bias, const float* gamma, uint16_t* C, int M, int N, int K, int act,
+                     int precision, int repeats, void* stream) {
+  EC_REQUIRE(precision == EC_BF16 || precision == EC_F16, EC_ERR_ARG, "ec_op_linear_h16: precision must be EC_BF16 or EC_F16");
+  EC_REQUIRE(bias && repeats >= 1, EC_ERR_ARG, "ec_op_linear_h16: bias is required");
+  hipStream_t st = (hipStream_t)stream;
+  const int f16 = precision == EC_F16;
+  GemmP p;
+  p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N; p.C = C; p.bias = bias; p.gamma = gamma; p.act = act;
+  p.ab_bf16 = 1; p.c_bf16 = 1; p.h_f16 = f16;
+  bf16_t *a16 = nullptr, *w16 = nullptr;
+  EC_HIP(hipMalloc((void**)&a16, (size_t)M * K * 2));
+  EC_HIP(hipMalloc((void**)&w16, (size_t)N * K * 2));
+  int rc = f32_to_bf16(A, a16, (long)M * K, st, f16);
+  if (!rc) rc = f32_to_bf16(W, w16, (long)N * K, st, f16);
+  p.A = a16; p.B = w16;
+  for (int i = 0; i < repeats && !rc; ++i) rc = gemm_nt(p, st);   // back to back: every launch overwrites C with the same values
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(a16); (void)hipFree(w16);
+  return rc;
+}
+
 int ec_op_gemm_bench(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int precision, int iters,
                      void* stream, float* ms) {
   EC_REQUIRE(iters > 0 && ms, EC_ERR_ARG, "bad argument");

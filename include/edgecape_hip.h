@@ -169,6 +169,12 @@ int ec_profile_read(ec_handle h, float* total_ms, int* launches);
  * rounded to bf16 on device first.  act: 0 none, 1 relu, 2 gelu(erf).  bias/gamma/resid may be NULL. */
 int ec_op_linear(const float* A_dev, const float* W_dev, const float* bias_dev, const float* gamma_dev,
                  const float* resid_dev, float* C_dev, int M, int N, int K, int act, int precision, void* stream);
+/* The block GEMMs of the backbone as the model runs them: operands rounded to the 16-bit format of `precision` (EC_BF16 / EC_F16) on
+ * device, 16-BIT OUTPUT (bit patterns) with the fused epilogue act(A @ W^T + bias) * gamma - the output kinds of the 8-phase kernel
+ * (ec_gemm8.hip: qkv / proj: bias; fc2: bias, LayerScale; fc1: bias, GELU; dinov2 Attention / Mlp / LayerScale).  gamma may be NULL,
+ * act 0 or 2 (not both gamma and act).  The launch is repeated `repeats` times back to back (race screens). */
+int ec_op_linear_h16(const float* A_dev, const float* W_dev, const float* bias_dev, const float* gamma_dev, uint16_t* C_dev, int M, int N,
+                     int K, int act, int precision, int repeats, void* stream);
 /* Same GEMM on operands already in the precision's storage type (bf16 as uint16_t bit patterns), repeated
  * `iters` times; returns mean kernel time in ms via *ms (HIP events on `stream`).  Used by bench.py roofline. */
 int ec_op_gemm_bench(const void* A_dev, const void* W_dev, const float* bias_dev, void* C_dev, int M, int N, int K,

@@ -277,6 +277,50 @@ def test_gemm8_race_screen(lib, M, N, K):
         assert torch.equal(o, outs[0])
 
 
+@pytest.mark.parametrize("prec", [1, 3])
+@pytest.mark.parametrize("M,N,K,kind", [(20800, 2304, 768, "bias"), (20800, 768, 768, "scale"), (4099, 3072, 768, "gelu"), (4099, 768, 3072, "scale"),
+                                        (2600, 1152, 384, "bias"), (2600, 384, 1536, "scale"), (1300, 1536, 384, "gelu"), (5840, 1024, 1024, "bias")])
+def test_linear_h16_output_kinds(lib, M, N, K, kind, prec):
+    """The 16-bit-output epilogues of the 8-phase kernel (qkv / proj: + bias; fc2: + bias, * LayerScale; fc1: GELU(+ bias)) as the
+    backbone runs them, at ViT-B / ViT-S / ViT-L shapes with ragged M and N not a multiple of 256: values vs fp64 math of the rounded
+    operands (half an ulp of the 16-bit result + accumulation noise), nothing stored past M rows (guard region), and bit-identical
+    results over repeated back-to-back launches beside a bandwidth-heavy kernel (the tile seam's counted vmcnt waits)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    gam = (torch.rand(N, generator=g) + 0.5) if kind == "scale" else None
+    h = (lambda t: t.bfloat16()) if prec == 1 else (lambda t: t.half())
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
+    ref = h(Ad).double() @ h(Wd).double().T + bd.double()
+    if kind == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    if kind == "scale":
+        ref = ref * gam.cuda().double()
+    dt = torch.bfloat16 if prec == 1 else torch.float16
+    guard_rows = 300
+    noise = torch.empty(64 * 1024 * 1024, device="cuda")
+    side = torch.cuda.Stream()
+    outs = []
+    for it in range(4):
+        buf = torch.full(((M + guard_rows) * N,), 7.0, device="cuda", dtype=dt)
+        if it >= 2:
+            with torch.cuda.stream(side):
+                noise.add_(1.0)
+        _chk(lib, lib.ec_op_linear_h16(_p(Ad), _p(Wd), _p(bd), _p(gam.cuda()) if gam is not None else None, _p(buf), M, N, K,
+                                       2 if kind == "gelu" else 0, prec, 1 if it == 0 else 6, None))
+        torch.cuda.synchronize()
+        assert torch.all(buf[M * N:] == 7.0), "stored past the last row"
+        outs.append(buf[:M * N].view(M, N))
+    got = outs[0].double()
+    ulp = 2.0 ** -7 if prec == 1 else 2.0 ** -10
+    tol = ref.abs() * (ulp * 0.5 + 2e-6) + 3e-4 + (3e-5 if kind == "gelu" else 0.0)
+    bad = ((got - ref).abs() > tol)
+    assert not bad.any(), (int(bad.sum()), (got - ref).abs().max().item())
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 @pytest.mark.parametrize("batch,M,N,K,transB", [(3, 100, 768, 324, 0), (3, 100, 100, 100, 0), (2, 100, 100, 256, 1), (2, 100, 324, 256, 1),
                                                 (2, 17, 384, 256, 0), (2, 17, 17, 256, 1), (2, 17, 17, 17, 0), (1, 5, 256, 256, 1),
                                                 (2, 33, 65, 12, 0), (1, 1, 384, 256, 0)])

@@ -34,23 +34,28 @@ __global__ __launch_bounds__(NW * 64) void probe(char* C, int M, int N, long ldc
     const long base = (long)(m0 + wr * 128) * ldc2 + (long)n0 * 2 + wc * wbytes;
     const u32x4 v = {(unsigned)t, (unsigned)lane, 3u, 4u};
     const long s0 = __builtin_amdgcn_s_memtime();
-#pragma unroll 4
+#pragma unroll
     for (int i = 0; i < nst; ++i) {
       long off;
+      int rowi;                    // row of the store inside the wave's sub-tile
       if (pattern == 0) {          // rows of 128 B: lane>>3 = row, lane&7 = chunk; NW = 4: two column halves
         const int half = NW == 8 ? 0 : i & 1, ii = NW == 8 ? i : i >> 1;
-        off = (long)(ii * 8 + (lane >> 3)) * ldc2 + half * 128 + (lane & 7) * 16;
+        rowi = ii * 8 + (lane >> 3);
+        off = (long)rowi * ldc2 + half * 128 + (lane & 7) * 16;
       } else if (pattern == 1) {   // 16 rows x 64 B
         const int per = wbytes / 64;
-        off = (long)((i / per) * 16 + (lane & 15)) * ldc2 + (i % per) * 64 + (lane >> 4) * 16;
+        rowi = (i / per) * 16 + (lane & 15);
+        off = (long)rowi * ldc2 + (i % per) * 64 + (lane >> 4) * 16;
       } else if (pattern == 2) {   // 32 rows x 32 B
         const int per = wbytes / 32;
-        off = (long)((i / per) * 32 + (lane & 31)) * ldc2 + (i % per) * 32 + (lane >> 5) * 16;
+        rowi = (i / per) * 32 + (lane & 31);
+        off = (long)rowi * ldc2 + (i % per) * 32 + (lane >> 5) * 16;
       } else {                     // 64 rows x 16 B
         const int per = wbytes / 16;
-        off = (long)((i / per) * 64 + lane) * ldc2 + (i % per) * 16;
+        rowi = (i / per) * 64 + lane;
+        off = (long)rowi * ldc2 + (i % per) * 16;
       }
-      const int row = m0 + wr * 128 + (int)(off / ldc2);
+      const int row = m0 + wr * 128 + rowi;
       if (row < M) {
         if (nt_hint) __builtin_nontemporal_store(v, (u32x4*)(C + base + off));
         else *(u32x4*)(C + base + off) = v;
