@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--precision", default=os.environ.get("EC_BENCH_PRECISION", "fp16"), choices=["bf16", "fp16", "bf16x3", "fp32"],
                     help="backbone MFMA operand type (fp32 accumulate).  Default fp16: same MFMA rate as bf16, 8x smaller rounding - the "
                          "fastest mode whose keypoints stay inside the 1e-3 tolerance (tests/test_gpu_precision_modes.py)")
-    ap.add_argument("--head-precision", default=os.environ.get("EC_BENCH_HEAD_PRECISION", "bf16x3"), choices=["fp32", "bf16x3"],
+    ap.add_argument("--head-precision", default=os.environ.get("EC_BENCH_HEAD_PRECISION", "mixed"), choices=["fp32", "bf16x3", "mixed"],
                     help="head GEMMs: exact fp32 MFMA, or split-bf16 (hi+lo, 3 MFMAs per product; fp32-class accuracy)")
     ap.add_argument("--cpu-batches", default="2,32", help="batch sizes of the CPU-baseline protocol (BASELINE.md §4)")
     ap.add_argument("--cpu-runs", type=int, default=5, help="timed CPU forwards per batch size (after 2 warm-ups)")

@@ -13,7 +13,7 @@ from . import build as _build
 
 _LIB = None
 
-EC_F32, EC_BF16, EC_BF16X3, EC_F16 = 0, 1, 2, 3
+EC_F32, EC_BF16, EC_BF16X3, EC_F16, EC_MIXED = 0, 1, 2, 3, 4
 EC_ABI_VERSION = 2   # include/edgecape_hip.h EC_ABI_VERSION: bumped whenever a struct layout or a signature changes
 EC_DT_F32, EC_DT_F16, EC_DT_BF16, EC_DT_F64 = 0, 1, 2, 3
 EC_LAYOUT_TOKENS, EC_LAYOUT_NCHW = 0, 1
@@ -96,7 +96,7 @@ def load():
     lib.ec_op_bgemm.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, vp]
     lib.ec_op_layernorm.argtypes = [vp, vp, vp, vp, ci, ci, cf, vp]
     lib.ec_op_attention.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
-    lib.ec_op_chain.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp]
+    lib.ec_op_chain.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, vp]
     for n in EXPORTS:
         if n not in ("ec_last_error", "ec_version", "ec_abi_sizes"):
             getattr(lib, n).restype = ci

@@ -30,6 +30,7 @@ struct ChainStage {
   float* out = nullptr; long ldo = 0;
   int s_off = -1;
   int keep = 0;
+  int h1 = 0;                    // W is the single-pass fp16 packing (must agree with ChainP::h1)
 };
 struct ChainP {
   int rows = 0, n_stages = 0, lds_bytes = 0;
@@ -38,12 +39,16 @@ struct ChainP {
   // workgroup streams roughly half of those stages' weights.  Needs out != resid in the shared stages (the other part may still
   // be reading the residual): the callers ping-pong the token state between two buffers.
   int split = 1;
+  // h1: single-pass fp16 arithmetic (the head's mixed precision, ec_gemm.hip GM_SPLIT1) in EVERY stage: the hi plane of the weights
+  // (pack_chain_weights with h1) and of the LDS activations holds fp16, the lo planes are neither loaded nor written, one
+  // v_mfma_f32_16x16x32_f16 per product.  Half the weight bytes - which is what bounds the kernel - and a third of the MFMAs.
+  int h1 = 0;
   ChainStage st[CH_MAX_STAGES];
 };
 
 int chain_layout_bytes(int k);   // bytes of an operand buffer of k columns (32 rows)
 int run_chain(const ChainP& p, hipStream_t st);
 // host: W [N, K] fp32 -> fragment-major split packing, N*K*4 bytes (N % 16 == 0, K % 32 == 0)
-void pack_chain_weights(const float* W, long N, long K, void* out);
+void pack_chain_weights(const float* W, long N, long K, void* out, bool h1 = false);   // h1: hi plane = fp16(W), lo plane = 0
 
 }  // namespace ec

@@ -52,6 +52,11 @@ __device__ __forceinline__ void split4(const f32x4 x, u32x2& hi, u32x2& lo) {
   }
 }
 
+// 4 floats -> 4 fp16 (RNE): the single-pass form's only plane
+__device__ __forceinline__ u32x2 half4(const f32x4 x) {
+  return __builtin_bit_cast(u32x2, __builtin_convertvector(x, f16x4));
+}
+
 struct WBatch { bf16x8 w[4][2][2]; };   // [k-block of the batch][n-fragment][plane]
 
 __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
@@ -62,6 +67,7 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
   const int slab = blockIdx.x / p.split, part = blockIdx.x - slab * p.split;
   const int row0 = slab * CH_BM;
   const int lrow = lane & 15, lq = lane >> 4;
+  const bool h1 = p.h1 != 0;
   float* const red = (float*)smem;
 
   f32x4 keep[2][2];
@@ -105,12 +111,14 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
       // fragment (f, kb, plane) = 1 KiB at ((f * nkb + kb) * 2 + plane) * 1024, lane-linear
       const unsigned v0 = i < T ? (unsigned)(((pass_of(ps) * 16 + wave * 2) * nkb + kb0) * 2048 + lane * 16) : 0x80000000u;
       const unsigned v1 = v0 + (unsigned)nkb * 2048u;
+      // single-pass fp16: the lo planes are requested out of range (zeros, no memory traffic; the load count stays the same)
+      const unsigned l0 = h1 ? 0x80000000u : v0, l1 = h1 ? 0x80000000u : v1;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         b.w[k][0][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, v0 + k * 2048, 0, 0));
-        b.w[k][0][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, v0 + (1024 + k * 2048), 0, 0));
+        b.w[k][0][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, l0 + (1024 + k * 2048), 0, 0));
         b.w[k][1][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, v1 + k * 2048, 0, 0));
-        b.w[k][1][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, v1 + (1024 + k * 2048), 0, 0));
+        b.w[k][1][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, l1 + (1024 + k * 2048), 0, 0));
       }
     };
 
@@ -127,6 +135,15 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
         const char* x = kb < nkb1 ? xa + kb * 128 : xb + (kb - nkb1) * 128;
         const long pitch = kb < nkb1 ? pitch_a : pitch_b;
         bf16x8 xh[2], xl[2];
+        if (h1) {   // (wave-uniform) single-pass fp16: hi planes only, one MFMA per product
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) xh[mi] = *(const bf16x8*)(x + mi * 16 * pitch);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) acc[mi][j] = mfma16x16x32_h<true>(b.w[k][j][0], xh[mi], acc[mi][j]);
+          continue;
+        }
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           xh[mi] = *(const bf16x8*)(x + mi * 16 * pitch);
@@ -237,11 +254,15 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
           const int r = mi * 16 + lrow;
           if (store_out && row0 + r < p.rows) *(f32x4*)(S.out + (long)(row0 + r) * S.ldo + n) = acc[mi][j];
           if (S.s_off >= 0) {
-            u32x2 hi, lo;
-            split4(acc[mi][j], hi, lo);
             char* dst = smem + S.s_off + r * ((long)S.N * 4 + 16) + (n >> 5) * 128 + (n & 31) * 2;
-            *(u32x2*)dst = hi;
-            *(u32x2*)(dst + 64) = lo;
+            if (h1) {
+              *(u32x2*)dst = half4(acc[mi][j]);
+            } else {
+              u32x2 hi, lo;
+              split4(acc[mi][j], hi, lo);
+              *(u32x2*)dst = hi;
+              *(u32x2*)(dst + 64) = lo;
+            }
           }
           if (S.keep) keep[mi][j] = acc[mi][j];
           acc[mi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -289,11 +310,15 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (base + u * 512 >= total) continue;
-          u32x2 hi, lo;
-          split4(v[u], hi, lo);
           char* dst = smem + S.g_off + r[u] * pitch + (c[u] >> 5) * 128 + (c[u] & 31) * 2;
-          *(u32x2*)dst = hi;
-          *(u32x2*)(dst + 64) = lo;
+          if (h1) {
+            *(u32x2*)dst = half4(v[u]);
+          } else {
+            u32x2 hi, lo;
+            split4(v[u], hi, lo);
+            *(u32x2*)dst = hi;
+            *(u32x2*)(dst + 64) = lo;
+          }
         }
       }
     }
@@ -321,7 +346,7 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
 // host: W [N, K] fp32 (nn.Linear layout) -> fragment-major bf16x3 packing, N*K*4 bytes:
 //   fragment (f = n / 16, kb = k / 32, plane) is 1 KiB: lane l holds the 8 bf16 W[f*16 + (l & 15)][kb*32 + (l >> 4)*8 .. +7]
 //   (hi plane: RNE(w); lo plane: RNE(w - hi)); fragments ordered ((f * K/32 + kb) * 2 + plane).
-void pack_chain_weights(const float* W, long N, long K, void* out) {
+void pack_chain_weights(const float* W, long N, long K, void* out, bool h1) {
   bf16_t* o = (bf16_t*)out;
   const long nkb = K / 32;
   for (long f = 0; f < N / 16; ++f)
@@ -331,6 +356,7 @@ void pack_chain_weights(const float* W, long N, long K, void* out) {
         bf16_t* hi = o + ((f * nkb + kb) * 2) * 512 + l * 8;
         bf16_t* lo = hi + 512;
         for (int i = 0; i < 8; ++i) {
+          if (h1) { hi[i] = f2half_host(src[i]); lo[i] = 0; continue; }
           const bf16_t h = f2bf(src[i]);
           hi[i] = h;
           lo[i] = f2bf(src[i] - bf2f(h));
@@ -359,6 +385,7 @@ int run_chain(const ChainP& p, hipStream_t st) {
     EC_REQUIRE(S.g_k == 0 || (S.g_in && S.g_k % 32 == 0 && S.g_off >= CH_RED && S.g_off + chain_layout_bytes(S.g_k) <= p.lds_bytes), -1, "chain: staged input out of range");
     EC_REQUIRE(S.s_off < 0 || (S.s_off >= CH_RED && S.s_off + chain_layout_bytes(S.N) <= p.lds_bytes), -1, "chain: output buffer out of range");
     EC_REQUIRE(!S.table || S.period > 0, -1, "chain: table period");
+    EC_REQUIRE((S.h1 != 0) == (p.h1 != 0), -1, "chain: stages packed for different arithmetic");
     EC_REQUIRE(p.split == 1 || !(S.s_off >= 0 || S.keep || S.ln_w) || !S.resid || !S.out || S.resid != S.out, -1,
                "chain: split chains need out != resid in the stages both workgroups compute");
   }

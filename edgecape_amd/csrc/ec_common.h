@@ -163,12 +163,14 @@ struct GemmP {
   int c_bf16 = 0;   // store C as bf16
   int ab_bf16 = 0;  // A and B are 16-bit (else fp32)
   int h_f16 = 0;    // the 16-bit format (operands and, with c_bf16, the output) is IEEE fp16 instead of bf16
-  int split = 0;    // bf16x3: A fp32, B pre-split into [32 hi | 32 lo] bf16 per 32-k block (split_pack_weights)
+  int split = 0;    // 1 = bf16x3: A fp32, B pre-split into [32 hi | 32 lo] bf16 per 32-k block (split_pack_weights);
+                    // 2 = fp16x1: A fp32 rounded to fp16 in registers, B [32 fp16 | unused] per 32-k block (split_pack_weights_h1)
   int tag = 0;      // kernel-symbol tag (profiling only): 1 qkv, 2 proj, 3 fc1, 4 fc2
 };
 int gemm_nt(const GemmP& p, hipStream_t st);
 // host: W [N,K] fp32 -> bf16x3 packing of the same byte size: per row, per 32-k block, 32 hi bf16 then 32 lo bf16
 void split_pack_weights(const float* W, long n_rows, long K, float* out);
+void split_pack_weights_h1(const float* W, long n_rows, long K, float* out);   // [32 fp16 | 32 x 0] per 32-k block
 // 256x256x64 8-phase bf16 kernel (ec_gemm8.hip): 1 = handled, 0 = shape not eligible (use gemm_nt's own kernels), < 0 error
 int gemm8_bf16(const GemmP& p, hipStream_t st);
 // 256x256x64 four-wave kernel, one wave per SIMD, stores of a tile under the next tile's K loop (ec_gemm4.hip): same return contract;

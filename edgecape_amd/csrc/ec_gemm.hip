@@ -71,7 +71,11 @@ __device__ inline float gelu_fast(float x) {
 // the host into the same 128-byte K-blocks ([32 hi | 32 lo] bf16 per 32 k) so staging and addressing are those of fp32;
 // acc += hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate): ~2^-17 relative operand error at 16/3 of the
 // fp32 MFMA rate — the head's throughput mode (the head is 6 % of the FLOPs; keeping it fp32-class keeps the 1e-3 gate).
-enum { GM_F32 = 0, GM_BF16 = 1, GM_SPLIT = 2, GM_F16 = 3 };   // GM_F16: as GM_BF16 with IEEE fp16 operands / output
+// MODE 4 ("fp16x1", the single-pass form of the head's mixed precision): the same data as MODE 2 - A fp32 in memory, B in 128-byte
+// K-blocks of 32 k - but ONE v_mfma_f32_32x32x16_f16 per product: A is rounded to fp16 in registers, the first 64 bytes of a B
+// block hold fp16(W) (split_pack_weights_h1; the second half is unused).  Used where oracle/head_precision_study.py shows the
+// 1e-3 gate has room for it (skeleton head, decoder): a third of the MFMA work of bf16x3.
+enum { GM_F32 = 0, GM_BF16 = 1, GM_SPLIT = 2, GM_F16 = 3, GM_SPLIT1 = 4 };   // GM_F16: as GM_BF16 with IEEE fp16 operands / output
 
 __device__ __forceinline__ void split8(const f32x4 x0, const f32x4 x1, bf16x8& hi, bf16x8& lo) {
   typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -202,6 +206,31 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_nt_kernel(GemmP p) {
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[i], al[j], acc[i][j], 0, 0, 0);
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[i], ah[j], acc[i][j], 0, 0, 0);
             }
+        }
+      } else if constexpr (MODE == GM_SPLIT1) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {   // two 16-k MFMA steps per 32-k stage, one MFMA per product
+          bf16x8 ah[MT], bh[NT];
+#pragma unroll
+          for (int j = 0; j < MT; ++j) {
+            const int ra = wm * (BM / WGM) + j * 32 + lrow;
+            const int sw = (ra >> 1) & 7, c0 = ks * 4 + hi * 2;
+            const f32x4 x0 = *(const f32x4*)(At + ra * KBYTES + ((c0 ^ sw) << 4));
+            const f32x4 x1 = *(const f32x4*)(At + ra * KBYTES + (((c0 + 1) ^ sw) << 4));
+            typedef __attribute__((ext_vector_type(8))) float f32x8_;
+            const f32x8_ x = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            ah[j] = __builtin_bit_cast(bf16x8, __builtin_convertvector(x, f16x8));   // 4 x v_cvt_pk_f16_f32 (RNE)
+          }
+#pragma unroll
+          for (int i = 0; i < NT; ++i) {
+            const int rb = wn * (BN / WGN) + i * 32 + lrow;
+            const int sw = (rb >> 1) & 7, c0 = ks * 2 + hi;
+            bh[i] = *(const bf16x8*)(Bt + rb * KBYTES + ((c0 ^ sw) << 4));
+          }
+#pragma unroll
+          for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = mfma32x32x16_h<true>(bh[i], ah[j], acc[i][j]);
         }
       } else
 #pragma unroll
@@ -488,7 +517,7 @@ struct Cfg { int bm, bn, threads, lds, per_cu; };
 template <int MODE, int BM, int BN, int WGM, int WGN, int NS>
 int launch_cfg(const GemmP& p, hipStream_t st, int per_cu) {
   typedef void (*kern_t)(GemmP);
-  constexpr bool TAGGED = MODE != GM_SPLIT && MODE != GM_F16 && BM == 256;   // per-tag symbols only where rocprof needs to tell the backbone GEMMs apart
+  constexpr bool TAGGED = MODE != GM_SPLIT && MODE != GM_SPLIT1 && MODE != GM_F16 && BM == 256;   // per-tag symbols only where rocprof needs to tell the backbone GEMMs apart
   static const kern_t table[5] = {gemm_nt_kernel<MODE, BM, BN, WGM, WGN, NS, 0>, gemm_nt_kernel<MODE, BM, BN, WGM, WGN, NS, TAGGED ? 1 : 0>,
                                   gemm_nt_kernel<MODE, BM, BN, WGM, WGN, NS, TAGGED ? 2 : 0>, gemm_nt_kernel<MODE, BM, BN, WGM, WGN, NS, TAGGED ? 3 : 0>,
                                   gemm_nt_kernel<MODE, BM, BN, WGM, WGN, NS, TAGGED ? 4 : 0>};
@@ -576,6 +605,15 @@ int gemm_nt(const GemmP& p, hipStream_t st) {
       default: return (deep ? launch_cfg<GM_BF16, 64, 64, 2, 2, 4>(p, st, 2) : launch_cfg<GM_BF16, 64, 64, 2, 2, 2>(p, st, 4));
     }
   }
+  if (p.split == 2) {   // fp16x1: the single-pass form of the head's mixed precision
+    switch (sel) {
+      case 0: return launch_cfg<GM_SPLIT1, 256, 256, 2, 4, 2>(p, st, 1);
+      case 1: return launch_cfg<GM_SPLIT1, 256, 128, 4, 2, 2>(p, st, 1);
+      case 2: return launch_cfg<GM_SPLIT1, 128, 128, 2, 2, 2>(p, st, 2);
+      case 3: return launch_cfg<GM_SPLIT1, 128, 64, 2, 2, 2>(p, st, 3);
+      default: return launch_cfg<GM_SPLIT1, 64, 64, 2, 2, 2>(p, st, 4);
+    }
+  }
   if (p.split) {
     // experiment kept for A/B: wide-N wave tiles (32 x 128 per wave) share the in-register hi/lo split of an A fragment
     // (~30 VALU) between 4 x 3 MFMAs instead of 1-2 x 3 (PMC at 128x64: 16.7 VALU per MFMA, MFMA pipe 19 % busy, waves one third
@@ -636,6 +674,18 @@ void split_pack_weights(const float* W, long n_rows, long K, float* out) {
         const bf16_t h = f2bf(src[j]);
         dst[j] = h;
         dst[32 + j] = f2bf(src[j] - bf2f(h));
+      }
+    }
+}
+
+void split_pack_weights_h1(const float* W, long n_rows, long K, float* out) {
+  for (long r = 0; r < n_rows; ++r)
+    for (long kb = 0; kb < K / 32; ++kb) {
+      const float* src = W + r * K + kb * 32;
+      bf16_t* dst = (bf16_t*)(out + r * K + kb * 32);
+      for (int j = 0; j < 32; ++j) {
+        dst[j] = f2half_host(src[j]);
+        dst[32 + j] = 0;
       }
     }
 }

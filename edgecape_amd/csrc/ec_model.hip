@@ -46,6 +46,7 @@ struct Lin {  // a Linear layer view: W [N,K] (+ optional bf16 copy), bias [N]
   const float* b = nullptr;
   int N = 0, K = 0;
   bool w16_is_f16 = false;     // w16 holds IEEE fp16 (EC_F16 backbone) instead of bf16
+  bool h1 = false;             // ws / wc are the single-pass fp16 packings (head mixed precision: skeleton head + decoder layers)
   const void* wsel(bool split) const { return split ? (const void*)ws : (const void*)w; }
 };
 struct Norm { const float* w = nullptr; const float* b = nullptr; };
@@ -79,6 +80,8 @@ struct ec_model {
   bool bbf16 = false;        // ... in IEEE fp16 (EC_F16) instead of bf16 (EC_BF16)
   bool bb_split = false;     // EC_BF16X3 backbone: fp32 activations, every MFMA operand split hi+lo bf16 (3 MFMAs per product)
   bool head_split = false;   // head GEMMs in bf16x3 (ec_gemm.hip GM_SPLIT)
+  bool head_mixed = false;   // ... except the Linear layers of the skeleton head and the decoder layers: single-pass fp16 (GM_SPLIT1)
+  bool cur_h1 = false;       // build time: the Lin being made belongs to that set
   bool head_chain = false;   // ... and the row-wise stretches of every head layer as row-chain launches (ec_chain.hip); EC_CHAIN=0: off
   // the support half of the head (pooling + SkeletonPredictor) has no query input: it runs on a side stream, concurrently
   // with input_proj / encoder / proposal generator on the caller's stream (both are small-grid, latency-bound kernels)
@@ -193,14 +196,15 @@ static int upload16(ec_model* m, const std::vector<float>& h, const bf16_t** out
 static int upload_split(ec_model* m, const float* W, long rows, long K, const float** out) {
   EC_REQUIRE(K % 32 == 0, EC_ERR_ARG, "bf16x3 packing needs K % 32 == 0");
   std::vector<float> packed((size_t)rows * K);
-  split_pack_weights(W, rows, K, packed.data());
+  if (m->cur_h1) split_pack_weights_h1(W, rows, K, packed.data());
+  else split_pack_weights(W, rows, K, packed.data());
   return upload(m, packed, out);
 }
 // fragment-major split packing for the row-chain kernel; shapes the kernel cannot take simply get no such copy
 static int upload_chain(ec_model* m, const float* W, long rows, long K, const void** out) {
   if (rows % 32 != 0 || K % 128 != 0) return 0;
   std::vector<float> packed((size_t)rows * K);
-  pack_chain_weights(W, rows, K, packed.data());
+  pack_chain_weights(W, rows, K, packed.data(), m->cur_h1);
   const float* dev = nullptr;
   int rc = upload(m, packed, &dev);
   *out = dev;
@@ -234,6 +238,7 @@ static int make_lin(ec_model* m, const std::string& wname, const std::string& bn
     int rc = upload_split(m, w->host.data(), out->N, out->K, &out->ws);
     if (rc) return rc;
     if (m->head_chain && name_is_head(wname) && (rc = upload_chain(m, w->host.data(), out->N, out->K, &out->wc))) return rc;
+    out->h1 = m->cur_h1 && name_is_head(wname);
   }
   return 0;
 }
@@ -243,6 +248,7 @@ static int make_lin_host(ec_model* m, const std::vector<float>& W, const std::ve
   if (rc) return rc;
   if (m->head_split && (rc = upload_split(m, W.data(), N, K, &out->ws))) return rc;   // make_lin_host is only used by the head
   if (m->head_chain && (rc = upload_chain(m, W.data(), N, K, &out->wc))) return rc;
+  out->h1 = m->head_split && m->cur_h1;
   if (!b.empty()) rc = upload(m, b, &out->b);
   return rc;
 }
@@ -383,7 +389,7 @@ static int linear(const void* A, long lda, bool a16, const Lin& W, void* C, long
   GemmP p;
   p.tag = tag;
   p.A = A; p.lda = lda; p.ab_bf16 = a16 ? 1 : 0; p.h_f16 = (a16 && W.w16_is_f16) ? 1 : 0;
-  p.split = (!a16 && W.ws) ? 1 : 0;     // head in bf16x3 mode: every head Lin carries a split-packed copy
+  p.split = (!a16 && W.ws) ? (W.h1 ? 2 : 1) : 0;   // head in bf16x3 mode: every head Lin carries a split-packed copy (h1: fp16x1)
   p.B = a16 ? (const void*)W.w16 : W.wsel(p.split); p.ldb = W.K;
   EC_REQUIRE(p.B != nullptr, EC_ERR_STATE, "linear: weight copy for this precision was not built");
   p.C = C; p.ldc = ldc; p.c_bf16 = c16 ? 1 : 0;
@@ -518,7 +524,7 @@ static int project_image_kv(ec_model* m, const DecLayer& L, const float* mem, lo
   const int d = m->d, E = m->E, HW = m->HW;
   GemmP p;
   p.A = mem; p.lda = d; p.sA = s_mem;
-  p.split = L.ca_kv.ws ? 1 : 0; p.B = L.ca_kv.wsel(p.split); p.ldb = d;
+  p.split = L.ca_kv.ws ? (L.ca_kv.h1 ? 2 : 1) : 0; p.B = L.ca_kv.wsel(p.split); p.ldb = d;
   p.C = kv; p.ldc = 2 * E; p.sC = (long)HW * 2 * E;
   p.table = L.ca_kv_table; p.ldt = 2 * E; p.period = HW;
   p.M = HW; p.N = 2 * E; p.K = d; p.batch = nb;
@@ -555,13 +561,14 @@ struct ChainBuild {
   ChainStage& add() { return p.st[p.n_stages++]; }
   int run(int rows, hipStream_t st, bool may_split = false) {
     p.rows = rows; p.lds_bytes = top;
+    p.h1 = p.st[0].h1;   // one arithmetic per chain (run_chain checks that every stage was packed for it)
     // two workgroups per slab while that still fits one round of the chip and there is a stage to deal out
     static const bool no_split = getenv("EC_CHAIN_SPLIT") && atoi(getenv("EC_CHAIN_SPLIT")) == 0;   // A/B switch
     p.split = (may_split && !no_split && p.n_stages > 1 && ((rows + CH_BM - 1) / CH_BM) * 2 <= 256) ? 2 : 1;
     return run_chain(p, st);
   }
 };
-static void chain_lin(ChainStage& S, const Lin& W) { S.W = W.wc; S.bias = W.b; S.N = W.N; S.K = W.K; S.k1 = W.K; }
+static void chain_lin(ChainStage& S, const Lin& W) { S.W = W.wc; S.bias = W.b; S.N = W.N; S.K = W.K; S.k1 = W.K; S.h1 = W.h1 ? 1 : 0; }
 static bool chain_ok(const Lin& W) { return W.wc != nullptr; }
 
 // x <- LayerNorm(x + in @ W^T + b): the residual branch shared by the three chains of a layer.  Returns the LDS buffer with x.
@@ -953,7 +960,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
      // tokens for ALL decoder layers in one GEMM (stacked weights [nL*2E, d], stacked positional tables [HW, nL*2E])
     GemmP p;
     p.A = mem; p.lda = d; p.sA = s_tok;
-    p.split = m->dec_kv_all.ws ? 1 : 0; p.B = m->dec_kv_all.wsel(p.split); p.ldb = d;
+    p.split = m->dec_kv_all.ws ? (m->dec_kv_all.h1 ? 2 : 1) : 0; p.B = m->dec_kv_all.wsel(p.split); p.ldb = d;
     p.C = m->d_kv; p.ldc = (long)nL * 2 * E; p.sC = (long)HW * nL * 2 * E;
     p.table = m->dec_kv_table; p.ldt = (long)nL * 2 * E; p.period = HW;
     p.M = HW; p.N = nL * 2 * E; p.K = d; p.batch = bs;
@@ -1183,8 +1190,8 @@ int ec_create(const ec_config* cfg, ec_handle* out) {
   EC_REQUIRE(cfg->dec_layers >= 1 && cfg->dec_layers <= 8, EC_ERR_ARG, "num_decoder_layers must be within 1..8");
   EC_REQUIRE(cfg->enc_layers >= 0 && cfg->enc_layers <= 8, EC_ERR_ARG, "num_encoder_layers must be within 0..8");
   EC_REQUIRE(cfg->skel_layers >= 1 && cfg->skel_layers <= 8, EC_ERR_ARG, "skeleton_predictor depth must be within 1..8");
-  EC_REQUIRE(cfg->head_precision == EC_F32 || cfg->head_precision == EC_BF16X3, EC_ERR_ARG,
-             "head_precision: EC_F32 (exact) or EC_BF16X3 (split-bf16 MFMA, fp32-class accuracy)");
+  EC_REQUIRE(cfg->head_precision == EC_F32 || cfg->head_precision == EC_BF16X3 || cfg->head_precision == EC_MIXED, EC_ERR_ARG,
+             "head_precision: EC_F32 (exact), EC_BF16X3 (split-bf16 MFMA, fp32-class accuracy) or EC_MIXED (bf16x3 + single-pass fp16)");
   EC_REQUIRE(cfg->max_batch > 0 && cfg->max_shots > 0, EC_ERR_ARG, "max_batch / max_shots must be positive");
   ec_model* m = new ec_model();
   m->cfg = *cfg;
@@ -1196,7 +1203,8 @@ int ec_create(const ec_config* cfg, ec_handle* out) {
   m->bb_split = cfg->backbone_precision == EC_BF16X3;
   m->bb16 = cfg->backbone_precision == EC_BF16 || cfg->backbone_precision == EC_F16;
   m->bbf16 = cfg->backbone_precision == EC_F16;
-  m->head_split = cfg->head_precision == EC_BF16X3;
+  m->head_split = cfg->head_precision == EC_BF16X3 || cfg->head_precision == EC_MIXED;
+  m->head_mixed = cfg->head_precision == EC_MIXED;
   m->head_chain = m->head_split && !(getenv("EC_CHAIN") && atoi(getenv("EC_CHAIN")) == 0);
   EC_REQUIRE(m->g >= 2 && m->g <= 32, EC_ERR_ARG, "token grid must be within 2..32");
   *out = m;
@@ -1291,8 +1299,10 @@ int ec_finalize(ec_handle m) {
   }
   if ((rc = make_lin(m, hp + "input_proj.weight", hp + "input_proj.bias", &m->input_proj, false))) return rc;
   if ((rc = make_lin(m, hp + "query_proj.weight", hp + "query_proj.bias", &m->query_proj, false))) return rc;
-  if ((rc = make_lin(m, hp + "skeleton_head.image_project.weight", hp + "skeleton_head.image_project.bias", &m->image_project, false)))
-    return rc;
+  m->cur_h1 = m->head_mixed;   // the skeleton head's image projection, its two-way layers and the decoder layers: single-pass fp16
+  rc = make_lin(m, hp + "skeleton_head.image_project.weight", hp + "skeleton_head.image_project.bias", &m->image_project, false);
+  m->cur_h1 = false;
+  if (rc) return rc;
   EC_REQUIRE(m->input_proj.K == C && m->query_proj.K == C, EC_ERR_ARG, "head in_channels must equal backbone width");
   EC_REQUIRE(m->image_project.K == C && m->cfg.skel_ffn_dim == C, EC_ERR_ARG,
              "skeleton_head.dim_feedforward must equal the backbone width (skeleton.py:40,92)");
@@ -1300,6 +1310,8 @@ int ec_finalize(ec_handle m) {
     GET(zw, hp + "skeleton_head.zero_conv.weight"); GET(zb, hp + "skeleton_head.zero_conv.bias");
     m->zc_w = zw->dev; m->zc_b = zb->dev;
   }
+  m->cur_h1 = m->head_mixed;
+  struct H1Off { ec_model* m; ~H1Off() { m->cur_h1 = false; } } h1_off{m};   // (every early return below leaves the flag cleared)
   m->skel.resize(m->cfg.skel_layers);
   for (int i = 0; i < m->cfg.skel_layers; ++i)
     if ((rc = build_dec_layer(m, hp + "skeleton_head.skeleton_predictor." + std::to_string(i) + ".", false, true, pos_img, &m->skel[i])))
@@ -1321,6 +1333,7 @@ int ec_finalize(ec_handle m) {
     for (auto& l : m->dec) { std::vector<float>().swap(l.h_kv_w); std::vector<float>().swap(l.h_kv_table); }
     for (auto& l : m->skel) { std::vector<float>().swap(l.h_kv_w); std::vector<float>().swap(l.h_kv_table); }
   }
+  m->cur_h1 = false;
   for (auto& l : m->skel) EC_REQUIRE(l.ffn1.N == 2 * m->cfg.skel_ffn_dim, EC_ERR_ARG, "skeleton GCN width mismatch");
   for (auto& l : m->dec) EC_REQUIRE(l.ffn1.N == 2 * m->cfg.ffn_dim, EC_ERR_ARG, "decoder GCN width mismatch");
   m->enc.resize(m->cfg.enc_layers);
@@ -1640,16 +1653,17 @@ int ec_op_linear(const float* A, const float* W, const float* bias, const float*
     (void)hipFree(a16); (void)hipFree(w16);
     return rc;
   }
-  if (precision == EC_BF16X3) {   // W is split-packed on the host (as ec_finalize does for the head weights), A stays fp32
+  if (precision == EC_BF16X3 || precision == EC_MIXED) {   // W is packed on the host (as ec_finalize does for the head weights), A stays fp32
     EC_REQUIRE(K % 32 == 0, EC_ERR_ARG, "bf16x3 needs K % 32 == 0");
     std::vector<float> hw((size_t)N * K), packed((size_t)N * K);
     EC_HIP(hipStreamSynchronize(st));
     EC_HIP(hipMemcpy(hw.data(), W, hw.size() * 4, hipMemcpyDeviceToHost));
-    split_pack_weights(hw.data(), N, K, packed.data());
+    if (precision == EC_MIXED) split_pack_weights_h1(hw.data(), N, K, packed.data());   // the single-pass fp16 form of EC_MIXED
+    else split_pack_weights(hw.data(), N, K, packed.data());
     float* ws = nullptr;
     EC_HIP(hipMalloc((void**)&ws, packed.size() * 4));
     EC_HIP(hipMemcpy(ws, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
-    p.A = A; p.B = ws; p.split = 1;
+    p.A = A; p.B = ws; p.split = precision == EC_MIXED ? 2 : 1;
     int rc = gemm_nt(p, st);
     (void)hipStreamSynchronize(st);
     (void)hipFree(ws);
@@ -1722,15 +1736,17 @@ int ec_op_layernorm(const float* x, const float* w, const float* b, float* y, in
 int ec_op_chain(const float* X, int K1, const float* W1, const float* b1, const float* resid, const float* ln1_w, const float* ln1_b,
                 float* x1_out, const float* cat, int Kcat, const float* W2, const float* b2, int N2, int act2, const float* table,
                 int period, float* out2, const float* W3, const float* b3, const float* ln3_w, const float* ln3_b, float* x3_out,
-                int rows, void* stream) {
+                int rows, int precision, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   EC_REQUIRE(X && W1 && ln1_w && ln1_b && x1_out && W2 && out2 && rows > 0, EC_ERR_ARG, "ec_op_chain: missing argument");
+  EC_REQUIRE(precision == EC_BF16X3 || precision == EC_MIXED, EC_ERR_ARG, "ec_op_chain: precision EC_BF16X3 or EC_MIXED (single-pass fp16)");
+  const bool h1 = precision == EC_MIXED;
   EC_REQUIRE(K1 % 128 == 0 && Kcat % 128 == 0 && N2 % 128 == 0 && (Kcat == 0 || cat), EC_ERR_ARG, "ec_op_chain: shapes");
   std::vector<void*> tmp;
   auto pack = [&](const float* Wd, int N, int K, const void** out) -> int {   // device fp32 [N,K] -> chain packing on device
     std::vector<float> h((size_t)N * K), pk((size_t)N * K);
     EC_HIP(hipMemcpy(h.data(), Wd, h.size() * 4, hipMemcpyDeviceToHost));
-    pack_chain_weights(h.data(), N, K, pk.data());
+    pack_chain_weights(h.data(), N, K, pk.data(), h1);
     void* d = nullptr;
     EC_HIP(hipMalloc(&d, pk.size() * 4));
     tmp.push_back(d);
@@ -1768,6 +1784,8 @@ int ec_op_chain(const float* X, int K1, const float* W1, const float* b1, const 
     S.resid_keep = 1; S.ln_w = ln3_w; S.ln_b = ln3_b;
     S.out = x3_out; S.ldo = 256;
   }
+  p.h1 = h1 ? 1 : 0;
+  for (int i = 0; i < p.n_stages; ++i) p.st[i].h1 = p.h1;
   p.rows = rows; p.lds_bytes = top;
   // a residual input that is NOT the output buffer selects the two-workgroups-per-slab form (ChainP::split), as the head uses it
   p.split = (resid && resid != x1_out && ((rows + CH_BM - 1) / CH_BM) * 2 <= 256) ? 2 : 1;

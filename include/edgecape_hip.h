@@ -52,8 +52,13 @@ enum ec_precision {
   EC_F32 = 0,     /* fp32 operands, exact products (v_mfma_f32_32x32x2_f32) */
   EC_BF16 = 1,    /* bf16 operands, fp32 accumulate */
   EC_BF16X3 = 2,  /* fp32 data, each operand split into hi+lo bf16, 3 bf16 MFMAs per product: ~2^-17 relative (head only) */
-  EC_F16 = 3      /* IEEE fp16 operands (11 significand bits, same MFMA rate as bf16), fp32 accumulate: the backbone mode that
+  EC_F16 = 3,     /* IEEE fp16 operands (11 significand bits, same MFMA rate as bf16), fp32 accumulate: the backbone mode that
                      keeps output_kpts inside the 1e-3 tolerance at bf16 speed (backbone only) */
+  EC_MIXED = 4    /* head only: EC_BF16X3 everywhere the proposal generator's argmax depends on (input projections, support pooling,
+                     encoder, proposal generator - encoder_decoder.py:91-110 is the path's one discontinuity) and in the small MLPs;
+                     single-pass fp16 MFMAs (fp32 data rounded to fp16 operands, fp32 accumulate) in the Linear layers of the skeleton
+                     head (skeleton.py:58-161) and of the decoder layers (encoder_decoder.py:584-651), which only move the output
+                     continuously: max |d kpt| 1.6e-4 vs 1.55e-4 without (oracle/head_precision_study.py, 32 pairs) */
 };
 enum ec_dtype { EC_DT_F32 = 0, EC_DT_F16 = 1, EC_DT_BF16 = 2, EC_DT_F64 = 3 };
 enum ec_layout { EC_LAYOUT_TOKENS = 0, EC_LAYOUT_NCHW = 1 };
@@ -77,7 +82,7 @@ typedef struct ec_config {
   int32_t max_shots;          /* S_max */
   int32_t max_batch;          /* bs_max (pairs per call) */
   int32_t backbone_precision; /* ec_precision: operand type of the backbone MFMA GEMMs/attention (fp32 accumulate always) */
-  int32_t head_precision;     /* EC_F32 or EC_BF16X3: GEMM operand handling in the head (attention/LayerNorm/softmax stay fp32) */
+  int32_t head_precision;     /* EC_F32, EC_BF16X3 or EC_MIXED: GEMM operand handling in the head (LayerNorm / softmax statistics stay fp32) */
 } ec_config;
 
 typedef struct ec_outputs {
@@ -166,7 +171,7 @@ int ec_profile_read(ec_handle h, float* total_ms, int* launches);
 
 /* ---- single ops (parity tests / microbenchmarks) -------------------------------------------- */
 /* C[M,N] = epilogue(A[M,K] @ W[N,K]^T): precision EC_F32 -> fp32 operands, EC_BF16 -> operands are
- * rounded to bf16 on device first.  act: 0 none, 1 relu, 2 gelu(erf).  bias/gamma/resid may be NULL. */
+ * rounded to bf16 on device first (EC_MIXED: the single-pass fp16 form of the mixed head precision).  act: 0 none, 1 relu, 2 gelu(erf).  bias/gamma/resid may be NULL. */
 int ec_op_linear(const float* A_dev, const float* W_dev, const float* bias_dev, const float* gamma_dev,
                  const float* resid_dev, float* C_dev, int M, int N, int K, int act, int precision, void* stream);
 /* The block GEMMs of the backbone as the model runs them: operands rounded to the 16-bit format of `precision` (EC_BF16 / EC_F16) on
@@ -192,11 +197,12 @@ int ec_op_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, 
  * (transformer.py-style residual blocks: EdgeCape/models/keypoint_heads/encoder_decoder.py:461-483, 596-649).  Weights are plain
  * fp32 [N,K] device arrays (packed inside).  cat / table / the whole third stage (W3 = NULL) are optional; resid may alias x1_out (one workgroup per 32-row slab; a separate resid buffer
  * selects two workgroups per slab that deal the column passes of stage 2 out between them);
- * LayerNorm eps = 1e-5; act2: 0 none, 1 relu, 2 gelu(erf).  K1, Kcat, N2 multiples of 128. */
+ * LayerNorm eps = 1e-5; act2: 0 none, 1 relu, 2 gelu(erf).  K1, Kcat, N2 multiples of 128.  precision: EC_BF16X3, or EC_MIXED for the
+ * single-pass fp16 form the skeleton head / decoder layers use under head_precision = EC_MIXED. */
 int ec_op_chain(const float* X_dev, int K1, const float* W1_dev, const float* b1_dev, const float* resid_dev, const float* ln1_w_dev,
                 const float* ln1_b_dev, float* x1_out_dev, const float* cat_dev, int Kcat, const float* W2_dev, const float* b2_dev,
                 int N2, int act2, const float* table_dev, int period, float* out2_dev, const float* W3_dev, const float* b3_dev,
-                const float* ln3_w_dev, const float* ln3_b_dev, float* x3_out_dev, int rows, void* stream);
+                const float* ln3_w_dev, const float* ln3_b_dev, float* x3_out_dev, int rows, int precision, void* stream);
 /* softmax(q k^T * hd^-0.5 + bias, key mask) v ; q [B,Lq,H*hd], k,v [B,Lk,H*hd]; kmask [B,Lk] uint8 (1 = masked) or NULL;
  * bias [B,H,Lq,Lk] or NULL. */
 int ec_op_attention(const float* q_dev, const float* k_dev, const float* v_dev, const uint8_t* kmask_dev,

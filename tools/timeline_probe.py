@@ -12,7 +12,7 @@ from edgecape_amd.engine import HipEngine
 
 bs, S, H, arch = 32, int(os.environ.get("SHOTS", 1)), 256, "dinov2_vitb14"
 sd = synth.make_weights(arch, seed=0)
-eng = HipEngine(sd, arch=arch, image_size=H, max_batch=bs, max_shots=S, backbone_precision="bf16", head_precision="bf16x3")
+eng = HipEngine(sd, arch=arch, image_size=H, max_batch=bs, max_shots=S, backbone_precision=os.environ.get("BB", "fp16"), head_precision=os.environ.get("HEADP", "bf16x3"))
 b = synth.make_pairs(bs, S, H, seed=1000, fixed_n_kp=False)
 dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
 iq = dev(b["img_q"]); is_ = [dev(x) for x in b["img_s"]]; ts = [dev(x) for x in b["target_s"]]
