@@ -254,23 +254,36 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
     cur ^= 1;
     if (!active) continue;
     const bool edge = k0 + 64 > p.Lk;    // only the last tile needs the key-range mask
+    // ... and when at most 32 of its keys exist (T = 325: 5 of 64; T = 730: 26) its second 32-key half is skipped altogether
+    // (QK MFMAs, maximum, exponentials, PV MFMAs: half of that tile's work, 1/12 of the kernel at T = 325); wave-uniform
+    const bool half_tile = k0 + 32 >= p.Lk;
     f32x16 s[2];
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     {  // all eight K fragments first (one LDS latency instead of eight read -> wait -> MFMA round trips), then the two
        // accumulator chains interleaved so consecutive MFMAs never depend on each other
       bf16x8 ka[2][4];
+      if (!half_tile) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int row = t * 32 + j;
+        for (int t = 0; t < 2; ++t) {
+          const int row = t * 32 + j;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) ka[t][m] = *(const bf16x8*)(Kt + row * 128 + (((2 * m + hi) ^ ((row >> 1) & 7)) << 4));
+          for (int m = 0; m < 4; ++m) ka[t][m] = *(const bf16x8*)(Kt + row * 128 + (((2 * m + hi) ^ ((row >> 1) & 7)) << 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            s[t] = mfma32x32x16_h<F16>(ka[t][m], qf[m], m == 0 ? zero16 : s[t]);   // C = inline 0 first
+      } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) ka[0][m] = *(const bf16x8*)(Kt + j * 128 + (((2 * m + hi) ^ ((j >> 1) & 7)) << 4));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) s[0] = mfma32x32x16_h<F16>(ka[0][m], qf[m], m == 0 ? zero16 : s[0]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[1][r] = -INFINITY;   // (never read as scores: every use below is skipped too)
       }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-          s[t] = mfma32x32x16_h<F16>(ka[t][m], qf[m], m == 0 ? zero16 : s[t]);   // C = inline 0 first
     }
     if (edge) {   // last key tile only (a real branch: the empty asm keeps the compiler from if-converting it into 64 selects)
       asm volatile("" ::: "memory");
@@ -285,9 +298,11 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
     // raw-score maximum (the scale c > 0 is folded into the exponent below)
     float tmax = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
+      if (t == 1 && half_tile) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[t][r]);
+    }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * c;
     // LAZY running maximum: the reference point mrun only moves when some query's tile maximum exceeds it by more than 2^8
     // (softmax is invariant to the reference; exp2 arguments stay <= 8, so P <= 256 and the row sums stay far inside fp32 /
@@ -311,7 +326,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
     f32x2 psum2 = {0.f, 0.f};
     const f32x2 c2 = {c, c}, nm2 = {-mrun, -mrun};
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
+      if (t == 1 && half_tile) continue;
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const f32x2 x = __builtin_elementwise_fma(f32x2{s[t][r], s[t][r + 1]}, c2, nm2);
@@ -320,10 +336,12 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
         s[t][r + 1] = e[1];
         psum2 += e;
       }
+    }
     lrun += psum2[0] + psum2[1];
     A16_STAMP(5);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
+      if (t == 1 && half_tile) continue;
 #pragma unroll
       for (int uu = 0; uu < 2; ++uu) {
         f32x8 pv;
