@@ -1,5 +1,6 @@
 """-m gpu: each HIP kernel exported through the C ABI vs a plain PyTorch fp32 reference of the same op."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -207,7 +208,9 @@ def test_attention_bf16x3(lib, B, H, Lq, Lk, hd, masked, biased):
     assert err < 1e-4, err          # plain bf16 operands give ~1e-2 here
 
 
-@pytest.mark.parametrize("B,H,L", [(2, 6, 257), (2, 12, 325), (1, 16, 730), (1, 6, 64), (2, 6, 300), (2, 6, 96), (1, 6, 33), (1, 6, 161)])
+@pytest.mark.parametrize("B,H,L", [(2, 6, 257), (2, 12, 325), (1, 16, 730), (1, 6, 64), (2, 6, 300), (2, 6, 96), (1, 6, 33), (1, 6, 161),
+                                   (1, 6, 20), (1, 6, 32), (1, 6, 128), (1, 6, 129), (2, 6, 65), (1, 6, 193),
+                                   (40, 12, 325), (70, 12, 130), (150, 6, 64)])   # > 768 work items: several per persistent workgroup
 def test_attention_bf16(lib, B, H, L):
     """bf16 MFMA attention (backbone shape) vs fp64 math on the bf16-rounded operands."""
     hd = 64
@@ -225,6 +228,18 @@ def test_attention_bf16(lib, B, H, L):
     # P and O are rounded to bf16 (8 mantissa bits): |O| <~ 1 -> a few 1e-3 absolute
     assert err < 2e-2, err
     assert (od.cpu() - ref).abs().mean().item() < 2e-3
+
+
+def test_attention_pipelined_experiment():
+    """The software-pipelined persistent attention kernel (ec_attn.hip, EC_ATTN_PIPE=1; not the default) through the same cases:
+    the switch is read once per process, so the cases run in a child process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, EC_ATTN_PIPE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "test_attention_bf16 and not x3",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
 
 
 @pytest.mark.parametrize("M,N,K,prec", [(20800, 2304, 768, 1), (5000, 768, 3072, 1), (4100, 1152, 384, 1), (4500, 384, 384, 0),

@@ -15,5 +15,5 @@ k = torch.randn(B, L, H * hd, device="cuda")
 v = torch.randn(B, L, H * hd, device="cuda")
 o = torch.empty_like(q)
 for _ in range(int(os.environ.get("ITERS", 20))):
-    _lib.check(lib.ec_op_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), None, None, o.data_ptr(), B, H, L, L, hd, 1, None))
+    _lib.check(lib.ec_op_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), None, None, o.data_ptr(), B, H, L, L, hd, int(os.environ.get("PREC", 1)), None))
 torch.cuda.synchronize()
