@@ -14,7 +14,7 @@ constexpr int CH_LDS0 = 4096;      // first byte of the activation buffers (the 
 //      split hi/lo bf16 planes).  An operand buffer is filled either by an earlier stage (s_off) or, right before this stage, from
 //      global memory (g_in: fp32 [rows, g_k] -> buffer at g_off).
 //   epilogue: v = acc + bias[n] + table[row % period][n]; v = act(v); v += resid[row][n]; v += kept tile; v = LayerNorm(v)
-//      (N = 256 only); then any of: global fp32 store, split write into the LDS buffer at s_off, register copy (keep) for a later
+//      (N = 256 only); v += post_table[row % post_period][n]; then any of: global fp32 store, split write into the LDS buffer at s_off, register copy (keep) for a later
 //      stage's residual.
 struct ChainStage {
   const void* W = nullptr;       // pack_chain_weights image of W [N, K]
@@ -27,6 +27,7 @@ struct ChainStage {
   const float* resid = nullptr; long ldr = 0;
   int resid_keep = 0;
   const float* ln_w = nullptr; const float* ln_b = nullptr; float eps = 1e-5f;
+  const float* post_table = nullptr; long ldpt = 0; int post_period = 1;   // added AFTER the LayerNorm: v += post_table[row % post_period][n]
   float* out = nullptr; long ldo = 0;
   int s_off = -1;
   int keep = 0;

@@ -252,6 +252,8 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           const int r = mi * 16 + lrow;
+          if (S.post_table)   // (encoder: src = norm2(..) + pos is what the next layer's q, k AND v read, encoder_decoder.py:461-470)
+            acc[mi][j] += *(const f32x4*)(S.post_table + (long)(min(row0 + r, p.rows - 1) % S.post_period) * S.ldpt + n);
           if (store_out && row0 + r < p.rows) *(f32x4*)(S.out + (long)(row0 + r) * S.ldo + n) = acc[mi][j];
           if (S.s_off >= 0) {
             char* dst = smem + S.s_off + r * ((long)S.N * 4 + 16) + (n >> 5) * 128 + (n & 31) * 2;
@@ -385,6 +387,7 @@ int run_chain(const ChainP& p, hipStream_t st) {
     EC_REQUIRE(S.g_k == 0 || (S.g_in && S.g_k % 32 == 0 && S.g_off >= CH_RED && S.g_off + chain_layout_bytes(S.g_k) <= p.lds_bytes), -1, "chain: staged input out of range");
     EC_REQUIRE(S.s_off < 0 || (S.s_off >= CH_RED && S.s_off + chain_layout_bytes(S.N) <= p.lds_bytes), -1, "chain: output buffer out of range");
     EC_REQUIRE(!S.table || S.period > 0, -1, "chain: table period");
+    EC_REQUIRE(!S.post_table || S.post_period > 0, -1, "chain: post-table period");
     EC_REQUIRE((S.h1 != 0) == (p.h1 != 0), -1, "chain: stages packed for different arithmetic");
     EC_REQUIRE(p.split == 1 || !(S.s_off >= 0 || S.keep || S.ln_w) || !S.resid || !S.out || S.resid != S.out, -1,
                "chain: split chains need out != resid in the stages both workgroups compute");
