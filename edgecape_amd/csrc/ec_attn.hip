@@ -373,18 +373,27 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
   }
   lrun += __shfl_xor(lrun, 32, 64);
   const float inv = 1.f / lrun;
-  if (q0 + j < p.Lq) {
-    char* O = (char*)p.O + ((long)b * p.sO + (long)(q0 + j) * p.ldo + h * 64) * 2;
+  // Output: lane (query j, half hi) holds, per 8-column group g of a d-tile, the 4 columns 8 g + 4 hi .. + 3.  One v_permlane32_swap per
+  // packed dword between the groups of a pair gives the lower half-wave all 8 columns of the even group and the upper half-wave
+  // those of the odd group: FOUR 16-byte stores per lane instead of eight 8-byte ones (the store tail is issue-bound:
+  // MI355X_MICROARCH.md "attention epilogue store tail").  Every lane takes part in the swaps; only the store is predicated.
+  char* O = (char*)p.O + ((long)b * p.sO + (long)min(q0 + j, p.Lq - 1) * p.ldo + h * 64) * 2;
+  const bool q_ok = q0 + j < p.Lq;
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+  for (int d = 0; d < 2; ++d)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (short)f2h<F16>(ot[d][4 * g + e] * inv);
-        *(bf16x4*)(O + (d * 32 + 8 * g + 4 * hi) * 2) = o;
-      }
-  }
+    for (int gp = 0; gp < 2; ++gp) {
+      u32x2_t a, c;   // packed columns of group 2 gp (a) and 2 gp + 1 (c)
+      a = pack4_h<F16>(f32x4{ot[d][8 * gp] * inv, ot[d][8 * gp + 1] * inv, ot[d][8 * gp + 2] * inv, ot[d][8 * gp + 3] * inv});
+      c = pack4_h<F16>(f32x4{ot[d][8 * gp + 4] * inv, ot[d][8 * gp + 5] * inv, ot[d][8 * gp + 6] * inv, ot[d][8 * gp + 7] * inv});
+      // swap(vdst = a, src = c): a's upper half-wave <-> c's lower half-wave  =>  lower lanes: (a, c) = own | partner columns of the
+      // even group; upper lanes: (a, c) = partner | own columns of the odd group
+      const u32x2_t s0 = __builtin_amdgcn_permlane32_swap(a[0], c[0], false, false);
+      const u32x2_t s1 = __builtin_amdgcn_permlane32_swap(a[1], c[1], false, false);
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+      const u32x4_ o = {s0[0], s1[0], s0[1], s1[1]};
+      if (q_ok) *(u32x4_*)(O + (d * 32 + 16 * gp + 8 * hi) * 2) = o;
+    }
 }
 
 
