@@ -6,7 +6,7 @@
 namespace ec {
 
 constexpr int CH_BM = 32;          // rows per workgroup
-constexpr int CH_MAX_STAGES = 4;
+constexpr int CH_MAX_STAGES = 5;
 constexpr int CH_LDS0 = 4096;      // first byte of the activation buffers (the LayerNorm scratch sits in front)
 
 // One stage: Y[32, N] = epilogue(X[32, K] @ W[N, K]^T).
@@ -28,6 +28,12 @@ struct ChainStage {
   int resid_keep = 0;
   const float* ln_w = nullptr; const float* ln_b = nullptr; float eps = 1e-5f;
   const float* post_table = nullptr; long ldpt = 0; int post_period = 1;   // added AFTER the LayerNorm: v += post_table[row % post_period][n]
+  // Keypoint-branch tail + reference-point embedding (decoder helper chain; encoder_decoder.py:395-402, 363-371; N = 256, no LayerNorm):
+  // with t this stage's output,  b_next[row] = sigmoid(inverse_sigmoid(kp_prev[row]) + t . kp_w[2, 256]^T + kp_b[2])  is stored to
+  // kp_next [rows, 2], and with kp_dim_t the sine embedding of b_next ([32, 256]: 128 features of y, then 128 of x) goes to the LDS
+  // buffer at s_off INSTEAD of t - the next stage is ref_point_head.
+  const float* kp_w = nullptr; const float* kp_b = nullptr; const float* kp_prev = nullptr; float* kp_next = nullptr;
+  const float* kp_dim_t = nullptr;
   float* out = nullptr; long ldo = 0;
   int s_off = -1;
   int keep = 0;

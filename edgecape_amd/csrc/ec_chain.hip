@@ -93,7 +93,7 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
     const int nb = nkb >> 2;
     const int npass_all = wave * 2 < nfr ? (nfr - wave * 2 + 15) >> 4 : 0;   // passes in which this wave has fragments
     // two workgroups per slab (p.split = 2): a stage that later stages read is computed by both, any other is dealt out by passes
-    const bool shared = S.s_off >= 0 || S.keep || ln;
+    const bool shared = S.s_off >= 0 || S.keep || ln || S.kp_w;
     const int pstep = shared ? 1 : p.split, p0 = shared ? 0 : part;
     const int npass = npass_all > p0 ? (npass_all - p0 + pstep - 1) / pstep : 0;
     const bool store_out = S.out != nullptr && (!shared || part == 0);
@@ -245,6 +245,66 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
           for (int mi = 0; mi < 2; ++mi) acc[mi][j] = (acc[mi][j] - mean[mi]) * rstd[mi] * lg[j] + lb[j];
         }
       }
+      const bool kp_sine = S.kp_w && S.kp_dim_t;
+      if (S.kp_w) {
+        // keypoint-branch tail (see ChainStage): two dot products per row over the 256 columns - 4 columns x 2 fragments per lane, the
+        // 4 lanes of a row by shuffles, the 8 waves through LDS - then the reference-point update by one thread per (row, coordinate)
+        float d0[2] = {0.f, 0.f}, d1[2] = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = (f0 + j) * 16 + lq * 4;
+          const f32x4 w0 = *(const f32x4*)(S.kp_w + n), w1 = *(const f32x4*)(S.kp_w + 256 + n);
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              d0[mi] = fmaf(acc[mi][j][e], w0[e], d0[mi]);
+              d1[mi] = fmaf(acc[mi][j][e], w1[e], d1[mi]);
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          d0[mi] += __shfl_xor(d0[mi], 16, 64); d0[mi] += __shfl_xor(d0[mi], 32, 64);
+          d1[mi] += __shfl_xor(d1[mi], 16, 64); d1[mi] += __shfl_xor(d1[mi], 32, 64);
+          if (lq == 0) {
+            red[(mi * 16 + lrow) * 8 + wave] = d0[mi];
+            red[256 + (mi * 16 + lrow) * 8 + wave] = d1[mi];
+          }
+        }
+        __syncthreads();
+        float* const coord = red + 512;   // [32 rows][2]: (x, y) of b_next, read by the sine embedding below
+        if (tid < 64) {
+          const int r = tid >> 1, c = tid & 1;
+          const float* q = red + c * 256 + r * 8;
+          const float dl = (((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]))) + S.kp_b[c];
+          const int gr = min(row0 + r, p.rows - 1);
+          float x = S.kp_prev[(long)gr * 2 + c];   // inverse_sigmoid, eps 1e-3 (head.py:27-31)
+          x = fminf(fmaxf(x, 0.f), 1.f);
+          const float z = dl + logf(fmaxf(x, 1e-3f) / fmaxf(1.f - x, 1e-3f));
+          const float bn = 1.f / (1.f + expf(-z));
+          coord[r * 2 + c] = bn;
+          if (row0 + r < p.rows && part == 0) S.kp_next[(long)(row0 + r) * 2 + c] = bn;
+        }
+        __syncthreads();
+        if (kp_sine) {   // sine embedding of b_next -> the operand buffer of the next stage (positional_encoding.py; sincos_kernel)
+          for (int qd = tid; qd < CH_BM * 64; qd += 512) {
+            const int r = qd >> 6, c = (qd & 63) << 2;           // 4 consecutive features of row r
+            const int isx = c >= 128, i0 = c & 127;
+            const float e = coord[r * 2 + (isx ? 0 : 1)] * 6.283185307179586f;
+            const f32x4 dt = *(const f32x4*)(S.kp_dim_t + i0);
+            const f32x4 v = {sinf(e / dt[0]), cosf(e / dt[1]), sinf(e / dt[2]), cosf(e / dt[3])};   // even feature: sin, odd: cos
+            char* dst = smem + S.s_off + r * (256l * 4 + 16) + (c >> 5) * 128 + (c & 31) * 2;
+            if (h1) {
+              *(u32x2*)dst = half4(v);
+            } else {
+              u32x2 hi, lo;
+              split4(v, hi, lo);
+              *(u32x2*)dst = hi;
+              *(u32x2*)(dst + 64) = lo;
+            }
+          }
+        }
+      }
       // part 2: global store, split write-back for the next stage, register copy for a later residual
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -255,7 +315,7 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
           if (S.post_table)   // (encoder: src = norm2(..) + pos is what the next layer's q, k AND v read, encoder_decoder.py:461-470)
             acc[mi][j] += *(const f32x4*)(S.post_table + (long)(min(row0 + r, p.rows - 1) % S.post_period) * S.ldpt + n);
           if (store_out && row0 + r < p.rows) *(f32x4*)(S.out + (long)(row0 + r) * S.ldo + n) = acc[mi][j];
-          if (S.s_off >= 0) {
+          if (S.s_off >= 0 && !kp_sine) {
             char* dst = smem + S.s_off + r * ((long)S.N * 4 + 16) + (n >> 5) * 128 + (n & 31) * 2;
             if (h1) {
               *(u32x2*)dst = half4(acc[mi][j]);
@@ -388,6 +448,7 @@ int run_chain(const ChainP& p, hipStream_t st) {
     EC_REQUIRE(S.s_off < 0 || (S.s_off >= CH_RED && S.s_off + chain_layout_bytes(S.N) <= p.lds_bytes), -1, "chain: output buffer out of range");
     EC_REQUIRE(!S.table || S.period > 0, -1, "chain: table period");
     EC_REQUIRE(!S.post_table || S.post_period > 0, -1, "chain: post-table period");
+    EC_REQUIRE(!S.kp_w || (S.N == 256 && !S.ln_w && S.kp_b && S.kp_prev && S.kp_next && (!S.kp_dim_t || S.s_off >= 0)), -1, "chain: keypoint tail needs N = 256, no LayerNorm");
     EC_REQUIRE((S.h1 != 0) == (p.h1 != 0), -1, "chain: stages packed for different arithmetic");
     EC_REQUIRE(p.split == 1 || !(S.s_off >= 0 || S.keep || S.ln_w) || !S.resid || !S.out || S.resid != S.out, -1,
                "chain: split chains need out != resid in the stages both workgroups compute");

@@ -1089,17 +1089,50 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     float* bnext = pts + (long)(li + 1) * Mk * 2;
     const bool last_split = ovd && li + 1 == nL;   // after the last layer nothing is left to hide under: the two keypoint
                                                   // branches (on x and on dec_norm(x)) run side by side on st and ax
-    RUN(ln(dx, dx_ld, hs, d, false, m->dec_norm, Mk, d, 1e-5f, last_split ? st : ax));
-    // b_{l+1} = sigmoid(inverse_sigmoid(b_l) + kpt_branch[l](x))   (un-normed x, :395-402)
     const KptBranch& kb = m->kpt[li];
-    RUN(linear(dx, dx_ld, false, kb.l0, m->d_k1, d, false, Mk, ACT_GELU, ax));
-    RUN(mark(ev_x));                       // x_{l+1} has been read: layer l+1 may overwrite it
-    RUN(linear(m->d_k1, d, false, kb.l2, m->d_k2, d, false, Mk, ACT_GELU, ax));
-    RUN(linear(m->d_k2, d, false, kb.l4, m->d_k1, d, false, Mk, ACT_GELU, ax));
-    RUN(kpt_out(m->d_k1, d, kb.w6, kb.b6, bi, bnext, Mk, d, ax));
-    if (li + 1 < nL) {
-      RUN(ref_point_embed(bnext));
+    // b_{l+1} = sigmoid(inverse_sigmoid(b_l) + kpt_branch[l](x))   (un-normed x, :395-402), then qpe_{l+1} = ref_point_head(sine(b_{l+1})).
+    // Layer l+1 waits for qpe_{l+1} right after its self-attention kernel (~25 us), so these seven dependent launches (~70 us) were on
+    // the decoder's critical path: as ONE row chain (three GELU stages, the keypoint tail + sine embedding inside the kernel, two
+    // ref_point_head stages) the helper lane is back under the attention.  EC_KPT_CHAIN=0 restores the separate launches.
+    static const bool kpt_chain_off = getenv("EC_KPT_CHAIN") && atoi(getenv("EC_KPT_CHAIN")) == 0;
+    const bool kpt_chain = !kpt_chain_off && li + 1 < nL && m->head_chain && chain_ok(kb.l0) && chain_ok(kb.l2) && chain_ok(kb.l4) &&
+                           chain_ok(m->rp0) && chain_ok(m->rp1) && kb.l0.K == d && kb.l0.N == d && kb.l2.K == d && kb.l2.N == d &&
+                           kb.l4.K == d && kb.l4.N == d && m->rp0.K == d && m->rp0.N == d && m->rp1.K == d && d == 256 &&
+                           kb.l0.h1 == m->rp0.h1 && kb.l0.h1 == m->rp1.h1 && kb.l0.h1 == kb.l2.h1 && kb.l0.h1 == kb.l4.h1;
+    if (kpt_chain) {
+      ChainBuild cb;
+      const int b0 = cb.buf(d), b1 = cb.buf(d);
+      ChainStage& S1 = cb.add();
+      chain_lin(S1, kb.l0);
+      S1.g_in = dx; S1.ld_in = dx_ld; S1.g_k = d; S1.g_off = b0; S1.a_off = b0; S1.act = ACT_GELU; S1.s_off = b1;
+      ChainStage& S2 = cb.add();
+      chain_lin(S2, kb.l2);
+      S2.a_off = b1; S2.act = ACT_GELU; S2.s_off = b0;
+      ChainStage& S3 = cb.add();
+      chain_lin(S3, kb.l4);
+      S3.a_off = b0; S3.act = ACT_GELU; S3.s_off = b1;
+      S3.kp_w = kb.w6; S3.kp_b = kb.b6; S3.kp_prev = bi; S3.kp_next = bnext; S3.kp_dim_t = m->dim_t;
+      ChainStage& S4 = cb.add();
+      chain_lin(S4, m->rp0);
+      S4.a_off = b1; S4.act = ACT_GELU; S4.s_off = b0;
+      ChainStage& S5 = cb.add();
+      chain_lin(S5, m->rp1);
+      S5.a_off = b0; S5.out = m->d_qin + d; S5.ldo = 2 * d;
+      RUN(cb.run(Mk, ax));
       RUN(mark(ev_qpe));
+      RUN(ln(dx, dx_ld, hs, d, false, m->dec_norm, Mk, d, 1e-5f, ax));
+      RUN(mark(ev_x));                     // x_{l+1} has been read (chain and dec_norm): layer l+1 may overwrite it
+    } else {
+      RUN(ln(dx, dx_ld, hs, d, false, m->dec_norm, Mk, d, 1e-5f, last_split ? st : ax));
+      RUN(linear(dx, dx_ld, false, kb.l0, m->d_k1, d, false, Mk, ACT_GELU, ax));
+      RUN(mark(ev_x));                       // x_{l+1} has been read: layer l+1 may overwrite it
+      RUN(linear(m->d_k1, d, false, kb.l2, m->d_k2, d, false, Mk, ACT_GELU, ax));
+      RUN(linear(m->d_k2, d, false, kb.l4, m->d_k1, d, false, Mk, ACT_GELU, ax));
+      RUN(kpt_out(m->d_k1, d, kb.w6, kb.b6, bi, bnext, Mk, d, ax));
+      if (li + 1 < nL) {
+        RUN(ref_point_embed(bnext));
+        RUN(mark(ev_qpe));
+      }
     }
     // (7) head output of this level (head.py:216-220): kpt_branch[l](hs[l]) on top of out_points[l] = b_l
     if (last_split) RUN(kpt_mlp(m, kb, hs, d, Mk, bi, out->output_kpts_dev + (long)li * Mk * 2, st, m->d_k3, m->d_k4));
