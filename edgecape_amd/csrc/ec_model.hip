@@ -716,6 +716,24 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
 static int kpt_mlp(ec_model* m, const KptBranch& kb, const float* x, long ldx, int rows, const float* prev, float* out,
                    hipStream_t st, float* t1 = nullptr, float* t2 = nullptr) {
   const int d = m->d;
+  static const bool kpt_chain_off = getenv("EC_KPT_CHAIN") && atoi(getenv("EC_KPT_CHAIN")) == 0;
+  if (!kpt_chain_off && m->head_chain && chain_ok(kb.l0) && chain_ok(kb.l2) && chain_ok(kb.l4) && d == 256 && kb.l0.K == d &&
+      kb.l0.N == d && kb.l2.K == d && kb.l2.N == d && kb.l4.K == d && kb.l4.N == d && kb.l0.h1 == kb.l2.h1 && kb.l0.h1 == kb.l4.h1) {
+    // the three GELU Linear layers and the keypoint tail (kpt_out) as ONE row chain (see the decoder's helper lane)
+    ChainBuild cb;
+    const int b0 = cb.buf(d), b1 = cb.buf(d);
+    ChainStage& S1 = cb.add();
+    chain_lin(S1, kb.l0);
+    S1.g_in = x; S1.ld_in = ldx; S1.g_k = d; S1.g_off = b0; S1.a_off = b0; S1.act = ACT_GELU; S1.s_off = b1;
+    ChainStage& S2 = cb.add();
+    chain_lin(S2, kb.l2);
+    S2.a_off = b1; S2.act = ACT_GELU; S2.s_off = b0;
+    ChainStage& S3 = cb.add();
+    chain_lin(S3, kb.l4);
+    S3.a_off = b0; S3.act = ACT_GELU;
+    S3.kp_w = kb.w6; S3.kp_b = kb.b6; S3.kp_prev = prev; S3.kp_next = out;
+    return cb.run(rows, st);
+  }
   if (!t1) { t1 = m->d_k1; t2 = m->d_k2; }   // scratch pair; a second pair lets two branches run on two streams
   RUN(linear(x, ldx, false, kb.l0, t1, d, false, rows, ACT_GELU, st));
   RUN(linear(t1, d, false, kb.l2, t2, d, false, rows, ACT_GELU, st));
@@ -1122,6 +1140,11 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
       RUN(mark(ev_qpe));
       RUN(ln(dx, dx_ld, hs, d, false, m->dec_norm, Mk, d, 1e-5f, ax));
       RUN(mark(ev_x));                     // x_{l+1} has been read (chain and dec_norm): layer l+1 may overwrite it
+    } else if (!kpt_chain_off && li + 1 == nL) {
+      // last layer: b_L = update(b_{L-1}, kpt_branch(x)) on the helper lane, dec_norm + kpt_branch(hs) beside it (one row chain each)
+      RUN(ln(dx, dx_ld, hs, d, false, m->dec_norm, Mk, d, 1e-5f, last_split ? st : ax));
+      RUN(kpt_mlp(m, kb, dx, dx_ld, Mk, bi, bnext, ax));
+      RUN(mark(ev_x));
     } else {
       RUN(ln(dx, dx_ld, hs, d, false, m->dec_norm, Mk, d, 1e-5f, last_split ? st : ax));
       RUN(linear(dx, dx_ld, false, kb.l0, m->d_k1, d, false, Mk, ACT_GELU, ax));
