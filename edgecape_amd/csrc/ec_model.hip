@@ -92,7 +92,7 @@ struct ec_model {
   // state of each layer and only rejoin it at the next layer's cross-attention: they run on a second helper stream
   hipStream_t aux = nullptr, side2 = nullptr;   // side2: image lane of the skeleton head (run_head_support)
   hipEvent_t ev_aux[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_sup[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_sup[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool overlap_dec = false;
   // EC_TIMELINE=1: timed HIP events at the head's milestones on every stream, printed (us from the head's start) after a
   // device sync at the end of the call - the unprofiled picture of which lane is critical (rocprofv3 makes the head host-bound)
@@ -771,13 +771,19 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
   // image lane of the skeleton head (see (3)): forked first so image_project overlaps the pooling chain
   const bool ov2 = m->overlap_dec && m->side2 != nullptr;
   hipStream_t s2 = ov2 ? m->side2 : st;
-  hipEvent_t const ev_x = m->ev_sup[0], ev_xr = m->ev_sup[1], ev_kv = m->ev_sup[2], ev_f = m->ev_sup[3];
+  hipEvent_t const ev_x = m->ev_sup[0], ev_xr = m->ev_sup[1], ev_kv = m->ev_sup[2], ev_f = m->ev_sup[3], ev_adjb = m->ev_sup[4];
   if (ov2) {
     EC_HIP(hipEventRecord(ev_f, st));
     EC_HIP(hipStreamWaitEvent(s2, ev_f, 0));
   }
   const int nb = S * bs;
   const int nsk = (int)m->skel.size();
+  // adjacency from the skeleton edges + key masks (skeleton.py:58-75): needs only the edges and the keypoint mask, so with the helper
+  // lane it runs there FIRST, beside the pooling chain, instead of between query_proj and the first layer on the critical lane
+  if (ov2) {
+    RUN(adj_build(m->d_edges, m->d_off, mask_s, ss.valid, ss.kmask, ss.kmask_fixed, m->binary, m->adj_r1, bs, K, s2));
+    EC_HIP(hipEventRecord(ev_adjb, s2));
+  }
   for (int s = 0; s < S; ++s)
     RUN(linear(fs[s], C, false, m->image_project, m->s_mem + (long)s * Mi * d, d, false, Mi, ACT_NONE, s2));
   if (nsk > 0) {
@@ -812,7 +818,8 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
   // and image-query projections, and the image->token update of the previous layer - runs on the helper stream s2, so layer
   // i+1's self-attention block overlaps layer i's image update.  Hand-offs: ev_x (x_{i+1} final -> image update may read it),
   // ev_xr (image update has read x -> LN1 of layer i+1 may overwrite it), ev_kv (K|V of layer i ready -> cross attention).
-  RUN(adj_build(m->d_edges, m->d_off, mask_s, ss.valid, ss.kmask, ss.kmask_fixed, m->binary, m->adj_r1, bs, K, st));
+  if (ov2) EC_HIP(hipStreamWaitEvent(st, ev_adjb, 0));
+  else RUN(adj_build(m->d_edges, m->d_off, mask_s, ss.valid, ss.kmask, ss.kmask_fixed, m->binary, m->adj_r1, bs, K, st));
   if (ev_sk) EC_HIP(hipEventRecord(ev_sk, st));   // support tokens + key masks are ready: the encoder may start
   for (int s = 0; s < S; ++s) RUN(copy2d(m->s_x + (long)s * Mk * d, d, ss.sk, d, Mk, d, st));
   float* sx = m->s_x;                         // token state: ping-pongs with s_tmp under two-workgroup row chains (LayerIO::x_alt)
