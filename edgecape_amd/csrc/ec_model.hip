@@ -618,6 +618,8 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
   }
   if (chain) {
     // x = norm1(x + out_proj(att)); qc = q_proj([x | qpe]) - one launch (encoder_decoder.py:596-611)
+    // (with the ping-pong token state the layer's input buffer is first overwritten by the SECOND chain; waiting for the helper lane only
+    //  there was measured: no gain - 6.82-6.84 vs 6.81-6.84 ms, decoder layers 212-231 vs 201-222 us - so the wait stays here)
     if (io.wait_x) EC_HIP(hipStreamWaitEvent(st, io.wait_x, 0));
     for (hipEvent_t e : io.wait_ca)
       if (e) EC_HIP(hipStreamWaitEvent(st, e, 0));
