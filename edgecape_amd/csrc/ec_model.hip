@@ -865,16 +865,15 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
     kp_ref = m->kp_ref;
   }
   m->taps["skel_kp_refined"] = {kp_ref, (long)Mk * d};
-  RUN(rownorm(kp_ref, m->kn, Mk, d, st));
-  {
+  {  // Gram matrix of the refined tokens; adj_combine forms the cosine similarity from its diagonal (no row-normalisation launch)
     BgemmP p;
-    p.A = m->kn; p.lda = d; p.sA = (long)K * d;
-    p.B = m->kn; p.ldb = d; p.sB = (long)K * d; p.transB = 1;
+    p.A = kp_ref; p.lda = d; p.sA = (long)K * d;
+    p.B = kp_ref; p.ldb = d; p.sB = (long)K * d; p.transB = 1;
     p.C = m->P; p.ldc = K; p.sC = (long)K * K;
     p.M = K; p.N = K; p.K = d; p.batch = bs;
     RUN(bgemm_small(p, st));
   }
-  RUN(adj_combine(m->P, m->binary, ss.valid, m->zc_w, m->zc_b, adj_out, ss.adj1, attn_adj, bs, K, st));
+  RUN(adj_combine(m->P, m->binary, ss.valid, m->zc_w, m->zc_b, adj_out, ss.adj1, attn_adj, bs, K, st, 1));
   {  // Markov powers: A^2 = A A, A^3 = A^2 A, A^4 = A^2 A^2 (torch.matrix_power's association)
     const long KK = (long)K * K, hop = (long)bs * KK;
     auto mm = [&](const float* a, const float* b, float* c) {

@@ -68,7 +68,7 @@ int adj_build(const int32_t* edges, const int32_t* offsets, const float* mask_s,
 int rownorm(const float* x, float* y, int rows, int cols, hipStream_t st);
 // skeleton.py:134-161 — combine cosine similarity with the prior, soft-normalise, Markov matrix
 int adj_combine(const float* P, const float* binary, const float* valid, const float* zc_w, const float* zc_b,
-                float* adj_out, float* adj1, float* attn_adj, int bs, int K, hipStream_t st);
+                float* adj_out, float* adj1, float* attn_adj, int bs, int K, hipStream_t st, int gram = 0);
 int set_identity(float* dst, int bs, int K, hipStream_t st);
 // bias_attn.py:188-191 — MLP(hops+1 -> hops+nhead -> nhead) over the Markov stack
 int bias_mlp_layers(const float* attn_adj, const float* const* w1, const float* const* b1, const float* const* w2, const float* const* b2,

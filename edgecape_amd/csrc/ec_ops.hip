@@ -421,9 +421,12 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* x, float* y, 
 }
 
 // predict_skeleton tail + markov normalisation (skeleton.py:139-150,158): one wave per adjacency row, grid (bs, ceil(K/4))
+// gram = 1: P holds the UN-normalised Gram matrix X X^T of the refined keypoint tokens; the cosine similarity of skeleton.py:137-139
+// (x / (|x| + 1e-8) on both sides) is formed here from its diagonal, |x_i| = sqrt(G_ii) - the separate row-normalisation launch on
+// the support lane's critical path is gone.
 __global__ __launch_bounds__(256) void adj_combine_kernel(const float* P, const float* binary, const float* valid,
                                                           const float* zc_w, const float* zc_b, float* adj_out, float* adj1,
-                                                          float* attn_adj, int bs, int K) {
+                                                          float* attn_adj, int bs, int K, int gram) {
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float w = zc_w[0], c0 = zc_b[0];
   const float* Pb = P + (long)b * K * K;
@@ -435,13 +438,15 @@ __global__ __launch_bounds__(256) void adj_combine_kernel(const float* P, const 
   float* A1 = adj1 + (long)b * K * K;
   for (int i = blockIdx.y * 4 + wave; i < K; i += 4 * gridDim.y) {
     const float vi = valid[b * K + i];
+    const float ni = gram ? 1.f / (sqrtf(Pb[i * K + i]) + 1e-8f) : 1.f;
     float u[2], rs = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int j = lane + t * 64;
       u[t] = 0.f;
       if (j < K) {
-        const float sym = (Pb[i * K + j] + Pb[j * K + i]) / 2.f;
+        const float nj = gram ? 1.f / (sqrtf(Pb[j * K + j]) + 1e-8f) : 1.f;
+        const float sym = (Pb[i * K + j] * ni * nj + Pb[j * K + i] * nj * ni) / 2.f;
         float v = Bb[i * K + j] + (sym * w + c0);
         v = fmaxf(v, 0.f);
         u[t] = v * (vi * valid[b * K + j]);
@@ -858,9 +863,9 @@ int rownorm(const float* x, float* y, int rows, int cols, hipStream_t st) {
 }
 
 int adj_combine(const float* P, const float* binary, const float* valid, const float* zc_w, const float* zc_b, float* adj_out,
-                float* adj1, float* attn_adj, int bs, int K, hipStream_t st) {
+                float* adj1, float* attn_adj, int bs, int K, hipStream_t st, int gram) {
   EC_REQUIRE(K <= 128, -1, "adj_combine: K must be <= 128");
-  hipLaunchKernelGGL(adj_combine_kernel, dim3(bs, (K + 3) / 4), dim3(256), 0, st, P, binary, valid, zc_w, zc_b, adj_out, adj1, attn_adj, bs, K);
+  hipLaunchKernelGGL(adj_combine_kernel, dim3(bs, (K + 3) / 4), dim3(256), 0, st, P, binary, valid, zc_w, zc_b, adj_out, adj1, attn_adj, bs, K, gram);
   EC_LAUNCH_CHECK();
   return 0;
 }
