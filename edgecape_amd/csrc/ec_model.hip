@@ -43,6 +43,8 @@ struct Lin {  // a Linear layer view: W [N,K] (+ optional bf16 copy), bias [N]
   const bf16_t* w16 = nullptr;
   const float* ws = nullptr;   // bf16x3 split-packed copy (head_precision = EC_BF16X3), same byte size as w
   const void* wc = nullptr;    // ... and its fragment-major packing for the row-chain kernel (ec_chain.hip), head only
+  const bf16_t* wf16 = nullptr;  // plain IEEE fp16 [N, K] copy (single-pass fp16 layers of the head's mixed precision): the 8-phase 16-bit
+                               // GEMM runs the large image-row projections of the skeleton head on it when a 16-bit copy of A exists
   const float* b = nullptr;
   int N = 0, K = 0;
   bool w16_is_f16 = false;     // w16 holds IEEE fp16 (EC_F16 backbone) instead of bf16
@@ -132,6 +134,7 @@ struct ec_model {
   float *Wp, *pooled, *sk, *valid, *binary, *adj_r1, *adj1, *P, *kn, *kp_ref, *attn_adj;
   uint8_t *kmask, *kmask_fixed;
   float *s_mem, *s_x, *s_tmp, *s_qkv, *s_att, *s_qc, *s_kv, *s_y, *s_z, *s_qimg, *s_kvk, *s_attimg, *s_tmpimg;
+  bf16_t* s_mem16 = nullptr;   // fp16 copy of the skeleton head's image memory, written by norm4 (head mixed precision)
   float *e_x, *e_qkv, *e_att, *e_tmp, *e_h;
   float *p_fs, *p_fq, *p_g1, *p_fs2, *prop;
   float *d_qin, *d_sc, *d_rp, *d_bias, *d_bias_all, *d_qkv, *d_att, *d_tmp, *d_qc, *d_kv, *d_y, *d_z, *d_hs, *d_pts, *d_k1, *d_k2, *d_k3, *d_k4, *d_hn;
@@ -249,6 +252,14 @@ static int make_lin_host(ec_model* m, const std::vector<float>& W, const std::ve
   if (m->head_split && (rc = upload_split(m, W.data(), N, K, &out->ws))) return rc;   // make_lin_host is only used by the head
   if (m->head_chain && (rc = upload_chain(m, W.data(), N, K, &out->wc))) return rc;
   out->h1 = m->head_split && m->cur_h1;
+  if (out->h1 && N >= 256 && K % 128 == 0) {   // (shapes the 8-phase kernel takes)
+    std::vector<bf16_t> t(W.size());
+    for (size_t i = 0; i < W.size(); ++i) t[i] = f2half_host(W[i]);
+    bf16_t* p16 = nullptr;
+    if ((rc = dalloc(m, &p16, t.size()))) return rc;
+    EC_HIP(hipMemcpy(p16, t.data(), t.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+    out->wf16 = p16;
+  }
   if (!b.empty()) rc = upload(m, b, &out->b);
   return rc;
 }
@@ -520,8 +531,22 @@ struct LayerIO {
 
 // K|V of the image tokens for a layer's token->image cross attention, one batch entry per sample (mem may be a strided view):
 // kv[nb, HW, 2E], the positional half of K folded into the epilogue table (encoder_decoder.py:604-617).
-static int project_image_kv(ec_model* m, const DecLayer& L, const float* mem, long s_mem, int nb, float* kv, hipStream_t st) {
+static int project_image_kv(ec_model* m, const DecLayer& L, const float* mem, long s_mem, int nb, float* kv, hipStream_t st,
+                            const bf16_t* mem16 = nullptr) {
   const int d = m->d, E = m->E, HW = m->HW;
+  static const bool kv16_off = getenv("EC_KV16") && atoi(getenv("EC_KV16")) == 0;   // A/B switch
+  if (mem16 && !kv16_off && L.ca_kv.wf16 && L.ca_kv.h1 && s_mem == (long)HW * d && (long)nb * HW >= 1024) {
+    // single-pass fp16 layer, contiguous image rows and an fp16 copy of them at hand (norm4 wrote it): one [nb * HW, 2E] problem on the
+    // backbone's 8-phase 16-bit GEMM (fp32 output + positional table) - the same products and fp32 accumulation as the fp16x1 path of
+    // gemm_nt, which rounds A to fp16 in registers
+    GemmP q;
+    q.A = mem16; q.lda = d; q.ab_bf16 = 1; q.h_f16 = 1;
+    q.B = L.ca_kv.wf16; q.ldb = d;
+    q.C = kv; q.ldc = 2 * E;
+    q.table = L.ca_kv_table; q.ldt = 2 * E; q.period = HW;
+    q.M = nb * HW; q.N = 2 * E; q.K = d;
+    return gemm_nt(q, st);
+  }
   GemmP p;
   p.A = mem; p.lda = d; p.sA = s_mem;
   p.split = L.ca_kv.ws ? (L.ca_kv.h1 ? 2 : 1) : 0; p.B = L.ca_kv.wsel(p.split); p.ldb = d;
@@ -533,11 +558,22 @@ static int project_image_kv(ec_model* m, const DecLayer& L, const float* mem, lo
 
 // image -> token attention of a two-way layer, NO masks (encoder_decoder.py:638-649), in two pieces: the query projection only
 // needs the image memory; the rest needs the layer's final token state x.  `x_read` (optional) is recorded once x has been read.
-static int image_update_q(ec_model* m, const DecLayer& L, const float* mem, int nb, float* qimg, hipStream_t st) {
+static int image_update_q(ec_model* m, const DecLayer& L, const float* mem, int nb, float* qimg, hipStream_t st,
+                          const bf16_t* mem16 = nullptr) {
+  static const bool kv16_off = getenv("EC_KV16") && atoi(getenv("EC_KV16")) == 0;
+  if (mem16 && !kv16_off && L.i2t_q.wf16 && L.i2t_q.h1 && (long)nb * m->HW >= 1024) {   // (see project_image_kv)
+    GemmP q;
+    q.A = mem16; q.lda = m->d; q.ab_bf16 = 1; q.h_f16 = 1;
+    q.B = L.i2t_q.wf16; q.ldb = m->d; q.bias = L.i2t_q.b;
+    q.C = qimg; q.ldc = m->E;
+    q.table = L.i2t_q_table; q.ldt = m->E; q.period = m->HW;
+    q.M = nb * m->HW; q.N = m->E; q.K = m->d;
+    return gemm_nt(q, st);
+  }
   return linear(mem, m->d, false, L.i2t_q, qimg, m->E, false, nb * m->HW, ACT_NONE, st, nullptr, nullptr, 0, L.i2t_q_table, m->E, m->HW);
 }
 static int image_update(ec_model* m, const DecLayer& L, const float* x, long ldx, float* mem, int nb, const float* qimg, float* kvk,
-                        float* attimg, float* tmpimg, hipStream_t st, hipEvent_t x_read, bool kvk_ready = false) {
+                        float* attimg, float* tmpimg, hipStream_t st, hipEvent_t x_read, bool kvk_ready = false, bf16_t* mem16 = nullptr) {
   const int d = m->d, E = m->E, K = m->K, HW = m->HW, nh = m->cfg.nhead;
   const int Mi = nb * HW, Mk = nb * K;
   if (!kvk_ready) RUN(linear(x, ldx, false, L.i2t_kv, kvk, 2 * E, false, Mk, ACT_NONE, st));   // (else: the layer's last chain wrote it)
@@ -550,7 +586,10 @@ static int image_update(ec_model* m, const DecLayer& L, const float* x, long ldx
   a.split = m->head_split ? 1 : 0;   // head throughput mode: bf16x3 MFMAs
   RUN(attention(a, st));
   RUN(linear(attimg, E, false, L.i2t_fold, tmpimg, d, false, Mi, ACT_NONE, st, nullptr, mem, d));
-  return ln(tmpimg, d, mem, d, false, L.n4, Mi, d, 1e-5f, st);
+  LnP q;
+  q.x = tmpimg; q.ldx = d; q.y = mem; q.ldy = d; q.y_bf16 = 0; q.w = L.n4.w; q.b = L.n4.b; q.rows = Mi; q.cols = d; q.eps = 1e-5f;
+  if (mem16) { q.y2 = mem16; q.ldy2 = d; }   // fp16 copy for the next layer's K|V / image-query projections
+  return layernorm(q, st);
 }
 
 // ---- row chains of a decoder / two-way layer (ec_chain.hip).  LDS operand buffers are laid out by a bump allocator.
@@ -852,11 +891,11 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
         EC_HIP(hipStreamWaitEvent(s2, ev_x, 0));
       }
       RUN(image_update(m, m->skel[i], sx, d, m->s_mem, nb, m->s_qimg, m->s_kvk, m->s_attimg, m->s_tmpimg, s2, ov2 ? ev_xr : nullptr,
-                       io.kvk_in_chain));
-      RUN(project_image_kv(m, m->skel[i + 1], m->s_mem, (long)HW * d, nb, m->s_kv, s2));
+                       io.kvk_in_chain, m->s_mem16));
+      RUN(project_image_kv(m, m->skel[i + 1], m->s_mem, (long)HW * d, nb, m->s_kv, s2, m->s_mem16));
       if (ov2) EC_HIP(hipEventRecord(ev_kv, s2));
       RUN(tl_mark(m, i == 0 ? "I.kv1" : "I.kv2", s2));
-      if (i + 2 < nsk) RUN(image_update_q(m, m->skel[i + 1], m->s_mem, nb, m->s_qimg, s2));
+      if (i + 2 < nsk) RUN(image_update_q(m, m->skel[i + 1], m->s_mem, nb, m->s_qimg, s2, m->s_mem16));
     }
   }
   const float* kp_ref = sx;                  // mean over the shots (skeleton.py:114); one shot: the tokens themselves
@@ -1497,6 +1536,7 @@ int ec_finalize(ec_handle m) {
   WS(s_mem, S * Mi * d); WS(s_x, S * Mk * d); WS(s_tmp, S * Mk * d); WS(s_qkv, S * Mk * 3 * d); WS(s_att, S * Mk * E);
   WS(s_qc, S * Mk * E); WS(s_kv, S * Mi * 2 * E); WS(s_y, S * Mk * 2 * Fs); WS(s_z, S * Mk * Fs); WS(s_qimg, S * Mi * E);
   WS(s_kvk, S * Mk * 2 * E); WS(s_attimg, S * Mi * E); WS(s_tmpimg, S * Mi * d);
+  if (m->head_mixed) WS(s_mem16, S * Mi * d);
   const size_t Me = (size_t)bs * L;
   WS(e_x, Me * d); WS(e_qkv, Me * 3 * d); WS(e_att, Me * d); WS(e_tmp, Me * d); WS(e_h, Me * Fd);
   WS(p_fs, Mk * d); WS(p_fq, Mi * d); WS(p_g1, Mk * 128); WS(p_fs2, Mk * d);

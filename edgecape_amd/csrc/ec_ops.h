@@ -20,6 +20,7 @@ struct LnP {
   int add_fmt = 0;              // 16-bit format of add / add2 (1 bf16, 2 fp16); 0 = the output's format (bf16 for fp32 output)
   const void* add2 = nullptr;   // optional second branch (same stride): x' = (x + add) + add2
   float* xsum = nullptr;        // null with add set: x' is normalised but not written back
+  void* y2 = nullptr; long ldy2 = 0;   // optional second output in IEEE fp16 (fp32 main output only): the 16-bit operand of a following GEMM
 };
 int layernorm(const LnP& p, hipStream_t st);
 

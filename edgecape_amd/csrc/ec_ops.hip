@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnP p) {
         *(u32x2_t*)y = pack4_h<F16>(o);
       } else {
         *(f32x4*)((float*)p.y + orow * p.ldy + c) = o;
+        if (p.y2) *(u32x2_t*)((bf16_t*)p.y2 + orow * p.ldy2 + c) = pack4_h<true>(o);
       }
     }
   }
