@@ -51,6 +51,7 @@ struct ChainP {
   // v_mfma_f32_16x16x32_f16 per product.  Half the weight bytes - which is what bounds the kernel - and a third of the MFMAs.
   int h1 = 0;
   ChainStage st[CH_MAX_STAGES];
+  unsigned* trace = nullptr;   // EC_CHAIN_TRACE=1 (debug instantiation): s_memtime stamps of one mid-grid workgroup's wave 0
 };
 
 int chain_layout_bytes(int k);   // bytes of an operand buffer of k columns (32 rows)

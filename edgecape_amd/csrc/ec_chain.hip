@@ -59,9 +59,19 @@ __device__ __forceinline__ u32x2 half4(const f32x4 x) {
 
 struct WBatch { bf16x8 w[4][2][2]; };   // [k-block of the batch][n-fragment][plane]
 
+template <bool TRACE>
 __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
+  // TRACE (EC_CHAIN_TRACE=1): thread 0 of one mid-grid workgroup stamps s_memtime at the milestones of every stage
+  const bool tr_on = TRACE && blockIdx.x == gridDim.x / 2 && tid == 0;
+  int tr_i = 0;
+  auto stamp = [&]() __attribute__((always_inline)) {
+    if constexpr (TRACE) {
+      if (tr_on && tr_i < 63) p.trace[tr_i++] = (unsigned)__builtin_amdgcn_s_memtime();
+    }
+  };
+  stamp();
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int slab = blockIdx.x / p.split, part = blockIdx.x - slab * p.split;
@@ -344,6 +354,7 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
     };
     // The first weight batch and the first pass's epilogue operands are requested BEFORE the stage's input is staged: they
     // land under the staging and its two barriers instead of in front of the first MFMA / inside the epilogue.
+    stamp();   // stage start
     load_batch(b0, 0);
     load_bias(pass_of(0) * 16 + wave * 2);
     if (S.resid) {
@@ -354,6 +365,7 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
           presid[mi][j] = *(const f32x4*)(S.resid + (long)min(row0 + mi * 16 + lrow, p.rows - 1) * S.ldr + (wave * 2 + j) * 16 + lq * 4);
     }
     __syncthreads();   // every wave is done with the previous stage's operand buffers (this stage may re-stage one of them)
+    stamp();   // barrier passed
     if (S.g_k > 0) {
       // ---- stage a global fp32 input [rows, g_k] into LDS, split: one f32x4 per thread and step
       // (four loads per thread in flight before the first split: one load per trip paid a full memory latency per 8 KiB)
@@ -385,7 +397,7 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
       }
     }
     __syncthreads();
-
+    stamp();   // input staged
 
     // (sched_barrier: the machine scheduler otherwise sinks the prefetch three quarters into the batch it should run under)
     for (int i = 0; i < T;) {
@@ -400,6 +412,7 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
       step();
       ++i;
     }
+    stamp();   // stage done (K loop + epilogues)
   }
 }
 
@@ -457,10 +470,34 @@ int run_chain(const ChainP& p, hipStream_t st) {
   EC_HIP(hipGetDevice(&dev));
   EC_REQUIRE(dev >= 0 && dev < 64, -1, "chain: device ordinal out of range");
   if (!ch_dev[dev].attr_done) {
-    EC_HIP(hipFuncSetAttribute((const void*)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    EC_HIP(hipFuncSetAttribute((const void*)chain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    EC_HIP(hipFuncSetAttribute((const void*)chain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     ch_dev[dev].attr_done = true;
   }
-  hipLaunchKernelGGL(chain_kernel, dim3(((p.rows + CH_BM - 1) / CH_BM) * p.split), dim3(512), p.lds_bytes, st, p);
+  const dim3 grid(((p.rows + CH_BM - 1) / CH_BM) * p.split);
+  static const bool trace = getenv("EC_CHAIN_TRACE") != nullptr;
+  if (trace) {   // diagnostics: per-stage cycle counts of one workgroup (synchronises the stream: not for timing runs)
+    unsigned* d_tr = nullptr;
+    EC_HIP(hipMalloc((void**)&d_tr, 64 * sizeof(unsigned)));
+    EC_HIP(hipMemsetAsync(d_tr, 0, 64 * sizeof(unsigned), st));
+    ChainP q = p;
+    q.trace = d_tr;
+    hipLaunchKernelGGL(chain_kernel<true>, grid, dim3(512), p.lds_bytes, st, q);
+    EC_LAUNCH_CHECK();
+    EC_HIP(hipStreamSynchronize(st));
+    unsigned h[64];
+    EC_HIP(hipMemcpy(h, d_tr, sizeof(h), hipMemcpyDeviceToHost));
+    (void)hipFree(d_tr);
+    fprintf(stderr, "[chain trace] rows %d stages %d split %d h1 %d:", p.rows, p.n_stages, p.split, p.h1);
+    for (int s = 0; s < p.n_stages; ++s) {
+      const unsigned* t = h + 1 + 4 * s;
+      fprintf(stderr, " | N%d K%d%s: loads+barrier %u stage-in %u K-loop+epilogue %u", p.st[s].N, p.st[s].K, p.st[s].ln_w ? " LN" : "", t[1] - t[0],
+              t[2] - t[1], t[3] - t[2]);
+    }
+    fprintf(stderr, " | total %u (entry -> first stage %u)\n", h[4 * p.n_stages] - h[0], h[1] - h[0]);
+    return 0;
+  }
+  hipLaunchKernelGGL(chain_kernel<false>, grid, dim3(512), p.lds_bytes, st, p);
   EC_LAUNCH_CHECK();
   return 0;
 }
