@@ -399,8 +399,9 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
 
 // ------------------------------------------------------------------------------------------------
 // SOFTWARE-PIPELINED, PERSISTENT form of the bf16 / fp16 path (round 2).  An EXPERIMENT kept behind EC_ATTN_PIPE=1: correct
-// (same op tests as the kernel above), but not faster - 54.5 us as one workgroup per item, 58.5 us persistent, against 51.0 us
-// for the kernel above (B = 64, H = 12, T = 325, same box, rocprofv3 averages).
+// (same op tests as the kernel above), but not faster - 54.5 us as one workgroup per item (first build; 57.5 us in this persistent-capable
+// form with EC_ATTN_PIPE=2, the whole ring requested up front and 16-byte stores), 58.4 us persistent, against 51.0 us for the kernel
+// above at the time and 48.0 us now (B = 64, H = 12, T = 325, same box, rocprofv3 averages).
 // Idea: in the kernel above a wave runs QK^T MFMAs -> max -> exp -> PV MFMAs strictly one after the other, so its matrix and
 // vector phases only overlap with OTHER waves' phases by chance.  Here the unit of work is a 32-key sub-tile and every loop
 // body issues
@@ -520,10 +521,15 @@ __global__ __launch_bounds__(256, 3) void attn_pipe_kernel(AttnP p) {
   Item cur = decode(blockIdx.x);
   {
     const __amdgpu_buffer_rsrc_t rsK0 = desc(cur.Kb, ldk_b), rsV0 = desc(cur.Vb, ldv_b);
+    // the whole ring is requested up front (K stages 0..2, V stages 0..1): stage 1 would otherwise wait out a cold miss that was
+    // issued only one stage earlier
     stage_k(rsK0, 0, Kring);
     stage_v(rsV0, 0, Vring);
     if (ns > 1) stage_k(rsK0, 1, Kring + AP_SLOT);
+    if (ns > 1) stage_v(rsV0, 1, Vring + AP_SLOT);
+    if (ns > 2) stage_k(rsK0, 2, Kring + 2 * AP_SLOT);
   }
+  bool first_item = true;
 
   bf16x8 qf[4];
   f32x16 ot[2];
@@ -752,8 +758,10 @@ __global__ __launch_bounds__(256, 3) void attn_pipe_kernel(AttnP p) {
     stamp();
     __syncthreads();                                   // ... for every wave, and every wave is done with stage s - 1
     stamp();
-    if (s + 2 < ns) stage_k(rsK, s + 2, Kring + k2s * AP_SLOT);
-    if (s + 1 < ns) stage_v(rsV, s + 1, Vring + v1s * AP_SLOT);
+    if (!(first_item && s == 0)) {   // (the first item's prologue already asked for these two)
+      if (s + 2 < ns) stage_k(rsK, s + 2, Kring + k2s * AP_SLOT);
+      if (s + 1 < ns) stage_v(rsV, s + 1, Vring + v1s * AP_SLOT);
+    }
     if (s == ns - 1 && has_next) {   // last stage: the slots of (non-existent) stages s + 1, s + 2 take the next item's first stages
       const __amdgpu_buffer_rsrc_t rsKn = desc(nxt.Kb, ldk_b), rsVn = desc(nxt.Vb, ldv_b);
       stage_k(rsKn, 0, Kring + k1s * AP_SLOT);
@@ -801,22 +809,26 @@ __global__ __launch_bounds__(256, 3) void attn_pipe_kernel(AttnP p) {
   }
   lrun = ap_xhalf_sum(lrun);
   const float inv = 1.f / lrun;
-  {
+  {   // 16-byte stores after a half-wave exchange (see the kernel above)
     const int l = ap_lane_now();
-    if (q0 + (l & 31) < p.Lq) {
-      char* O = cur.Ob + (long)(q0 + (l & 31)) * p.ldo * 2 + (l >> 5) * 8;
+    const int jj = l & 31, hh = l >> 5;
+    char* O = cur.Ob + (long)min(q0 + jj, p.Lq - 1) * p.ldo * 2;
+    const bool q_ok = q0 + jj < p.Lq;
 #pragma unroll
-      for (int d = 0; d < 2; ++d)
+    for (int d = 0; d < 2; ++d)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (short)f2h<F16>(ot[d][4 * g + e] * inv);
-          *(bf16x4*)(O + (d * 32 + 8 * g) * 2) = o;
-        }
-    }
+      for (int gp = 0; gp < 2; ++gp) {
+        const u32x2_t a = pack4_h<F16>(f32x4{ot[d][8 * gp] * inv, ot[d][8 * gp + 1] * inv, ot[d][8 * gp + 2] * inv, ot[d][8 * gp + 3] * inv});
+        const u32x2_t c4 = pack4_h<F16>(f32x4{ot[d][8 * gp + 4] * inv, ot[d][8 * gp + 5] * inv, ot[d][8 * gp + 6] * inv, ot[d][8 * gp + 7] * inv});
+        const u32x2_t s0 = __builtin_amdgcn_permlane32_swap(a[0], c4[0], false, false);
+        const u32x2_t s1 = __builtin_amdgcn_permlane32_swap(a[1], c4[1], false, false);
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+        const u32x4_ o = {s0[0], s1[0], s0[1], s1[1]};
+        if (q_ok) *(u32x4_*)(O + (d * 32 + 16 * gp + 8 * hh) * 2) = o;
+      }
   }
   cur = nxt;
+  first_item = false;
   }   // next work item
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -1051,7 +1063,8 @@ int ap_grid(long nitems, int* grid) {
   EC_HIP(hipGetDevice(&dev));
   EC_REQUIRE(dev >= 0 && dev < 64, -1, "attention: device ordinal out of range");
   if (!ap_dev[dev].ncu) EC_HIP(hipDeviceGetAttribute(&ap_dev[dev].ncu, hipDeviceAttributeMultiprocessorCount, dev));
-  const long cap = 3l * ap_dev[dev].ncu;
+  static const bool one_per_item = getenv("EC_ATTN_PIPE") && atoi(getenv("EC_ATTN_PIPE")) == 2;   // 2: one workgroup per item
+  const long cap = one_per_item ? nitems : 3l * ap_dev[dev].ncu;
   *grid = (int)(nitems < cap ? nitems : cap);
   return 0;
 }
