@@ -169,6 +169,15 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16v8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
 
+__device__ __forceinline__ float xhalf_max(float v) {   // max over the two half-waves: one v_permlane32_swap instead of an LDS bpermute
+  const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+  const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 constexpr int A16_TILE = 64 * 128;           // 8 KiB per tile
 constexpr int A16_STAGE = 2 * A16_TILE;      // K + V^T
 constexpr int A16_LDS = 2 * A16_STAGE;       // double buffered: 32 KiB
@@ -225,16 +234,25 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
   float mrun = -1e30f, lrun = 0.f;
   const float c = 0.125f * 1.44269504088896340736f;   // hd^-0.5 * log2(e)
 
+  // Staging by buffer loads to LDS: one descriptor per operand that ends with key row Lk - 1 (rows past it read as zeros: K = 0 gives
+  // a score the edge mask removes, V = 0 meets P = 0), a fixed 32-bit per-lane offset and the tile as the scalar offset - no 64-bit
+  // address arithmetic per tile (host: one head's K / V rows span < 2 GiB)
+  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Kb), 0, (int)((long)(p.Lk - 1) * ldk_b + 128), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Vb), 0, (int)((long)(p.Lk - 1) * ldv_b + 128), 0x00020000);
+  unsigned vok[2], vov[2];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int r = (wave * 2 + jj) * 8 + (lane >> 3);
+    const int cc = (lane & 7) ^ ((r >> 1) & 7);
+    vok[jj] = (unsigned)r * (unsigned)ldk_b + (unsigned)cc * 16u;
+    vov[jj] = (unsigned)r * (unsigned)ldv_b + (unsigned)cc * 16u;
+  }
   auto stage = [&](int k0, char* buf) {
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int rb = wave * 2 + jj;
-      const int r = rb * 8 + (lane >> 3);
-      const int cc = (lane & 7) ^ ((r >> 1) & 7);
-      int key = k0 + r;
-      key = key < p.Lk ? key : p.Lk - 1;
-      __builtin_amdgcn_global_load_lds((gptr_t)(Kb + (long)key * ldk_b + cc * 16), (lptr_t)(buf + rb * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(Vb + (long)key * ldv_b + cc * 16), (lptr_t)(buf + A16_TILE + rb * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lptr_t)(buf + rb * 1024), 16, vok[jj], k0 * (int)ldk_b, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lptr_t)(buf + A16_TILE + rb * 1024), 16, vov[jj], k0 * (int)ldv_b, 0, 0);
     }
   };
 
@@ -303,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[t][r]);
     }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * c;
+    tmax = xhalf_max(tmax) * c;
     // LAZY running maximum: the reference point mrun only moves when some query's tile maximum exceeds it by more than 2^8
     // (softmax is invariant to the reference; exp2 arguments stay <= 8, so P <= 256 and the row sums stay far inside fp32 /
     // bf16 range).  With 32 queries per wave SOME row sets a new maximum in almost every tile, so an exact running maximum
@@ -354,24 +372,30 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
         // the group points at key row (i>>2) of a 4-key block and d-quad (i&3), and gets the 4 keys of column i.
         const int i16 = lane & 15, G = (lane >> 4) & 1;
         const int krow = 32 * t + 16 * uu + 4 * hi + (i16 >> 2);   // second block: + 8
+        // (inline asm: behind the intrinsic the compiler puts s_waitcnt vmcnt(0) - it cannot tell the read from the LDS-DMA writes in
+        //  flight - i.e. the NEXT tile's loads, issued at the top of this tile, would have to land before this tile's PV MFMAs)
+        u32x2_t vlo[2], vhi[2];
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
           const int chunk = 4 * d + 2 * G + ((i16 >> 1) & 1);
           const int off = (i16 & 1) * 8;
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (lds_s16x4_t)(Vtt + krow * 128 + ((chunk ^ ((krow >> 1) & 7)) << 4) + off));
-          const s16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (lds_s16x4_t)(Vtt + (krow + 8) * 128 + ((chunk ^ (((krow + 8) >> 1) & 7)) << 4) + off));
-          bf16x8 av;
+          const unsigned a0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)(Vtt + krow * 128 + ((chunk ^ ((krow >> 1) & 7)) << 4) + off);
+          const unsigned a1 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)(Vtt + (krow + 8) * 128 + ((chunk ^ (((krow + 8) >> 1) & 7)) << 4) + off);
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vlo[d]) : "v"(a0));
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vhi[d]) : "v"(a1));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[0]), "+v"(vhi[0]), "+v"(vlo[1]), "+v"(vhi[1]));
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { av[e] = lo[e]; av[4 + e] = hi2[e]; }
+        for (int d = 0; d < 2; ++d) {
+          typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+          const bf16x8 av = __builtin_bit_cast(bf16x8, u32x4_{vlo[d][0], vlo[d][1], vhi[d][0], vhi[d][1]});
           ot[d] = mfma32x32x16_h<F16>(av, pb, ot[d]);
         }
       }
     }
     A16_STAMP(6);
   }
-  lrun += __shfl_xor(lrun, 32, 64);
+  lrun = xhalf_sum(lrun);
   const float inv = 1.f / lrun;
   // Output: lane (query j, half hi) holds, per 8-column group g of a d-tile, the 4 columns 8 g + 4 hi .. + 3.  One v_permlane32_swap per
   // packed dword between the groups of a pair gives the lower half-wave all 8 columns of the even group and the upper half-wave
@@ -1160,8 +1184,8 @@ int attention(const AttnP& p, hipStream_t st) {
       return 0;
     }
     static const bool pipe = getenv("EC_ATTN_PIPE") && atoi(getenv("EC_ATTN_PIPE")) != 0;   // 1 = the pipelined persistent experiment
+    EC_REQUIRE((long)p.Lk * p.ldk * 2 < (1l << 31) && (long)p.Lk * p.ldv * 2 < (1l << 31), -1, "attention(bf16): K / V rows of one head beyond 2 GiB");
     if (pipe) {
-      EC_REQUIRE((long)p.Lk * p.ldk * 2 < (1l << 31) && (long)p.Lk * p.ldv * 2 < (1l << 31), -1, "attention(bf16): K / V rows of one head beyond 2 GiB");
       int pg = 0;
       if (ap_grid(grid.x * grid.y * grid.z, &pg) < 0) return -1;
       if (p.f16) hipLaunchKernelGGL((attn_pipe_kernel<true>), dim3(pg), dim3(256), AP_LDS_ALL, st, p);
