@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
         s[t][r] = v;
         tmax = fmaxf(tmax, v);
       }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    tmax = xhalf_max(tmax);
     const float mnew = fmaxf(mrun, tmax);
     const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
     mrun = mnew;
@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
         }
       }
   }
-  lrun += __shfl_xor(lrun, 32, 64);
+  lrun = xhalf_sum(lrun);
   const float inv = 1.f / lrun;
   if (q0 + j < p.Lq) {
     float* O = (float*)p.O + (long)b * p.sO + (long)(q0 + j) * p.ldo + h * HD;
