@@ -357,38 +357,49 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
     }
     lrun += psum2[0] + psum2[1];
     A16_STAMP(5);
+    {
+      // O^T += V^T P^T in four groups (t, uu) of 16 keys.  V^T fragments by transposing reads: this lane's 16-lane group covers
+      // d = 32*dt + 16*G .. +15; lane i of the group points at key row (i>>2) of a 4-key block and d-quad (i&3), and gets the 4 keys of
+      // column i.  The reads are inline asm (behind the intrinsic the compiler puts s_waitcnt vmcnt(0) - it cannot tell the read from the
+      // LDS-DMA writes in flight - i.e. the NEXT tile's loads, issued at the top of this tile, would have to land before this tile's PV
+      // MFMAs), closed by hand, and group g + 1 is requested before the MFMAs of group g.
+      const int i16 = lane & 15, G = (lane >> 4) & 1;
+      const int rr = 4 * hi + (i16 >> 2);
+      unsigned aoff[2][2];   // [d][block]: byte offset of this lane's read inside a 16-key group (the key offset 16 g adds 2 KiB)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      if (t == 1 && half_tile) continue;
+      for (int d = 0; d < 2; ++d) {
+        const int chunk = 4 * d + 2 * G + ((i16 >> 1) & 1);
+        aoff[d][0] = rr * 128 + ((chunk ^ ((rr >> 1) & 7)) << 4) + (i16 & 1) * 8;
+        aoff[d][1] = (rr + 8) * 128 + ((chunk ^ (((rr + 8) >> 1) & 7)) << 4) + (i16 & 1) * 8;
+      }
+      const unsigned vbase = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)Vtt;
+      u32x2_t vlo[2][2], vhi[2][2];   // [buffer][d]
+      auto issue = [&](int g, int bufi) __attribute__((always_inline)) {
 #pragma unroll
-      for (int uu = 0; uu < 2; ++uu) {
+        for (int d = 0; d < 2; ++d) {
+          const unsigned a0 = vbase + (unsigned)g * 2048u + aoff[d][0], a1 = vbase + (unsigned)g * 2048u + aoff[d][1];
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vlo[bufi][d]) : "v"(a0));
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vhi[bufi][d]) : "v"(a1));
+        }
+      };
+      const int ng = half_tile ? 2 : 4;
+      issue(0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (g >= ng) break;
+        const int bufi = g & 1, t = g >> 1, uu = g & 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[bufi][0]), "+v"(vhi[bufi][0]), "+v"(vlo[bufi][1]), "+v"(vhi[bufi][1]));
+        if (g + 1 < ng) issue(g + 1, bufi ^ 1);
         f32x8 pv;
 #pragma unroll
         for (int e = 0; e < 8; ++e) pv[e] = s[t][8 * uu + e];
         bf16x8 pb;   // P <= 2^8 by the lazy maximum: inside the fp16 range as well
         if constexpr (F16) pb = __builtin_bit_cast(bf16x8, __builtin_convertvector(pv, f16x8));
         else pb = __builtin_bit_cast(bf16x8, __builtin_convertvector(pv, bf16v8));
-        // V^T fragment by transposing reads: this lane's 16-lane group covers d = 32*dt + 16*G .. +15; lane i of
-        // the group points at key row (i>>2) of a 4-key block and d-quad (i&3), and gets the 4 keys of column i.
-        const int i16 = lane & 15, G = (lane >> 4) & 1;
-        const int krow = 32 * t + 16 * uu + 4 * hi + (i16 >> 2);   // second block: + 8
-        // (inline asm: behind the intrinsic the compiler puts s_waitcnt vmcnt(0) - it cannot tell the read from the LDS-DMA writes in
-        //  flight - i.e. the NEXT tile's loads, issued at the top of this tile, would have to land before this tile's PV MFMAs)
-        u32x2_t vlo[2], vhi[2];
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          const int chunk = 4 * d + 2 * G + ((i16 >> 1) & 1);
-          const int off = (i16 & 1) * 8;
-          const unsigned a0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)(Vtt + krow * 128 + ((chunk ^ ((krow >> 1) & 7)) << 4) + off);
-          const unsigned a1 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)(Vtt + (krow + 8) * 128 + ((chunk ^ (((krow + 8) >> 1) & 7)) << 4) + off);
-          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vlo[d]) : "v"(a0));
-          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vhi[d]) : "v"(a1));
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[0]), "+v"(vhi[0]), "+v"(vlo[1]), "+v"(vhi[1]));
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
           typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
-          const bf16x8 av = __builtin_bit_cast(bf16x8, u32x4_{vlo[d][0], vlo[d][1], vhi[d][0], vhi[d][1]});
+          const bf16x8 av = __builtin_bit_cast(bf16x8, u32x4_{vlo[bufi][d][0], vlo[bufi][d][1], vhi[bufi][d][0], vhi[bufi][d][1]});
           ot[d] = mfma32x32x16_h<F16>(av, pb, ot[d]);
         }
       }
