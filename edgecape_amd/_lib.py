@@ -19,7 +19,7 @@ EC_DT_F32, EC_DT_F16, EC_DT_BF16, EC_DT_F64 = 0, 1, 2, 3
 EC_LAYOUT_TOKENS, EC_LAYOUT_NCHW = 0, 1
 
 EXPORTS = ["ec_last_error", "ec_version", "ec_create", "ec_destroy", "ec_load_tensor", "ec_set_pos_embed", "ec_finalize",
-           "ec_backbone", "ec_head", "ec_forward", "ec_support_create", "ec_support_destroy", "ec_support_encode", "ec_forward_cached", "ec_preprocess_images", "ec_msra_targets", "ec_debug_read", "ec_profile", "ec_profile_read", "ec_op_linear", "ec_op_linear_h16", "ec_op_gemm_bench", "ec_op_bgemm", "ec_op_layernorm",
+           "ec_backbone", "ec_head", "ec_forward", "ec_support_create", "ec_support_destroy", "ec_support_encode", "ec_forward_cached", "ec_preprocess_images", "ec_preprocess_images_cv2", "ec_msra_targets", "ec_debug_read", "ec_profile", "ec_profile_read", "ec_op_linear", "ec_op_linear_h16", "ec_op_gemm_bench", "ec_op_bgemm", "ec_op_layernorm",
            "ec_op_attention", "ec_op_chain", "ec_abi_sizes"]
 
 
@@ -55,9 +55,10 @@ def load():
             "The EdgeCape hot path has no CPU/PyTorch fallback.")
     if _build.needs_build():
         # a prebuilt library from other sources would be called with mismatched struct layouts: rebuild where hipcc exists
-        # (build container, GPU box), refuse otherwise
+        # (build container, GPU box), refuse otherwise.  build_locked() serialises the ranks of a torchrun job on a lock file
+        # and re-checks the stamp once it holds the lock, so exactly one of them compiles.
         try:
-            _build.build(verbose=False)
+            _build.build_locked(verbose=False)
         except Exception as e:  # noqa: BLE001
             raise EdgeCapeHipError(f"{path} is stale (sources changed since it was built) and could not be rebuilt: {e}") from e
     lib = C.CDLL(path)
@@ -86,6 +87,7 @@ def load():
     lib.ec_support_encode.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(vp), vp, vp, vp, ci, ci, vp]
     lib.ec_forward_cached.argtypes = [vp, vp, vp, vp, ci, vp, C.POINTER(EcOutputs)]
     lib.ec_preprocess_images.argtypes = [C.POINTER(vp), vp, vp, vp, ci, ci, vp, vp, vp, vp]
+    lib.ec_preprocess_images_cv2.argtypes = [C.POINTER(vp), vp, vp, vp, ci, ci, vp, vp, vp, vp]
     lib.ec_msra_targets.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]
     lib.ec_debug_read.argtypes = [vp, C.c_char_p, vp, C.c_int64, C.POINTER(C.c_int64)]
     lib.ec_profile.argtypes = [vp, ci, ci]

@@ -18,7 +18,6 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-PATH_BYTES = 254   # fixed path field of a result record (longer paths are an error, never silently cut)
 
 
 # ---- process group --------------------------------------------------------------------------------------------------
@@ -142,23 +141,20 @@ def single_gpu_test(model, data_loader):
     return out
 
 
-def _pack(results, n_rows, K):
-    """per-sample result dicts -> uint8 [n_rows, record]; rows past len(results) are marked invalid."""
-    rec = 1 + K * 12 + 24 + 8 + 2 + PATH_BYTES
+def _pack(results, n_rows, K, path_bytes):
+    """per-sample result dicts -> uint8 [n_rows, record]; rows past len(results) are marked invalid.  Inputs were validated by
+    _local_meta on every rank before any collective."""
+    rec = 1 + K * 12 + 24 + 8 + 4 + path_bytes
     buf = np.zeros((n_rows, rec), np.uint8)
     for i, r in enumerate(results):
         p = np.ascontiguousarray(r["preds"], np.float32).reshape(-1)
-        if p.size != K * 3:
-            raise ValueError(f"result {i}: {p.size // 3} keypoints, expected {K} on every rank")
         path = str(r["image_paths"][0]).encode()
-        if len(path) > PATH_BYTES:
-            raise ValueError(f"image path longer than {PATH_BYTES} bytes: {path[:40]!r}...")
         row, o = buf[i], 1
         row[0] = 1
         row[o:o + K * 12] = p.view(np.uint8); o += K * 12
         row[o:o + 24] = np.ascontiguousarray(r["boxes"], np.float32).reshape(6).view(np.uint8); o += 24
         row[o:o + 8] = np.array([int(r["bbox_ids"][0])], np.int64).view(np.uint8); o += 8
-        row[o:o + 2] = np.array([len(path)], np.uint16).view(np.uint8); o += 2
+        row[o:o + 4] = np.array([len(path)], np.uint32).view(np.uint8); o += 4
         row[o:o + len(path)] = np.frombuffer(path, np.uint8)
     return buf
 
@@ -168,8 +164,28 @@ def _unpack(row, K):
     preds = row[o:o + K * 12].copy().view(np.float32).reshape(1, K, 3); o += K * 12
     boxes = row[o:o + 24].copy().view(np.float32).reshape(1, 6); o += 24
     bid = int(row[o:o + 8].copy().view(np.int64)[0]); o += 8
-    n = int(row[o:o + 2].copy().view(np.uint16)[0]); o += 2
+    n = int(row[o:o + 4].copy().view(np.uint32)[0]); o += 4
     return {"preds": preds, "boxes": boxes, "bbox_ids": [bid], "image_paths": [bytes(row[o:o + n]).decode()]}
+
+
+def _local_meta(local_results):
+    """(rows, K_max, -K_min, longest path, error flag) of this rank's results: reduced with MAX over the ranks BEFORE anything is
+    packed, so that a malformed result raises on every rank together instead of leaving the others blocked in the all_gather."""
+    ks, plen, bad = [], 0, 0
+    for r in local_results:
+        try:
+            p = np.asarray(r["preds"], np.float32)
+            if p.ndim < 2 or p.shape[-1] != 3 or np.asarray(r["boxes"]).size != 6:
+                bad = 1
+                continue
+            ks.append(int(p.size // 3))
+            plen = max(plen, len(str(r["image_paths"][0]).encode()))
+            int(r["bbox_ids"][0])
+        except Exception:  # noqa: BLE001
+            bad = 1
+    kmax = max(ks) if ks else 0
+    kmin = min(ks) if ks else 1 << 30
+    return [len(local_results), kmax, -kmin, plen, bad]
 
 
 def collect_results(local_results, size, device=None, all_ranks=False):
@@ -180,11 +196,14 @@ def collect_results(local_results, size, device=None, all_ranks=False):
     if world == 1:
         return list(local_results)[:size]
     dev = comm_device(device)
-    K_loc = int(np.asarray(local_results[0]["preds"]).shape[-2]) if local_results else 0
-    meta = torch.tensor([len(local_results), K_loc], dtype=torch.int64, device=dev)
-    dist.all_reduce(meta, op=dist.ReduceOp.MAX)          # rows per rank and K agreed without assuming equal shards
-    n_rows, K = int(meta[0].item()), int(meta[1].item())
-    mine = torch.from_numpy(_pack(local_results, n_rows, K)).to(dev)
+    meta = torch.tensor(_local_meta(local_results), dtype=torch.int64, device=dev)
+    dist.all_reduce(meta, op=dist.ReduceOp.MAX)          # rows per rank, K, path length, errors: agreed without assuming equal shards
+    n_rows, K, neg_kmin, path_bytes, bad = (int(v) for v in meta.tolist())
+    if bad:
+        raise ValueError("collect_results: a rank holds a malformed result dict (preds [.., K, 3], boxes [6], bbox_ids, image_paths)")
+    if -neg_kmin < K:                                     # (a rank without results reports K_min = 2^30 and does not lower it)
+        raise ValueError(f"collect_results: results with {-neg_kmin} and {K} keypoints: K must be the same on every rank")
+    mine = torch.from_numpy(_pack(local_results, n_rows, K, path_bytes)).to(dev)
     parts = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(parts, mine)
     if rank != 0 and not all_ranks:

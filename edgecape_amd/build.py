@@ -49,6 +49,18 @@ def needs_build():
         return f.read().strip() != source_hash()
 
 
+def build_locked(verbose=True):
+    """build() under an exclusive flock on <LIB>.lock: concurrent processes (the ranks of one job after a kernel edit) queue up,
+    the first one compiles, the others find the stamp current when they get the lock and return at once."""
+    import fcntl
+    with open(LIB + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            return build(force=False, verbose=verbose)      # build() re-checks needs_build() itself
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
 def build_lab(verbose=True):
     """Kernel-lab build (tools/g8_lab.py): the same sources with -DEC_G8_LAB (ablated instantiations of the 8-phase GEMM and their
     timing entry point) into libedgecape_hip_lab.so.  Never loaded by the product path."""
@@ -65,7 +77,7 @@ def build(force=False, verbose=True, lab=False):
     objs = []
     procs = []
     for s in sources():
-        o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
+        o = os.path.join(objdir, f"{os.path.basename(s)[:-4]}.{os.getpid()}.o")
         objs.append(o)
         cmd = [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-c", s, "-o", o]
         if lab:
@@ -76,11 +88,17 @@ def build(force=False, verbose=True, lab=False):
         if p.returncode != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + out)
     out = LIB.replace(".so", "_lab.so") if lab else LIB
-    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out + ".tmp"] + objs
+    tmp = f"{out}.{os.getpid()}.tmp"
+    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    for o in objs:
+        try:
+            os.remove(o)
+        except OSError:
+            pass
     if r.returncode != 0:
         raise RuntimeError("link failed: " + " ".join(cmd) + "\n" + r.stdout)
-    os.replace(out + ".tmp", out)
+    os.replace(tmp, out)
     if lab:
         return out
     with open(STAMP, "w") as f:
@@ -93,5 +111,7 @@ def build(force=False, verbose=True, lab=False):
 if __name__ == "__main__":
     if "--lab" in sys.argv:
         print(build_lab())
+    elif "--force" in sys.argv:
+        build(force=True)
     else:
-        build(force="--force" in sys.argv)
+        build_locked()

@@ -432,442 +432,10 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// SOFTWARE-PIPELINED, PERSISTENT form of the bf16 / fp16 path (round 2).  An EXPERIMENT kept behind EC_ATTN_PIPE=1: correct
-// (same op tests as the kernel above), but not faster - 54.5 us as one workgroup per item (first build; 57.5 us in this persistent-capable
-// form with EC_ATTN_PIPE=2, the whole ring requested up front and 16-byte stores), 58.4 us persistent, against 51.0 us for the kernel
-// above at the time and 48.0 us now (B = 64, H = 12, T = 325, same box, rocprofv3 averages).
-// Idea: in the kernel above a wave runs QK^T MFMAs -> max -> exp -> PV MFMAs strictly one after the other, so its matrix and
-// vector phases only overlap with OTHER waves' phases by chance.  Here the unit of work is a 32-key sub-tile and every loop
-// body issues
-//      QK^T of unit u+1 (4 MFMAs)  |  softmax of unit u (max3 / pk_fma / exp / pk_add / cvt)  |  PV of unit u-1 (4 MFMAs)
-// as ONE instruction stream (the MFMAs have no data dependence on the VALU work beside them).  T = 325 gives 11 units (352
-// keys; the 64-key tiles above pad to 384).
-//   * K/V stages stay 64 keys (two units), staged by LDS-DMA (buffer loads, range-checked rows), in two rings of three slots
-//     (K stage s+2 and V stage s+1 are in flight while the units of stage s run: QK reads one unit ahead, PV one behind);
-//     48 KiB per workgroup, 166 VGPRs: three workgroups per CU like the kernel above.  One wait + barrier per stage.
-//   * lazy running maximum as above, branch-free; the rescale of O^T (rare) happens at the top of the NEXT body, the row sum at once.
-//   * cross-half exchanges are v_permlane32_swap (VALU) instead of ds_bpermute; V^T reads are inline asm (see v_issue).
-//   * persistent over (query block, head, batch) items; the next item's first K / V stages stream in during the last stage.
-// What was learned (tools/valu_mfma_probe.hip, EC_ATTN_TRACE=1):
-//   * a unit body costs ~470 SIMD cycles per wave here against ~800 per 32 keys above - the pipelining works inside the body -
-//     but that is exactly MFMA time (8 x 32) PLUS vector time (17 v_exp x 8 + ~45 other x 2): with an exp-heavy vector mix the
-//     two pipes of a SIMD do not run side by side, neither inside one wave nor across the waves of a SIMD (probe: 8 x {MFMA +
-//     2 fma + 2 pk_fma + 2 exp} takes 954 cycles for two waves = the SUM of 512 MFMA and ~430 vector cycles).  v_exp_f32 is a
-//     quarter-rate instruction (8 cycles per wave-instruction per SIMD however many waves), plain VALU 2 cycles per SIMD but
-//     4 per wave, v_pk_fma_f32 ~3.5: a polynomial exp2 on the vector pipe would cost more than v_exp.
-//   * what is left of an item (half of its ~33 000 cycles) is the chain wait -> barrier -> issue per stage and the hand-over
-//     between items (epilogue, O stores, Q loads of the next item: ~9 000 cycles although K/V are prefetched); the three
-//     co-resident workgroups run in lock-step (equal items, common start), so those phases do not hide under one another.
-// ------------------------------------------------------------------------------------------------
-constexpr int AP_SLOT = 64 * 128;            // one 64-key K (or V) stage: 8 KiB
-constexpr int AP_LDS = 6 * AP_SLOT;          // K ring (3 slots) | V ring (3 slots)
-constexpr int AP_LDS_ALL = AP_LDS + 4 * 256;  // + one 256-byte dump slot per wave (Q prefetch of the next work item)
-
-template <bool B> struct ap_flag { static constexpr bool value = B; };
-template <int I> struct ap_int { static constexpr int value = I; };
-
-__device__ __forceinline__ float ap_xhalf_max(float v) {
-  const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float ap_xhalf_sum(float v) {
-  const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
-// Lane id recomputed in place (two VALU): per-lane address parts that are only needed once per work item would otherwise be hoisted
-// out of the item loop and SPILLED at 168 VGPRs - and the reload (scratch = VMEM) waits behind the LDS-DMA prefetch of the next item.
-__device__ __forceinline__ int ap_lane_now() {
-  int l;
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-  return l;
-}
-
-template <bool F16, bool TRACE = false>
-__global__ __launch_bounds__(256, 3) void attn_pipe_kernel(AttnP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef __attribute__((ext_vector_type(2))) float f32x2;
-  const int tid = threadIdx.x, lane = tid & 63;
-  // TRACE (debug instantiation, EC_ATTN_TRACE=1): lane 0 of every wave of one mid-grid workgroup stamps s_memtime into p.bias
-  const bool tr_on = TRACE && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == gridDim.z / 2;
-  int tr_i = 0;
-  auto stamp = [&]() __attribute__((always_inline)) {
-    if constexpr (TRACE) {
-      if (tr_on) {
-        const unsigned ts_ = (unsigned)__builtin_amdgcn_s_memtime();
-        if (lane == 0 && tr_i < 127) ((unsigned*)p.bias)[(tid >> 6) * 128 + tr_i] = ts_;
-        ++tr_i;
-      }
-    }
-  };
-  stamp();
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, hi = lane >> 5;
-  // PERSISTENT over work items (128-query block, head, batch), query block fastest: workgroup w takes items w, w + grid, ...
-  // While an item's LAST stage runs, the first K / V stages of the workgroup's next item are already streaming into the ring slots
-  // that stage no longer needs, and the next item's Q rows are touched into L2: a fresh workgroup per item started every item with
-  // ~8 000 cycles of cold HBM latency (prologue + the wait of stage 1) that three co-resident workgroups, all starting together,
-  // could not hide from each other.
-  const int nqb = (p.Lq + 127) >> 7, nitems = nqb * p.H * p.B;
-  const long ldk_b = p.ldk * 2, ldv_b = p.ldv * 2;
-  const int ns = (p.Lk + 63) >> 6, nu = (p.Lk + 31) >> 5;   // 64-key stages, 32-key units
-  struct Item { const char *Qb, *Kb, *Vb; char* Ob; int q0w; };   // wave-uniform (SGPRs)
-  auto decode = [&](int item) __attribute__((always_inline)) {
-    const int qb = item % nqb, hb = item / nqb, h = hb % p.H, b = hb / p.H;
-    Item it;
-    it.Qb = (const char*)p.Q + ((long)b * p.sQ + h * 64) * 2;
-    it.Kb = (const char*)p.K + ((long)b * p.sK + h * 64) * 2;
-    it.Vb = (const char*)p.V + ((long)b * p.sV + h * 64) * 2;
-    it.Ob = (char*)p.O + ((long)b * p.sO + h * 64) * 2;
-    it.q0w = qb * 128 + wave * 32;
-    return it;
-  };
-  auto desc = [&](const char* base, long ld_b) __attribute__((always_inline)) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)((long)(p.Lk - 1) * ld_b + 128), 0x00020000);
-  };
-
-  // staging: wave w brings row blocks 2w, 2w+1 (8 rows x 128 B each) of a stage; 16-byte chunks XOR-swizzled by (row >> 1) & 7.
-  // Buffer loads to LDS: one descriptor per operand that ends with key row Lk - 1 (rows past it read as zeros: K = 0 gives a
-  // score that the edge mask removes, V = 0 meets P = 0), a fixed 32-bit per-lane offset and the stage as the scalar offset -
-  // no per-stage 64-bit address arithmetic (the first build spent ~450 cycles per stage in it).
-  unsigned vok[2], vov[2];
-#pragma unroll
-  for (int jj = 0; jj < 2; ++jj) {
-    const int r = (wave * 2 + jj) * 8 + (lane >> 3);
-    const int cc = (lane & 7) ^ ((r >> 1) & 7);
-    vok[jj] = (unsigned)r * (unsigned)ldk_b + (unsigned)cc * 16u;
-    vov[jj] = (unsigned)r * (unsigned)ldv_b + (unsigned)cc * 16u;
-  }
-  auto stage_k = [&](const __amdgpu_buffer_rsrc_t rs, int s, char* slot) __attribute__((always_inline)) {
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(slot + (wave * 2 + jj) * 1024), 16, vok[jj], s * 64 * (int)ldk_b, 0, 0);
-  };
-  auto stage_v = [&](const __amdgpu_buffer_rsrc_t rs, int s, char* slot) __attribute__((always_inline)) {
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(slot + (wave * 2 + jj) * 1024), 16, vov[jj], s * 64 * (int)ldv_b, 0, 0);
-  };
-  char* const Kring = smem;
-  char* const Vring = smem + 3 * AP_SLOT;
-  int k0s = 0, k1s = 1, k2s = 2;   // ring slots of K stages s, s + 1, s + 2   (the rotation carries over from item to item)
-  int vm1 = 2, v0s = 0, v1s = 1;   // ring slots of V stages s - 1, s, s + 1
-  Item cur = decode(blockIdx.x);
-  {
-    const __amdgpu_buffer_rsrc_t rsK0 = desc(cur.Kb, ldk_b), rsV0 = desc(cur.Vb, ldv_b);
-    // the whole ring is requested up front (K stages 0..2, V stages 0..1): stage 1 would otherwise wait out a cold miss that was
-    // issued only one stage earlier
-    stage_k(rsK0, 0, Kring);
-    stage_v(rsV0, 0, Vring);
-    if (ns > 1) stage_k(rsK0, 1, Kring + AP_SLOT);
-    if (ns > 1) stage_v(rsV0, 1, Vring + AP_SLOT);
-    if (ns > 2) stage_k(rsK0, 2, Kring + 2 * AP_SLOT);
-  }
-  bool first_item = true;
-
-  bf16x8 qf[4];
-  f32x16 ot[2];
-  float mrun, lrun;
-  const float c = 0.125f * 1.44269504088896340736f;   // hd^-0.5 * log2(e)
-  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-  // per-lane fragment offsets inside a 32-key unit (4 KiB): K rows as MFMA A operand (key j, k half hi) ...
-  int kro[4];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) kro[m] = j * 128 + (((2 * m + hi) ^ ((j >> 1) & 7)) << 4);
-  // ... and V^T by transposing reads (see the kernel above): 16-lane group G covers d = 32 dt + 16 G .. + 15, lane i of the group
-  // addresses key row 4 hi + (i >> 2) (+ 8 for the second block) and d-quad i & 3; the unit's 16 uu key offset adds 2 KiB
-  int vlo[2], vhi[2];
-  {
-    const int i16 = lane & 15, G = (lane >> 4) & 1;
-    const int rr = 4 * hi + (i16 >> 2);
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-      const int chunk = 4 * d + 2 * G + ((i16 >> 1) & 1);
-      vlo[d] = rr * 128 + ((chunk ^ ((rr >> 1) & 7)) << 4) + (i16 & 1) * 8;
-      vhi[d] = (rr + 8) * 128 + ((chunk ^ (((rr + 8) >> 1) & 7)) << 4) + (i16 & 1) * 8;
-    }
-  }
-
-  bool pend = false;                        // O^T still has to be multiplied by alpha_p (reference point moved in the last body)
-  float alpha_p = 1.f;
-  f32x16 s_cur = zero16, s_next = zero16;   // S^T of unit u (softmax input) / of unit u + 1 (being accumulated)
-  bf16x8 p_prev[2], p_cur[2];               // P of unit u - 1 (B operand of its PV MFMAs) / of unit u
-#pragma unroll
-  for (int uu = 0; uu < 2; ++uu)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { p_prev[uu][e] = 0; p_cur[uu][e] = 0; }
-  int q0 = cur.q0w;
-
-  auto qk_unit = [&](const char* kunit, f32x16& acc) __attribute__((always_inline)) {   // acc = K(unit) Q^T
-    bf16x8 ka[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) ka[m] = *(const bf16x8*)(kunit + kro[m]);
-#pragma unroll
-    for (int m = 0; m < 4; ++m) acc = mfma32x32x16_h<F16>(ka[m], qf[m], m == 0 ? zero16 : acc);
-  };
-  // The transposing reads are issued as inline asm: behind the intrinsic the compiler puts s_waitcnt vmcnt(0) (it cannot tell
-  // the read from the LDS-DMA writes in flight), which here would wait for the stage issued a moment ago at the top of every
-  // stage - the whole load latency, exposed (first build of this kernel: 68 us).  Asm reads are invisible to the compiler's
-  // lgkmcnt bookkeeping, so v_wait() below closes them by hand and ties the registers to the wait.
-  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-  struct VFrag { u32x2 lo, hi; };
-  auto v_issue = [&](const char* vunit, int d, VFrag (&f)[2]) __attribute__((always_inline)) {   // both k-slot groups of d-tile d
-    const unsigned a0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)(vunit + vlo[d]);
-    const unsigned a1 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)(vunit + vhi[d]);
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[0].lo) : "v"(a0));
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[0].hi) : "v"(a1));
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(f[1].lo) : "v"(a0));
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(f[1].hi) : "v"(a1));
-  };
-  auto v_wait = [&](VFrag (&f0)[2], VFrag (&f1)[2]) __attribute__((always_inline)) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(f0[0].lo), "+v"(f0[0].hi), "+v"(f0[1].lo), "+v"(f0[1].hi), "+v"(f1[0].lo), "+v"(f1[0].hi), "+v"(f1[1].lo), "+v"(f1[1].hi));
-  };
-  // the same by k-slot group: f[d] = fragment (uu, d), d = 0, 1  (the body reads group 0 up front and group 1 under the exponentials)
-  auto v_issue_uu = [&](const char* vunit, auto UU, VFrag (&f)[2]) __attribute__((always_inline)) {
-    constexpr int uu = decltype(UU)::value;
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-      const unsigned a0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)(vunit + vlo[d]);
-      const unsigned a1 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)(vunit + vhi[d]);
-      if constexpr (uu == 0) {
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[d].lo) : "v"(a0));
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[d].hi) : "v"(a1));
-      } else {
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(f[d].lo) : "v"(a0));
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(f[d].hi) : "v"(a1));
-      }
-    }
-  };
-  auto v_wait2 = [&](VFrag (&f)[2]) __attribute__((always_inline)) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi));
-  };
-  auto v_op = [&](const VFrag& f) __attribute__((always_inline)) {
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    return __builtin_bit_cast(bf16x8, u32x4{f.lo[0], f.lo[1], f.hi[0], f.hi[1]});
-  };
-
-  // One pipelined body: softmax of unit u on s_cur -> p_cur;  s_next = QK^T of unit u + 1 (kunit);  O^T += P(u-1) V(u-1) (vunit).
-  auto unit = [&](auto HP, auto HN, auto ED, int u, const char* kunit, const char* vunit) __attribute__((always_inline)) {
-    constexpr bool HAS_PREV = decltype(HP)::value, HAS_NEXT = decltype(HN)::value, EDGE = decltype(ED)::value;
-    if (pend) {   // the previous body moved the reference point: O^T follows before this body's PV MFMAs (wave-uniform, rare)
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ot[d][r] *= alpha_p;
-    }
-    // fragment reads in two rounds (register pressure: all eight fragments at once cost the third wave per SIMD): k-slot group 0 of
-    // V and K steps 0, 1 up front, the rest under the exponentials
-    bf16x8 ka[2], kb[2];
-    VFrag vfa[2], vfb[2];   // [d-tile] of k-slot group 0 / 1
-    if constexpr (HAS_PREV) v_issue_uu(vunit, ap_int<0>{}, vfa);
-    if constexpr (HAS_NEXT) {
-#pragma unroll
-      for (int m = 0; m < 2; ++m) ka[m] = *(const bf16x8*)(kunit + kro[m]);
-    }
-    if constexpr (HAS_PREV) v_wait2(vfa);
-    if constexpr (EDGE) {   // last unit: keys past Lk never count (key of register r: 32 u + (r & 3) + 8 (r >> 2) + 4 hi)
-      const int lim = p.Lk - 32 * u - 4 * hi;
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if ((r & 3) + 8 * (r >> 2) >= lim) s_cur[r] = -INFINITY;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- ONE straight-line block from here to the end of the body (no branch: a conditional rescale in the middle makes the
-    // compiler sink every exponential below it and hoist every MFMA above it, i.e. the serial order again)
-    if constexpr (HAS_NEXT) s_next = mfma32x32x16_h<F16>(ka[0], qf[0], zero16);
-    if constexpr (HAS_PREV) ot[0] = mfma32x32x16_h<F16>(v_op(vfa[0]), p_prev[0], ot[0]);
-    // (v_max3_f32 by hand: through fmaxf the compiler puts a canonicalising v_max_f32 x, x in front of every accumulator it reads)
-    float tmax;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(s_cur[0]), "v"(s_cur[1]), "v"(s_cur[2]));
-#pragma unroll
-    for (int r = 3; r < 15; r += 2) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(tmax), "v"(s_cur[r]), "v"(s_cur[r + 1]));
-    asm("v_max_f32 %0, %1, %2" : "=v"(tmax) : "v"(tmax), "v"(s_cur[15]));
-    if constexpr (HAS_NEXT) s_next = mfma32x32x16_h<F16>(ka[1], qf[1], s_next);
-    tmax = ap_xhalf_max(tmax) * c;
-    // lazy reference point (see the kernel above), branch-free: it moves for the whole wave or not at all (practically only on
-    // the first unit); alpha = 1 exactly when it stays.  The row sum is rescaled at once, O^T at the top of the NEXT body.
-    const bool need = !__all(tmax <= mrun + 8.f);
-    const float mnew = need ? fmaxf(mrun, tmax) : mrun;
-    const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-    mrun = mnew;
-    lrun *= alpha;
-    pend = need;
-    alpha_p = alpha;
-    const f32x2 c2 = {c, c}, nm2 = {-mrun, -mrun};
-    f32x2 psum2 = {0.f, 0.f};
-    auto exps = [&](int uu, int half) __attribute__((always_inline)) {   // 4 of the 8 scores of k-slot group uu
-#pragma unroll
-      for (int r = 0; r < 4; r += 2) {
-        const int rr = 8 * uu + 4 * half + r;
-        const f32x2 x = __builtin_elementwise_fma(f32x2{s_cur[rr], s_cur[rr + 1]}, c2, nm2);
-        const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-        s_cur[rr] = e[0];
-        s_cur[rr + 1] = e[1];
-        psum2 += e;
-      }
-    };
-    auto pack = [&](int uu) __attribute__((always_inline)) {
-      f32x8 pv;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) pv[e] = s_cur[8 * uu + e];
-      if constexpr (F16) p_cur[uu] = __builtin_bit_cast(bf16x8, __builtin_convertvector(pv, f16x8));
-      else p_cur[uu] = __builtin_bit_cast(bf16x8, __builtin_convertvector(pv, bf16v8));
-    };
-    if constexpr (HAS_PREV) ot[1] = mfma32x32x16_h<F16>(v_op(vfa[1]), p_prev[0], ot[1]);
-    // second round of fragment reads (behind the four MFMAs that consumed the first)
-    if constexpr (HAS_PREV) v_issue_uu(vunit, ap_int<1>{}, vfb);
-    if constexpr (HAS_NEXT) {
-#pragma unroll
-      for (int m = 0; m < 2; ++m) kb[m] = *(const bf16x8*)(kunit + kro[2 + m]);
-    }
-    // phase 1 pinned: one MFMA, then its share of the maximum / reference-point arithmetic
-#pragma unroll
-    for (int g = 0; g < (HAS_PREV ? 2 : 0) + (HAS_NEXT ? 2 : 0); ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x402, (HAS_PREV && HAS_NEXT) ? 5 : 10, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    exps(0, 0);
-    exps(0, 1);
-    pack(0);
-    if constexpr (HAS_PREV) v_wait2(vfb);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (HAS_NEXT) s_next = mfma32x32x16_h<F16>(kb[0], qf[2], s_next);
-    if constexpr (HAS_PREV) ot[0] = mfma32x32x16_h<F16>(v_op(vfb[0]), p_prev[1], ot[0]);
-    exps(1, 0);
-    if constexpr (HAS_NEXT) s_next = mfma32x32x16_h<F16>(kb[1], qf[3], s_next);
-    exps(1, 1);
-    if constexpr (HAS_PREV) ot[1] = mfma32x32x16_h<F16>(v_op(vfb[1]), p_prev[1], ot[1]);
-    pack(1);
-    lrun += psum2[0] + psum2[1];
-    // (P is packed HERE: left alone the compiler sinks the conversions into the next body and keeps the 16 fp32 values alive
-    //  across the loop edge - 179 VGPRs, two waves per SIMD instead of three)
-    asm volatile("" : "+v"(p_cur[0]), "+v"(p_cur[1]));
-    // phase 3 pinned: one MFMA, then its share of the second half's exponentials
-    constexpr int NMF = (HAS_PREV ? 2 : 0) + (HAS_NEXT ? 2 : 0);
-#pragma unroll
-    for (int g = 0; g < NMF; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x402, NMF == 4 ? 6 : 12, 0);
-    }
-    p_prev[0] = p_cur[0];
-    p_prev[1] = p_cur[1];
-    if constexpr (HAS_NEXT) s_cur = s_next;
-  };
-  auto run_unit = [&](int u, const char* kunit, const char* vunit) __attribute__((always_inline)) {
-    if (u == 0) {
-      if (nu > 1) unit(ap_flag<false>{}, ap_flag<true>{}, ap_flag<false>{}, u, kunit, vunit);
-      else unit(ap_flag<false>{}, ap_flag<false>{}, ap_flag<true>{}, u, kunit, vunit);
-    } else if (u + 1 < nu) {
-      unit(ap_flag<true>{}, ap_flag<true>{}, ap_flag<false>{}, u, kunit, vunit);
-    } else {
-      unit(ap_flag<true>{}, ap_flag<false>{}, ap_flag<true>{}, u, kunit, vunit);
-    }
-  };
-
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-  q0 = cur.q0w;
-  const bool active = q0 < p.Lq;   // a wave whose 32 queries are all past Lq only helps staging (wave-uniform)
-  const __amdgpu_buffer_rsrc_t rsK = desc(cur.Kb, ldk_b), rsV = desc(cur.Vb, ldv_b);
-  const bool has_next = item + (int)gridDim.x < nitems;
-  const Item nxt = decode(has_next ? item + (int)gridDim.x : item);
-  {
-    const int l = ap_lane_now();
-    int qr = q0 + (l & 31);
-    qr = qr < p.Lq ? qr : p.Lq - 1;
-    const char* src = cur.Qb + (long)qr * p.ldq * 2 + (l >> 5) * 16;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) qf[m] = *(const bf16x8*)(src + m * 32);
-  }
-#pragma unroll
-  for (int d = 0; d < 2; ++d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
-  mrun = -1e30f; lrun = 0.f; pend = false; alpha_p = 1.f;
-  for (int s = 0; s < ns; ++s) {
-    stamp();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K stage s + 1 and V stage s (issued one stage ago) have landed
-    stamp();
-    __syncthreads();                                   // ... for every wave, and every wave is done with stage s - 1
-    stamp();
-    if (!(first_item && s == 0)) {   // (the first item's prologue already asked for these two)
-      if (s + 2 < ns) stage_k(rsK, s + 2, Kring + k2s * AP_SLOT);
-      if (s + 1 < ns) stage_v(rsV, s + 1, Vring + v1s * AP_SLOT);
-    }
-    if (s == ns - 1 && has_next) {   // last stage: the slots of (non-existent) stages s + 1, s + 2 take the next item's first stages
-      const __amdgpu_buffer_rsrc_t rsKn = desc(nxt.Kb, ldk_b), rsVn = desc(nxt.Vb, ldv_b);
-      stage_k(rsKn, 0, Kring + k1s * AP_SLOT);
-      stage_v(rsVn, 0, Vring + v1s * AP_SLOT);
-      if (ns > 1) stage_k(rsKn, 1, Kring + k2s * AP_SLOT);
-      // ... and one dword of every Q row of the next item is pulled towards L2 (the value is never read)
-      const int l = ap_lane_now();
-      int qr = nxt.q0w + (l & 31);
-      qr = qr < p.Lq ? qr : p.Lq - 1;
-      const char* qsrc = nxt.Qb + (long)qr * p.ldq * 2 + (l >> 5) * 64;
-      // (as LDS-DMA into a per-wave dump slot: a load with a VGPR destination would land in a register the compiler has long re-used)
-      __builtin_amdgcn_global_load_lds((gptr_t)qsrc, (lptr_t)(smem + AP_LDS + wave * 256), 4, 0, 0);
-    }
-    if (active) {
-      if (s == 0) qk_unit(Kring + k0s * AP_SLOT, s_cur);
-      const int u = 2 * s;
-      stamp();
-      // unit u: QK of unit u + 1 (second half of K stage s), PV of unit u - 1 (second half of V stage s - 1)
-      run_unit(u, Kring + k0s * AP_SLOT + 4096, Vring + vm1 * AP_SLOT + 4096);
-      stamp();
-      // unit u + 1: QK of unit u + 2 (first half of K stage s + 1), PV of unit u (first half of V stage s)
-      if (u + 1 < nu) run_unit(u + 1, Kring + k1s * AP_SLOT, Vring + v0s * AP_SLOT);
-    }
-    { const int t = k0s; k0s = k1s; k1s = k2s; k2s = t; }
-    { const int t = vm1; vm1 = v0s; v0s = v1s; v1s = t; }
-  }
-  stamp();
-  if (active) {   // PV of the last unit (its V stage is the one the loop left as "s - 1")
-    if (pend) {
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ot[d][r] *= alpha_p;
-    }
-    const char* vunit = Vring + vm1 * AP_SLOT + ((nu - 1) & 1) * 4096;
-    VFrag vf0[2], vf1[2];
-    v_issue(vunit, 0, vf0);
-    v_issue(vunit, 1, vf1);
-    v_wait(vf0, vf1);
-#pragma unroll
-    for (int uu = 0; uu < 2; ++uu) {
-      ot[0] = mfma32x32x16_h<F16>(v_op(vf0[uu]), p_prev[uu], ot[0]);
-      ot[1] = mfma32x32x16_h<F16>(v_op(vf1[uu]), p_prev[uu], ot[1]);
-    }
-  }
-  lrun = ap_xhalf_sum(lrun);
-  const float inv = 1.f / lrun;
-  {   // 16-byte stores after a half-wave exchange (see the kernel above)
-    const int l = ap_lane_now();
-    const int jj = l & 31, hh = l >> 5;
-    char* O = cur.Ob + (long)min(q0 + jj, p.Lq - 1) * p.ldo * 2;
-    const bool q_ok = q0 + jj < p.Lq;
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-      for (int gp = 0; gp < 2; ++gp) {
-        const u32x2_t a = pack4_h<F16>(f32x4{ot[d][8 * gp] * inv, ot[d][8 * gp + 1] * inv, ot[d][8 * gp + 2] * inv, ot[d][8 * gp + 3] * inv});
-        const u32x2_t c4 = pack4_h<F16>(f32x4{ot[d][8 * gp + 4] * inv, ot[d][8 * gp + 5] * inv, ot[d][8 * gp + 6] * inv, ot[d][8 * gp + 7] * inv});
-        const u32x2_t s0 = __builtin_amdgcn_permlane32_swap(a[0], c4[0], false, false);
-        const u32x2_t s1 = __builtin_amdgcn_permlane32_swap(a[1], c4[1], false, false);
-        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
-        const u32x4_ o = {s0[0], s1[0], s0[1], s1[1]};
-        if (q_ok) *(u32x4_*)(O + (d * 32 + 16 * gp + 8 * hh) * 2) = o;
-      }
-  }
-  cur = nxt;
-  first_item = false;
-  }   // next work item
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
+// (round 2 experiment, removed from the product library in round 3: a software-pipelined persistent form of the kernel above -
+// QK^T of unit u+1 | softmax of unit u | PV of unit u-1 as one instruction stream, K/V rings of three 64-key stages - was correct but
+// slower, 54.5-58.5 us against 48.0 us: with an exp-heavy vector mix the matrix and vector pipes of a SIMD do not run side by side
+// (tools/valu_mfma_probe.hip).  Source: git show 2cb8c78:edgecape_amd/csrc/ec_attn.hip.)
 
 // ------------------------------------------------------------------------------------------------
 // bf16x3 ("split") path for the HEAD's attentions in throughput mode (head_precision = EC_BF16X3): fp32 Q/K/V/O in memory,
@@ -1090,20 +658,6 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
   }
 }
 
-// persistent grid of the pipelined kernel: three workgroups (48 KiB of LDS, <= 168 VGPRs) per CU, per-device CU count
-struct ApDev { int ncu = 0; };
-ApDev ap_dev[64];
-int ap_grid(long nitems, int* grid) {
-  int dev = 0;
-  EC_HIP(hipGetDevice(&dev));
-  EC_REQUIRE(dev >= 0 && dev < 64, -1, "attention: device ordinal out of range");
-  if (!ap_dev[dev].ncu) EC_HIP(hipDeviceGetAttribute(&ap_dev[dev].ncu, hipDeviceAttributeMultiprocessorCount, dev));
-  static const bool one_per_item = getenv("EC_ATTN_PIPE") && atoi(getenv("EC_ATTN_PIPE")) == 2;   // 2: one workgroup per item
-  const long cap = one_per_item ? nitems : 3l * ap_dev[dev].ncu;
-  *grid = (int)(nitems < cap ? nitems : cap);
-  return 0;
-}
-
 }  // namespace
 
 int attention(const AttnP& p, hipStream_t st) {
@@ -1138,37 +692,6 @@ int attention(const AttnP& p, hipStream_t st) {
     EC_REQUIRE(p.hd == 64 && !p.kmask && !p.bias, -1, "attention(bf16): hd = 64, no mask / bias (backbone only)");
     EC_REQUIRE(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0, -1, "attention(bf16): stride alignment");
     static const bool trace = getenv("EC_ATTN_TRACE") != nullptr;
-    static const bool pipe_tr = getenv("EC_ATTN_PIPE") && atoi(getenv("EC_ATTN_PIPE")) != 0;
-    if (trace && !p.f16 && pipe_tr) {
-      unsigned* d_tr = nullptr;
-      EC_HIP(hipMalloc((void**)&d_tr, 4 * 128 * sizeof(unsigned)));
-      EC_HIP(hipMemsetAsync(d_tr, 0, 4 * 128 * sizeof(unsigned), st));
-      AttnP q = p;
-      q.bias = (const float*)d_tr;
-      int pg = 0;
-      if (ap_grid(grid.x * grid.y * grid.z, &pg) < 0) return -1;
-      hipLaunchKernelGGL((attn_pipe_kernel<false, true>), dim3(pg), dim3(256), AP_LDS_ALL, st, q);
-      EC_LAUNCH_CHECK();
-      EC_HIP(hipStreamSynchronize(st));
-      unsigned h[4 * 128];
-      EC_HIP(hipMemcpy(h, d_tr, sizeof(h), hipMemcpyDeviceToHost));
-      (void)hipFree(d_tr);
-      const int ns = (p.Lk + 63) / 64;
-      for (int w = 0; w < 4; ++w) {
-        const unsigned* r = h + w * 128;   // [0] start, then per stage: top, waited, barrier passed, (units start), unit u done
-        for (int it = 0; it < 3 && 1 + (it + 1) * (5 * ns + 1) < 127; ++it) {   // work items of the traced workgroup
-          const unsigned* ri = r + 1 + it * (5 * ns + 1);
-          if (!ri[0]) break;
-          fprintf(stderr, "[attn pipe trace] wave %d item %d: before %u", w, it, ri[0] - ri[-1]);
-          for (int s_ = 0; s_ < ns; ++s_) {
-            const unsigned* t = ri + 5 * s_;
-            fprintf(stderr, " | wait %u bar %u issue(+QK0) %u unit %u unit %u", t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4]);
-          }
-          fprintf(stderr, " | total %u\n", ri[5 * ns] - ri[-1]);
-        }
-      }
-      return 0;
-    }
     if (trace && !p.f16) {
       unsigned* d_tr = nullptr;
       EC_HIP(hipMalloc((void**)&d_tr, 4 * 128 * sizeof(unsigned)));
@@ -1194,14 +717,8 @@ int attention(const AttnP& p, hipStream_t st) {
       }
       return 0;
     }
-    static const bool pipe = getenv("EC_ATTN_PIPE") && atoi(getenv("EC_ATTN_PIPE")) != 0;   // 1 = the pipelined persistent experiment
     EC_REQUIRE((long)p.Lk * p.ldk * 2 < (1l << 31) && (long)p.Lk * p.ldv * 2 < (1l << 31), -1, "attention(bf16): K / V rows of one head beyond 2 GiB");
-    if (pipe) {
-      int pg = 0;
-      if (ap_grid(grid.x * grid.y * grid.z, &pg) < 0) return -1;
-      if (p.f16) hipLaunchKernelGGL((attn_pipe_kernel<true>), dim3(pg), dim3(256), AP_LDS_ALL, st, p);
-      else hipLaunchKernelGGL((attn_pipe_kernel<false>), dim3(pg), dim3(256), AP_LDS_ALL, st, p);
-    } else if (p.f16) hipLaunchKernelGGL((attn_bf16_kernel<false, true>), grid, dim3(256), A16_LDS, st, p);
+    if (p.f16) hipLaunchKernelGGL((attn_bf16_kernel<false, true>), grid, dim3(256), A16_LDS, st, p);
     else hipLaunchKernelGGL((attn_bf16_kernel<false, false>), grid, dim3(256), A16_LDS, st, p);
     EC_LAUNCH_CHECK();
     return 0;

@@ -173,9 +173,6 @@ void split_pack_weights(const float* W, long n_rows, long K, float* out);
 void split_pack_weights_h1(const float* W, long n_rows, long K, float* out);   // [32 fp16 | 32 x 0] per 32-k block
 // 256x256x64 8-phase bf16 kernel (ec_gemm8.hip): 1 = handled, 0 = shape not eligible (use gemm_nt's own kernels), < 0 error
 int gemm8_bf16(const GemmP& p, hipStream_t st);
-// 256x256x64 four-wave kernel, one wave per SIMD, stores of a tile under the next tile's K loop (ec_gemm4.hip): same return contract;
-// 16-bit outputs with bias (+ LayerScale | GELU) only
-int gemm4_h16(const GemmP& p, hipStream_t st);
 
 // Small batched fp32 GEMM on the vector ALU (ec_gemm.hip): C[b] = alpha * A[b] @ op(B[b]) + beta * C[b]
 // transB = 1: B is [N,K] (NT); transB = 0: B is [K,N] (NN).  Arbitrary sizes/strides.

@@ -556,9 +556,7 @@ int gemm_nt(const GemmP& p, hipStream_t st) {
   EC_REQUIRE(p.act != ACT_TANHGATE || p.aux, -1, "gemm_nt: tanh-gate epilogue needs aux");
   EC_REQUIRE(p.tag >= 0 && p.tag < 5, -1, "gemm_nt: bad tag");
   EC_REQUIRE(!(p.split && p.ab_bf16), -1, "gemm_nt: split (bf16x3) mode takes fp32 A and a pre-split B");
-  if (p.ab_bf16) {   // large 16-bit problems: the four-wave 256x256x64 kernel (block GEMMs of the backbone), else the 8-phase kernel
-    const int rc4 = gemm4_h16(p, st);
-    if (rc4 != 0) return rc4 < 0 ? rc4 : 0;
+  if (p.ab_bf16) {   // large 16-bit problems: the 8-phase 256x256x64 kernel (block GEMMs of the backbone)
     const int rc = gemm8_bf16(p, st);
     if (rc != 0) return rc < 0 ? rc : 0;
   }

@@ -71,21 +71,57 @@ enum { G8_GENERIC = 0, G8_BIAS_BF16 = 1, G8_SCALE_BF16 = 2, G8_GELU_BF16 = 3 };
 // form (nn.GELU default, dinov2 Mlp) on |x| <= 9.  bf16 outputs: degree 2 in x^2, max |err| 2.5e-5 (far below the bf16 rounding
 // of the result), 6 plain VALU ops + exp2 + rcp per element (the epilogue of fc1 is VALU-bound: 128 GELUs per lane per tile).
 // fp16 outputs carry three more significand bits: degree 4, max |err| 3.0e-6 (two more FMAs).
-template <bool F16>
+// The degree-4 polynomial needs no clamp: its leading coefficient is negative, P(s) < -100 for every s > 81 (x * P -> -/+ inf,
+// 2^ -> 0 / inf, rcp -> 1 / 0: the exact limits); the degree-2 one grows positive past s = 105 and keeps the clamp.
+// GV (lab builds only; 0 in the shipped library): 1 = the degree-2 polynomial for fp16 outputs too, 2 = see gelu4_pk below.
+template <bool F16, int GV = 0>
 __device__ __forceinline__ float gelu_fast8(float x) {
-  const float s = fminf(x * x, 81.f);
   float q;
-  if constexpr (F16) {
+  if constexpr (F16 && GV != 1) {
+    const float s = x * x;
     q = fmaf(-3.229071e-06f, s, 8.82395e-05f);
     q = fmaf(q, s, 3.6026796e-04f);
     q = fmaf(q, s, -1.0522668e-01f);
     q = fmaf(q, s, -2.3020453e+00f);
   } else {
+    const float s = fminf(x * x, 81.f);
     q = fmaf(1.01453915e-03f, s, -1.06777424e-01f);
     q = fmaf(q, s, -2.30111947e+00f);
   }
   const float e = __builtin_amdgcn_exp2f(x * q);
   return x * __builtin_amdgcn_rcpf(1.f + e);
+}
+
+// Lab variant GV = 2: the polynomial of TWO elements in packed fp16 (v_pk_mul_f16 / v_pk_min_f16 / 2 x v_pk_fma_f16: full rate, two
+// elements per lane), its fp16 value multiplied into the fp32 argument by v_fma_mix_f32 (no conversion instruction); exp2, rcp and the
+// products with x stay fp32.  q carries ~1e-3 relative error: |d Phi| <= 2.2e-4 (at |x| ~ 0.9).
+typedef _Float16 ec_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu2_pk(float& x0, float& x1) {
+  ec_h2 xh;
+  xh[0] = (_Float16)x0; xh[1] = (_Float16)x1;
+  const ec_h2 c81 = {(_Float16)81.f, (_Float16)81.f};
+  const ec_h2 s = __builtin_elementwise_min(xh * xh, c81);
+  const ec_h2 c2 = {(_Float16)1.01453915e-03f, (_Float16)1.01453915e-03f}, c1 = {(_Float16)-1.06777424e-01f, (_Float16)-1.06777424e-01f},
+              c0 = {(_Float16)-2.30111947e+00f, (_Float16)-2.30111947e+00f};
+  ec_h2 q = __builtin_elementwise_fma(c2, s, c1);
+  q = __builtin_elementwise_fma(q, s, c0);
+  float y0, y1;
+  asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(y0) : "v"(q), "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(y1) : "v"(q), "v"(x1));
+  x0 = x0 * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(y0));
+  x1 = x1 * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(y1));
+}
+template <bool F16, int GV>
+__device__ __forceinline__ void gelu4(f32x4& v) {
+  if constexpr (GV == 2) {
+    float a = v[0], b = v[1], c = v[2], d = v[3];
+    gelu2_pk(a, b);
+    gelu2_pk(c, d);
+    v = f32x4{a, b, c, d};
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = gelu_fast8<F16, GV>(v[e]);
+  }
 }
 
 // acc[mi][ni] (f32x4) of lane l: row m = m0 + wr*128 + mi*16 + (l&15),
@@ -152,10 +188,7 @@ __device__ __forceinline__ void g8_piece(f32x4 (&a)[4], const __amdgpu_buffer_rs
   for (int ni = 0; ni < 4; ++ni) {
     const int c0 = (ni >> 1) * 32 + (ni & 1) * 16 + wq * 4;         // first of this lane's 4 columns inside the wave's 64
     f32x4 v = a[ni] + *(const f32x4*)(bias_lds + c0 * 4);
-    if constexpr (KIND == G8_GELU_BF16) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = gelu_fast8<F16>(v[e]);
-    }
+    if constexpr (KIND == G8_GELU_BF16) gelu4<F16, (LAB >> 9) & 3>(v);
     if constexpr (KIND == G8_SCALE_BF16) v *= *(const f32x4*)(gam_lds + c0 * 4);
     const int chunk = (ni >> 1) * 4 + (ni & 1) * 2 + (wq >> 1);
     *(u32x2*)(stg + wrow * 128 + ((chunk ^ (wrow & 7)) << 4) + (wq & 1) * 8) = pack4_h<F16>(v);   // 2 x v_cvt_pk (RNE)
@@ -188,10 +221,7 @@ __device__ __forceinline__ void g8_piece_reg(f32x4 (&a)[4], const __amdgpu_buffe
   for (int ni = 0; ni < 4; ++ni) {
     const int c0 = (ni >> 1) * 32 + (ni & 1) * 16 + wq * 4;
     f32x4 v = a[ni] + *(const f32x4*)(bias_lds + c0 * 4);
-    if constexpr (KIND == G8_GELU_BF16) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = gelu_fast8<F16>(v[e]);
-    }
+    if constexpr (KIND == G8_GELU_BF16) gelu4<F16, (LAB >> 9) & 3>(v);
     if constexpr (KIND == G8_SCALE_BF16) v *= *(const f32x4*)(gam_lds + c0 * 4);
     pk[ni] = pack4_h<F16>(v);
     a[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -257,11 +287,15 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
 
   // XCD-aware persistent schedule: workgroup b runs on XCD b % 8 (observed, speed only); XCD x walks the contiguous tile
   // range [x*chunk, (x+1)*chunk) (row-major, n fastest) so the tiles in flight on one L2 share operand panels.
-  const int nxcd = (gridDim.x >= 8 && gridDim.x % 8 == 0) ? 8 : 1;
-  const int chunk = (ntiles + nxcd - 1) / nxcd;
-  const int xcd = blockIdx.x % nxcd, slot = blockIdx.x / nxcd, nslot = gridDim.x / nxcd;
-  const int t_end = min(ntiles, (xcd + 1) * chunk);
-  const int t_first = xcd * chunk + slot;
+  // (round 3: for ANY grid size - the N = 768 shapes have 246 tiles = 246 workgroups, and the former "grid % 8 == 0" condition sent
+  // their three column tiles of one A panel to three different XCDs.)  XCD x owns the workgroups b = x, x + 8, ... (nslot of them)
+  // and the share of the tile list proportional to that count.
+  const int nxcd = gridDim.x >= 8 ? 8 : 1;
+  const int gq = gridDim.x / nxcd, gr = gridDim.x % nxcd;
+  const int xcd = blockIdx.x % nxcd, slot = blockIdx.x / nxcd, nslot = gq + (xcd < gr ? 1 : 0);
+  const int w0 = xcd * gq + min(xcd, gr);                                // workgroups on the XCDs before this one
+  const int t_begin = (int)((long)ntiles * w0 / gridDim.x), t_end = (int)((long)ntiles * (w0 + nslot) / gridDim.x);
+  const int t_first = t_begin + slot;
   if (t_first >= t_end) return;                 // whole workgroup leaves: no barrier has been executed yet
 
   // ---- load stream (LDS-DMA) state -------------------------------------------------------------------------------
@@ -275,6 +309,10 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)(((unsigned)(p.M - 1) * (unsigned)p.lda + (unsigned)p.K) * 2u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)(((unsigned)(p.N - 1) * (unsigned)p.ldb + (unsigned)p.K) * 2u), 0x00020000);
   unsigned vo0, vo1, vo2, vo3;                       // A-h0, B-h0, B-h1, A-h1: byte offset of this lane's row (+ chunk)
+  // (round 3, measured and removed: a per-tile ROTATION of the K walk, so that the workgroups sharing an operand panel are at
+  // different K positions, and a start stagger over the slots.  Neither changes FETCH_SIZE / TCC_MISS on any of the four block
+  // shapes - workgroups that request the same line in lock-step are merged by the L2 - and rotation costs 3-17 % of the time
+  // because it widens the working set; profiles/r03_g8_sched_sweep.txt, r03_g8_sched_pmc.csv.)
   int ls_kt = 0, ls_tile = t_first;
   auto set_rows = [&](int t) {
     const int m0 = (LAB & 2) ? 0 : (t / ntn) << 8, n0 = (LAB & 2) ? 0 : (t % ntn) << 8;
@@ -580,17 +618,24 @@ extern "C" int ec_lab_gemm8(const void* A, const void* W, const float* bias, voi
     case 65: k = gemm8_bf16_kernel<1, 1, false, 65>; break;
     case 100: k = gemm8_bf16_kernel<3, 3, false, 0>; break;     // fc1 + GELU, pipelined
     case 164: k = gemm8_bf16_kernel<3, 3, false, 64>; break;    // fc1 + GELU, epilogue at the end of the tile
+    case 1000: k = gemm8_bf16_kernel<1, 1, true, 0>; break;     // the shipped fp16 instantiations: qkv / proj (bias)
+    case 2000: k = gemm8_bf16_kernel<2, 4, true, 0>; break;     // fc2 / proj with LayerScale (gamma = the bias vector here)
+    case 3000: k = gemm8_bf16_kernel<3, 3, true, 0>; break;     // fc1 + GELU
+    case 3512: k = gemm8_bf16_kernel<3, 3, true, 512>; break;   // ... degree-2 polynomial
+    case 4024: k = gemm8_bf16_kernel<3, 3, true, 1024>; break;  // ... packed-fp16 polynomial
     default: set_error("ec_lab_gemm8: variant not instantiated"); return -1;
   }
   hipStream_t st = (hipStream_t)stream;
   EC_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));
   GemmP p;
   p.A = A; p.B = W; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N; p.ab_bf16 = 1; p.c_bf16 = 1;
+  p.gamma = bias;
   int dev = 0, ncu = 0;
   EC_HIP(hipGetDevice(&dev));
   EC_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
   const long ntiles = (long)((M + 255) / 256) * ((N + 255) / 256);
-  const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);
+  unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);
+  if (getenv("EC_G8_GRID") && atoi(getenv("EC_G8_GRID")) > 0 && (unsigned)atoi(getenv("EC_G8_GRID")) < grid) grid = (unsigned)atoi(getenv("EC_G8_GRID"));
   hipEvent_t e0, e1;
   EC_HIP(hipEventCreate(&e0));
   EC_HIP(hipEventCreate(&e1));

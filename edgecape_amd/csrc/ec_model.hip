@@ -980,14 +980,10 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
 
   // (4) encoder (encoder_decoder.py:276-310, 461-483) over [bs, L = HW + K, d]
   const int Me = bs * L;
-  bool enc_qkv_ready = false;   // the previous layer's row chain already produced src + pos and this layer's in-proj
   for (size_t i = 0; i < m->enc.size(); ++i) {
     const EncLayer& e = m->enc[i];
-    if (!enc_qkv_ready) {
-      RUN(add_table(m->e_x, d, m->pos_cat, d, L, Me, d, st));   // src = src + pos, every layer, feeds q,k,v
-      RUN(linear(m->e_x, d, false, e.in, m->e_qkv, 3 * d, false, Me, ACT_NONE, st));
-    }
-    enc_qkv_ready = false;
+    RUN(add_table(m->e_x, d, m->pos_cat, d, L, Me, d, st));   // src = src + pos, every layer, feeds q,k,v
+    RUN(linear(m->e_x, d, false, e.in, m->e_qkv, 3 * d, false, Me, ACT_NONE, st));
     AttnP a;
     a.Q = m->e_qkv; a.K = m->e_qkv + d; a.V = m->e_qkv + 2 * d; a.O = m->e_att;
     a.ldq = a.ldk = a.ldv = 3 * d; a.ldo = d;
@@ -996,41 +992,10 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     a.B = bs; a.H = nh; a.Lq = L; a.Lk = L; a.hd = d / nh;
     a.split = m->head_split ? 1 : 0;   // head throughput mode: bf16x3 MFMAs
     RUN(attention(a, st));
-    // The row-wise rest of the layer (encoder_decoder.py:470-483) as ONE row chain: x1 = norm1(x + out_proj(att)); y = relu(linear1(x1));
-    // x = norm2(x1 + linear2(y)) (+ pos -> the next layer's in-proj).  x1 stays in registers (keep) and LDS, y [32, F] in LDS; att is
-    // staged into y's buffer (dead by then).  EXPERIMENT behind EC_ENC_CHAIN=1 (round 2): 7 launches per layer become 2 and the encoder
-    // alone gets 25-30 % faster (serial head 2 340 vs 2 417 us), but 424 CU-filling workgroups of ~80 us each starve the support lane
-    // beside it (S.end 1 380 vs 1 340 us), which is the critical one: the step is 0.5-1 % SLOWER (6.70-6.82 vs 6.63-6.73 ms, same box).
-    static const bool enc_chain_on = getenv("EC_ENC_CHAIN") && atoi(getenv("EC_ENC_CHAIN")) != 0;
-    const bool enc_chain = enc_chain_on && m->head_chain && chain_ok(e.out) && chain_ok(e.l1) && chain_ok(e.l2) && e.out.K == d &&
-                           e.l1.K == d && e.l2.N == d && CH_LDS0 + chain_layout_bytes(Fd) + chain_layout_bytes(d) <= 160 * 1024;
-    if (enc_chain) {
-      ChainBuild cb;
-      const int by = cb.buf(Fd), bx = cb.buf(d);
-      ChainStage& A = cb.add();
-      chain_lin(A, e.out);
-      A.g_in = m->e_att; A.ld_in = d; A.g_k = d; A.g_off = by; A.a_off = by;
-      A.resid = m->e_x; A.ldr = d; A.ln_w = e.n1.w; A.ln_b = e.n1.b; A.eps = 1e-5f;
-      A.s_off = bx; A.keep = 1;
-      ChainStage& B = cb.add();
-      chain_lin(B, e.l1);
-      B.a_off = bx; B.act = ACT_RELU; B.s_off = by;
-      ChainStage& Cc = cb.add();
-      chain_lin(Cc, e.l2);
-      Cc.a_off = by; Cc.resid_keep = 1; Cc.ln_w = e.n2.w; Cc.ln_b = e.n2.b; Cc.eps = 1e-5f;
-      Cc.out = m->e_x; Cc.ldo = d;
-      if (i + 1 < m->enc.size() && chain_ok(m->enc[i + 1].in) && m->enc[i + 1].in.K == d) {
-        // ... and the head of the next layer: src = x + pos (stored, and the operand of) its self-attention in-proj
-        Cc.post_table = m->pos_cat; Cc.ldpt = d; Cc.post_period = L;
-        Cc.s_off = bx;
-        ChainStage& D = cb.add();
-        chain_lin(D, m->enc[i + 1].in);
-        D.a_off = bx;
-        D.out = m->e_qkv; D.ldo = 3 * d;
-        enc_qkv_ready = true;
-      }
-      RUN(cb.run(Me, st));
-    } else {
+    // The row-wise rest of the layer (encoder_decoder.py:470-483) as separate launches.  (Round 2 ran it as ONE row chain behind a
+    // switch: the encoder alone got 25-30 % faster, but its 424 CU-filling workgroups of ~80 us starved the support lane beside it,
+    // which is the critical one - the step was 0.5-1 % slower; removed in round 3)
+    {
       RUN(linear(m->e_att, d, false, e.out, m->e_tmp, d, false, Me, ACT_NONE, st, nullptr, m->e_x, d));
       RUN(ln(m->e_tmp, d, m->e_x, d, false, e.n1, Me, d, 1e-5f, st));
       RUN(linear(m->e_x, d, false, e.l1, m->e_h, Fd, false, Me, ACT_RELU, st));
@@ -1723,6 +1688,38 @@ int ec_preprocess_images(const uint8_t* const* src_dev, const int32_t* src_hw, c
     }
     for (int c = 0; c < 3; ++c) { pb.mean[c] = mean[c]; pb.stdv[c] = stdv[c]; }
     RUN(preprocess_affine(pb, nb, out_dev + (size_t)i0 * 3 * out_size * out_size, out_size, st));
+  }
+  return EC_OK;
+}
+
+// cv::warpAffine's inversion of the src -> dst matrix (no WARP_INVERSE_MAP), float64, every operation rounded on its own
+static void cv2_invert_affine(const double* M, double* out) {
+#pragma clang fp contract(off)
+  double D = M[0] * M[4] - M[1] * M[3];
+  D = D != 0 ? 1. / D : 0;
+  const double A11 = M[4] * D, A22 = M[0] * D;
+  const double m0 = A11, m1 = M[1] * (-D), m3 = M[3] * (-D), m4 = A22;
+  const double b1 = -m0 * M[2] - m1 * M[5];
+  const double b2 = -m3 * M[2] - m4 * M[5];
+  out[0] = m0; out[1] = m1; out[2] = b1; out[3] = m3; out[4] = m4; out[5] = b2;
+}
+
+int ec_preprocess_images_cv2(const uint8_t* const* src_dev, const int32_t* src_hw, const int64_t* src_pitch, const double* fwd_affine,
+                             int n, int out_size, const float* mean, const float* stdv, float* out_dev, void* stream) {
+  EC_REQUIRE(src_dev && src_hw && fwd_affine && mean && stdv && out_dev && n > 0 && out_size > 0, EC_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  for (int i0 = 0; i0 < n; i0 += 16) {
+    PreprocBatchCv2 pb;
+    const int nb = std::min(16, n - i0);
+    for (int i = 0; i < nb; ++i) {
+      EC_REQUIRE(src_dev[i0 + i] && src_hw[2 * (i0 + i)] > 0 && src_hw[2 * (i0 + i) + 1] > 0, EC_ERR_ARG, "bad source image");
+      pb.src[i] = src_dev[i0 + i];
+      pb.hs[i] = src_hw[2 * (i0 + i)]; pb.ws[i] = src_hw[2 * (i0 + i) + 1];
+      pb.pitch[i] = src_pitch ? src_pitch[i0 + i] : (long)pb.ws[i] * 3;
+      cv2_invert_affine(fwd_affine + 6 * (size_t)(i0 + i), pb.minv[i]);
+    }
+    for (int c = 0; c < 3; ++c) { pb.mean[c] = mean[c]; pb.stdv[c] = stdv[c]; }
+    RUN(preprocess_affine_cv2(pb, nb, out_dev + (size_t)i0 * 3 * out_size * out_size, out_size, st));
   }
   return EC_OK;
 }

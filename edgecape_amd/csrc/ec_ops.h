@@ -50,6 +50,14 @@ struct PreprocBatch {
   float mean[3], stdv[3];
 };
 int preprocess_affine(const PreprocBatch& pb, int n, float* out, int H, hipStream_t st);
+struct PreprocBatchCv2 {
+  const unsigned char* src[16];
+  long pitch[16];
+  int hs[16], ws[16];
+  double minv[16][6];             // dst -> src affine in float64, inverted on the host exactly as cv::warpAffine does
+  float mean[3], stdv[3];
+};
+int preprocess_affine_cv2(const PreprocBatchCv2& pb, int n, float* out, int H, hipStream_t st);
 struct MsraP {
   int hm, tmp;        // heatmap side, 3 * sigma
   double stride;      // image_size / heatmap_size (float64 in the reference)

@@ -738,6 +738,53 @@ __global__ __launch_bounds__(256) void preprocess_affine_kernel(PreprocBatch pb,
   for (int c = 0; c < 3; ++c) o[(long)c * H * H] = (acc[c] * (1.f / 255.f) - pb.mean[c]) / pb.stdv[c];
 }
 
+// The same stage with cv2.warpAffine's OWN arithmetic (uint8 source, INTER_LINEAR, BORDER_CONSTANT 0; OpenCV imgwarp.cpp
+// WarpAffineInvoker + remapBilinear, the classic fixed-point path): source coordinates in 1/1024 px from float64 products rounded
+// half-to-even (cvRound), + 16, >> 5 -> 1/32 px; the four taps weighted by (32 - fy | fy) * (32 - fx | fx) * 32 (the int16 table
+// BilinearTab_i, sum 32768), (sum + 2^14) >> 15 saturated to uint8; then ToTensor / NormalizeTensor in their float32 arithmetic
+// ((u8 / 255 - mean) / std with IEEE divisions).  Bit-exact against oracle/pipeline_oracle.py cv2_warp_affine_linear_u8.
+__global__ __launch_bounds__(256) void preprocess_affine_cv2_kernel(PreprocBatchCv2 pb, float* out, int H) {
+  const int img = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= H * H) return;
+  const int y = i / H, x = i - y * H;
+  const double* M = pb.minv[img];
+  // every product and sum rounded on its own (no FMA contraction), as the host code of OpenCV evaluates them
+  const double xd = (double)x, yd = (double)y;
+  const long ad = (long)__builtin_rint(__dmul_rn(__dmul_rn(M[0], xd), 1024.0));
+  const long bd = (long)__builtin_rint(__dmul_rn(__dmul_rn(M[3], xd), 1024.0));
+  const long X0 = (long)__builtin_rint(__dmul_rn(__dadd_rn(__dmul_rn(M[1], yd), M[2]), 1024.0)) + 16;
+  const long Y0 = (long)__builtin_rint(__dmul_rn(__dadd_rn(__dmul_rn(M[4], yd), M[5]), 1024.0)) + 16;
+  const long X = (X0 + ad) >> 5, Y = (Y0 + bd) >> 5;
+  const long sxl = X >> 5, syl = Y >> 5;
+  const int sx = (int)(sxl < -32768 ? -32768 : sxl > 32767 ? 32767 : sxl);       // saturate_cast<short>
+  const int sy = (int)(syl < -32768 ? -32768 : syl > 32767 ? 32767 : syl);
+  const int fx = (int)(X & 31), fy = (int)(Y & 31);
+  const int Hs = pb.hs[img], Ws = pb.ws[img];
+  const unsigned char* src = pb.src[img];
+  const long pitch = pb.pitch[img];
+  int acc[3] = {0, 0, 0};
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int xx = sx + dx, yy = sy + dy;
+      const int w = (dy ? fy : 32 - fy) * (dx ? fx : 32 - fx) * 32;
+      if (xx >= 0 && xx < Ws && yy >= 0 && yy < Hs) {
+        const unsigned char* px = src + (long)yy * pitch + (long)xx * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] += w * (int)px[c];
+      }
+    }
+  float* o = out + (long)img * 3 * H * H + (long)y * H + x;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    int v = (acc[c] + (1 << 14)) >> 15;
+    v = v < 0 ? 0 : v > 255 ? 255 : v;
+    o[(long)c * H * H] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)v, 255.f), pb.mean[c]), pb.stdv[c]);
+  }
+}
+
 __global__ __launch_bounds__(256) void msra_target_kernel(const float* joints, const float* visible, float* target, float* weight,
                                                           MsraP mp) {
   // one workgroup per (sample, keypoint): zero the hm x hm map, then paste the in-bounds part of the (2*3*sigma+1)^2 gaussian
@@ -769,6 +816,12 @@ int gather_rows(float* dst, const float* src, const int32_t* idx_dev, long row, 
 
 int preprocess_affine(const PreprocBatch& pb, int n, float* out, int H, hipStream_t st) {
   hipLaunchKernelGGL(preprocess_affine_kernel, dim3(cdiv((long)H * H, 256), n), dim3(256), 0, st, pb, out, H);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int preprocess_affine_cv2(const PreprocBatchCv2& pb, int n, float* out, int H, hipStream_t st) {
+  hipLaunchKernelGGL(preprocess_affine_cv2_kernel, dim3(cdiv((long)H * H, 256), n), dim3(256), 0, st, pb, out, H);
   EC_LAUNCH_CHECK();
   return 0;
 }

@@ -16,28 +16,43 @@ IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
-def get_affine_transform(center, scale, rot, output_size, shift=(0., 0.), inv=False):
-    """The 2x3 matrix of the reference's crop warp (post_transforms.py:197-252), in closed form.
+def _triangle(p0, p1):
+    """[p0, p1, p1 rotated a quarter turn about... ] as the reference's float32 3-point set: the third point is p1 + perp(p0 - p1),
+    every coordinate rounded to float32 when it is stored (post_transforms.py:49-57, _get_3rd_point :83-102)."""
+    t = np.zeros((3, 2), np.float32)
+    t[0], t[1] = p0, p1
+    d = t[0] - t[1]                                   # float32 arithmetic on the rounded points, as in the reference
+    t[2] = t[1] + np.array([-d[1], d[0]], np.float32)
+    return t
 
-    The reference builds three point pairs - the (shifted) box centre, a point half a box width "above" it rotated by `rot`, and
-    a third obtained by a quarter turn of that segment - maps them to the output centre, the point half an OUTPUT width above it
-    and its quarter turn, and lets cv2.getAffineTransform solve for the matrix.  Both triangles are right isosceles with the
-    same orientation, so the solution is the similarity
-        q = s * R(-rot) * (p - c) + d0,     s = output_w / (200 * scale_x),  c = center + 200 * scale * shift,  d0 = output / 2
-    (pixel_std = 200).  inv=True returns the inverse map p = R(rot) * (q - d0) / s + c (the reference swaps the triangles)."""
-    center, scale = np.asarray(center, np.float64), np.asarray(scale, np.float64)
+
+def _solve_affine(src, dst):
+    """cv2.getAffineTransform: the 2x3 matrix with M @ [x, y, 1] = [u, v] for three point pairs, solved in float64 from the
+    float32 points (OpenCV converts to double and solves the 6x6 system; the two rows decouple into two 3x3 systems)."""
+    A = np.concatenate([src.astype(np.float64), np.ones((3, 1))], 1)
+    return np.linalg.solve(A, dst.astype(np.float64)).T
+
+
+def get_affine_transform(center, scale, rot, output_size, shift=(0., 0.), inv=False):
+    """The 2x3 matrix of the reference's crop warp (post_transforms.py:197-252), with the reference's arithmetic.
+
+    Three point pairs - the (shifted) box centre, the point half a box width "above" it rotated by `rot`, and the quarter turn of
+    that segment - are mapped to the output centre, the point half an OUTPUT width above it and its quarter turn (pixel_std = 200).
+    The points are stored as float32 exactly where the reference stores them, then solved in float64 as cv2.getAffineTransform
+    does: the matrix equals the reference's to rounding of the solve (~1e-12), so a joint warped by it lands in the same heatmap
+    cell.  (The triangles are right isosceles, i.e. the map is the similarity q = s R(-rot)(p - c) + d0 with s = output_w /
+    (200 scale_x); the closed form differs from the reference by the float32 rounding of the points, up to ~5e-3 px.)"""
+    center, scale = np.asarray(center), np.asarray(scale)
     assert center.shape == (2,) and scale.shape == (2,) and len(output_size) == 2 and len(shift) == 2
     box = scale * 200.0
-    c = center + box * np.asarray(shift, np.float64)
+    th = np.pi * rot / 180
+    sn, cs = np.sin(th), np.cos(th)
+    up = -0.5 * box[0]                                            # (0, up) rotated by `rot`
+    c = center + box * np.asarray(shift)
+    src = _triangle(c, c + np.array([-up * sn, up * cs]))
     d0 = np.array([output_size[0] * 0.5, output_size[1] * 0.5])
-    s = output_size[0] / box[0]
-    th = np.pi * rot / 180.0
-    cs, sn = np.cos(th), np.sin(th)
-    if inv:
-        L = np.array([[cs, -sn], [sn, cs]]) / s          # R(rot) / s
-        return np.concatenate([L, (c - L @ d0)[:, None]], 1)
-    L = np.array([[cs, sn], [-sn, cs]]) * s              # s * R(-rot)
-    return np.concatenate([L, (d0 - L @ c)[:, None]], 1)
+    dst = _triangle(d0, d0 + np.array([0., output_size[0] * -0.5]))
+    return _solve_affine(dst, src) if inv else _solve_affine(src, dst)
 
 
 def warp_points(pts, trans_mat):
@@ -61,9 +76,12 @@ def gaussian_7x7(sigma=1):
     return np.exp(-((x - x0) ** 2 + (y - y0) ** 2) / (2 * sigma ** 2)).astype(np.float32)
 
 
-def preprocess_images(images, centers, scales, image_size, rotations=None, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+def preprocess_images(images, centers, scales, image_size, rotations=None, mean=IMAGENET_MEAN, std=IMAGENET_STD, interpolation="cv2"):
     """images: list of RGB uint8 HWC arrays/tensors (any sizes).  Returns (img [n,3,S,S] fp32 cuda, trans list of 2x3
-    src->dst matrices for warping the keypoints with `affine_transform`)."""
+    src->dst matrices for warping the keypoints with `affine_transform`).
+
+    interpolation="cv2" (default): the reference's pixels - cv2.warpAffine's fixed-point INTER_LINEAR on uint8, rounded to uint8,
+    then ToTensor / NormalizeTensor (ec_preprocess_images_cv2).  "float": exact float bilinear on un-rounded values."""
     lib = _lib.load()
     n = len(images)
     dev = [torch.as_tensor(np.ascontiguousarray(im) if isinstance(im, np.ndarray) else im).to("cuda", torch.uint8).contiguous()
@@ -77,8 +95,15 @@ def preprocess_images(images, centers, scales, image_size, rotations=None, mean=
     out = torch.empty(n, 3, image_size, image_size, device="cuda")
     ptrs = (C.c_void_p * n)(*[d.data_ptr() for d in dev])
     m, s = np.asarray(mean, np.float32), np.asarray(std, np.float32)
-    _lib.check(lib.ec_preprocess_images(ptrs, hw.ctypes.data, None, inv.ctypes.data, n, image_size, m.ctypes.data, s.ctypes.data,
-                                        out.data_ptr(), _lib.current_stream()))
+    if interpolation == "cv2":
+        fwd = np.ascontiguousarray(np.stack(trans).reshape(n, 6), np.float64)
+        _lib.check(lib.ec_preprocess_images_cv2(ptrs, hw.ctypes.data, None, fwd.ctypes.data, n, image_size, m.ctypes.data, s.ctypes.data,
+                                                out.data_ptr(), _lib.current_stream()))
+    elif interpolation == "float":
+        _lib.check(lib.ec_preprocess_images(ptrs, hw.ctypes.data, None, inv.ctypes.data, n, image_size, m.ctypes.data, s.ctypes.data,
+                                            out.data_ptr(), _lib.current_stream()))
+    else:
+        raise ValueError("interpolation must be 'cv2' or 'float'")
     torch.cuda.current_stream().synchronize()      # `dev`, `inv` are released on return
     return out, trans
 

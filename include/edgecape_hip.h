@@ -149,14 +149,24 @@ int ec_forward_cached(ec_handle h, ec_support_t s, const float* img_q_dev, const
  *   119-125) for n RGB uint8 HWC images already on the device: src_dev = host array of n device pointers, src_hw = host
  *   [n,2] (rows, cols), src_pitch = host [n] row pitches in bytes or NULL (= cols*3), inv_affine = host [n,6] dst->src 2x3
  *   matrices (get_affine_transform(center, scale, rot, size, inv=True)), out_dev [n,3,out_size,out_size] fp32.
- *   Interpolation is exact float bilinear; cv2 quantises the source coordinate to 1/32 px (third-party, absent here:
- *   parity unpinned).
+ *   Interpolation is exact float bilinear on un-rounded pixel values (NOT what cv2 computes: see ec_preprocess_images_cv2,
+ *   the default of edgecape_amd.preprocess).
  * ec_msra_targets = TopDownGenerateTargetFewShot._msra_generate_target, biased branch (top_down_transform.py:165-194):
  *   joints_dev [n,K,2] model-input pixels, visible_dev [n,K] -> target_dev [n,K,hm,hm], weight_dev [n,K]; gauss_host = the
  *   7x7 float32 gaussian computed on the host as the reference does (np.exp on float32), so the result is bit-exact. */
 int ec_preprocess_images(const uint8_t* const* src_dev, const int32_t* src_hw, const int64_t* src_pitch,
                          const float* inv_affine, int n, int out_size, const float* mean, const float* stdv,
                          float* out_dev, void* stream);
+/* The same stage with cv2.warpAffine's own arithmetic on the uint8 pixels (the reference's call, top_down_transform.py:55-58):
+ *   fwd_affine = host [n,6] FLOAT64 src->dst matrices exactly as the reference hands them to cv2.warpAffine
+ *   (get_affine_transform(center, scale, rot, size)); the library inverts them as cv::warpAffine does, quantises the source
+ *   coordinate to 1/32 px through OpenCV's 1/1024-px fixed point, weights the four taps with the int16 bilinear table
+ *   (sum 32768), rounds (acc + 2^14) >> 15 to uint8, then ToTensor / NormalizeTensor in float32: out = (u8 / 255 - mean) / std.
+ *   cv2 itself is absent from the build image: pinned to OpenCV's published algorithm (imgwarp.cpp, classic fixed-point path)
+ *   through the numpy restatement oracle/pipeline_oracle.py::cv2_warp_affine_linear_u8, bit for bit. */
+int ec_preprocess_images_cv2(const uint8_t* const* src_dev, const int32_t* src_hw, const int64_t* src_pitch,
+                             const double* fwd_affine, int n, int out_size, const float* mean, const float* stdv,
+                             float* out_dev, void* stream);
 int ec_msra_targets(const float* joints_dev, const float* visible_dev, int n, int K, int image_size, int heatmap_size,
                     int sigma, const float* gauss_host, float* target_dev, float* weight_dev, void* stream);
 

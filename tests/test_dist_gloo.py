@@ -119,6 +119,44 @@ def test_world2_multi_gpu_test_matches_single_process(n_total, mode):
         assert ev == ev_single and "PCK@0.2" in ev and "mPCK" in ev
 
 
+def _worker_edge(rank, world, port, case, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from edgecape_amd import apis
+    apis.init_distributed("gloo")
+    res = apis.single_gpu_test(_FakeModel(), [dict(idx=[[rank, rank + 2]])])
+    if case == "longpath" and rank == 1:       # the reference's pickled gather has no path-length limit (apis/test.py:154-198)
+        res[0]["image_paths"] = ["d/" * 300 + "q.jpg"]
+    if case == "kmismatch" and rank == 1:      # a malformed shard must fail on EVERY rank before the all_gather, not hang the others
+        res[1]["preds"] = res[1]["preds"][:, :K - 1]
+    try:
+        out = apis.collect_results(res, 4, all_ranks=True)
+        q.put((rank, "ok", [r["image_paths"][0] for r in out]))
+    except ValueError as e:
+        q.put((rank, "ValueError", str(e)))
+    apis.barrier()
+    apis.finalize_distributed()
+
+
+@pytest.mark.parametrize("case", ["longpath", "kmismatch"])
+def test_world2_collect_results_edge_cases(case):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_edge, args=(r, 2, port, case, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if case == "longpath":
+        assert [o[1] for o in out] == ["ok", "ok"]
+        assert out[0][2] == out[1][2] and out[0][2][1] == "d/" * 300 + "q.jpg" and out[0][2][0] == "img/q0000.jpg"
+    else:
+        assert [o[1] for o in out] == ["ValueError", "ValueError"] and "same on every rank" in out[0][2]
+
+
 def test_shard_indices_is_distributed_sampler():
     from edgecape_amd import apis
     from torch.utils.data.distributed import DistributedSampler

@@ -230,18 +230,6 @@ def test_attention_bf16(lib, B, H, L):
     assert (od.cpu() - ref).abs().mean().item() < 2e-3
 
 
-def test_attention_pipelined_experiment():
-    """The software-pipelined persistent attention kernel (ec_attn.hip, EC_ATTN_PIPE=1; not the default) through the same cases:
-    the switch is read once per process, so the cases run in a child process."""
-    import subprocess
-    import sys
-    env = dict(os.environ, EC_ATTN_PIPE="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "test_attention_bf16 and not x3",
-                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
-
-
 @pytest.mark.parametrize("M,N,K,prec", [(20800, 2304, 768, 1), (5000, 768, 3072, 1), (4100, 1152, 384, 1), (4500, 384, 384, 0),
                                         (6000, 512, 256, 0), (300, 256, 256, 1)])
 def test_linear_tile_configs(lib, M, N, K, prec):
