@@ -63,7 +63,10 @@ def main():
     from edgecape_amd import apis, _lib, build
 
     # one process per GPU; the same helpers the world-size-2 gloo tests drive (tests/test_dist_gloo.py)
-    rank, world, local_rank = apis.init_distributed("nccl")
+    # backend: RCCL ("nccl") whenever a GPU is visible; gloo only without one (tests/test_dist_gloo.py drives this function with
+    # world size 2 and a stand-in engine on CPU so that the N > 1 branches below run before an 8-GPU job does)
+    rank, world, local_rank = apis.init_distributed(None)
+    device = "cuda" if torch.cuda.is_available() else "cpu"
     if world != args.gpus and rank == 0:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
@@ -76,7 +79,7 @@ def main():
 
     # this rank's shard: global pair indices rank*bs .. rank*bs+bs-1 (fixed per-GPU work => weak scaling)
     batch = synth.make_pairs(bs, S, H, seed=1000, first_index=rank * bs, fixed_n_kp=False)
-    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)   # (no GPU: HipEngine below refuses - there is no CPU path)
     iq = dev(batch["img_q"])
     is_ = [dev(x) for x in batch["img_s"]]
     ts = [dev(x) for x in batch["target_s"]]

@@ -54,7 +54,7 @@ __device__ __forceinline__ void split4(const f32x4 x, u32x2& hi, u32x2& lo) {
 
 // 4 floats -> 4 fp16 (RNE): the single-pass form's only plane
 __device__ __forceinline__ u32x2 half4(const f32x4 x) {
-  return __builtin_bit_cast(u32x2, __builtin_convertvector(x, f16x4));
+  return __builtin_bit_cast(u32x2, pack4_h<true>(x));   // (saturating)
 }
 
 struct WBatch { bf16x8 w[4][2][2]; };   // [k-block of the batch][n-fragment][plane]
@@ -455,6 +455,7 @@ int run_chain(const ChainP& p, hipStream_t st) {
     EC_REQUIRE(S.W && S.N % 32 == 0 && S.K % 128 == 0 && S.k1 % 32 == 0 && S.k1 > 0 && S.k1 <= S.K, -1, "chain: stage shape");
     EC_REQUIRE(!S.ln_w || (S.N == 256 && S.ln_b), -1, "chain: LayerNorm needs N = 256");
     EC_REQUIRE(!(S.keep || S.resid_keep) || S.N == 256, -1, "chain: register-kept tiles need N = 256");
+    EC_REQUIRE(!S.resid || S.N == 256, -1, "chain: a global residual is loaded once per stage for the single 256-column pass: N = 256");
     EC_REQUIRE(S.a_off >= CH_RED && S.a_off + chain_layout_bytes(S.k1) <= p.lds_bytes, -1, "chain: operand buffer A out of range");
     EC_REQUIRE(S.k1 == S.K || (S.b_off >= CH_RED && S.b_off + chain_layout_bytes(S.K - S.k1) <= p.lds_bytes), -1, "chain: operand buffer B out of range");
     EC_REQUIRE(S.g_k == 0 || (S.g_in && S.g_k % 32 == 0 && S.g_off >= CH_RED && S.g_off + chain_layout_bytes(S.g_k) <= p.lds_bytes), -1, "chain: staged input out of range");

@@ -68,15 +68,21 @@ template <bool F16> __device__ __forceinline__ f32x16 mfma32x32x16_h(bf16x8 a, b
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 // 4 floats -> 4 packed 16-bit values (round to nearest even): 2 x v_cvt_pk_{bf16,f16}_f32
+// (fp16: saturated at +-65504 first - one v_med3_f32 per value - so an activation outlier of a real checkpoint becomes the largest
+// finite half instead of inf -> NaN in the next softmax / LayerNorm; NaN inputs stay NaN)
 template <bool F16> __device__ __forceinline__ u32x2_t pack4_h(f32x4 v) {
-  if constexpr (F16) return __builtin_bit_cast(u32x2_t, __builtin_convertvector(v, f16x4));
+  if constexpr (F16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+    return __builtin_bit_cast(u32x2_t, __builtin_convertvector(v, f16x4));
+  }
   else {
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16v4_;
     return __builtin_bit_cast(u32x2_t, __builtin_convertvector(v, bf16v4_));
   }
 }
 template <bool F16> __device__ __forceinline__ bf16_t f2h(float f) {
-  if constexpr (F16) return __builtin_bit_cast(bf16_t, (_Float16)f);
+  if constexpr (F16) return __builtin_bit_cast(bf16_t, (_Float16)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f));
   else return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 template <bool F16> __device__ __forceinline__ float h2f(bf16_t h) {

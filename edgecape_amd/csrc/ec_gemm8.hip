@@ -73,11 +73,13 @@ enum { G8_GENERIC = 0, G8_BIAS_BF16 = 1, G8_SCALE_BF16 = 2, G8_GELU_BF16 = 3 };
 // fp16 outputs carry three more significand bits: degree 4, max |err| 3.0e-6 (two more FMAs).
 // The degree-4 polynomial needs no clamp: its leading coefficient is negative, P(s) < -100 for every s > 81 (x * P -> -/+ inf,
 // 2^ -> 0 / inf, rcp -> 1 / 0: the exact limits); the degree-2 one grows positive past s = 105 and keeps the clamp.
-// GV (lab builds only; 0 in the shipped library): 1 = the degree-2 polynomial for fp16 outputs too, 2 = see gelu4_pk below.
-template <bool F16, int GV = 0>
+// Measured and not adopted for fp16 outputs (round 3, tools/g8_ab.py, interleaved medians on the fc1 shape): the degree-2 polynomial
+// -1.4 % of the launch, the polynomial of two elements in packed fp16 (v_pk_*_f16 + v_fma_mix_f32, |d Phi| up to 2e-4) -2.7 %: the
+// epilogue's exp2 / rcp (quarter rate, 16 of its ~34 cycles per element) stay either way.
+template <bool F16>
 __device__ __forceinline__ float gelu_fast8(float x) {
   float q;
-  if constexpr (F16 && GV != 1) {
+  if constexpr (F16) {
     const float s = x * x;
     q = fmaf(-3.229071e-06f, s, 8.82395e-05f);
     q = fmaf(q, s, 3.6026796e-04f);
@@ -90,38 +92,6 @@ __device__ __forceinline__ float gelu_fast8(float x) {
   }
   const float e = __builtin_amdgcn_exp2f(x * q);
   return x * __builtin_amdgcn_rcpf(1.f + e);
-}
-
-// Lab variant GV = 2: the polynomial of TWO elements in packed fp16 (v_pk_mul_f16 / v_pk_min_f16 / 2 x v_pk_fma_f16: full rate, two
-// elements per lane), its fp16 value multiplied into the fp32 argument by v_fma_mix_f32 (no conversion instruction); exp2, rcp and the
-// products with x stay fp32.  q carries ~1e-3 relative error: |d Phi| <= 2.2e-4 (at |x| ~ 0.9).
-typedef _Float16 ec_h2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void gelu2_pk(float& x0, float& x1) {
-  ec_h2 xh;
-  xh[0] = (_Float16)x0; xh[1] = (_Float16)x1;
-  const ec_h2 c81 = {(_Float16)81.f, (_Float16)81.f};
-  const ec_h2 s = __builtin_elementwise_min(xh * xh, c81);
-  const ec_h2 c2 = {(_Float16)1.01453915e-03f, (_Float16)1.01453915e-03f}, c1 = {(_Float16)-1.06777424e-01f, (_Float16)-1.06777424e-01f},
-              c0 = {(_Float16)-2.30111947e+00f, (_Float16)-2.30111947e+00f};
-  ec_h2 q = __builtin_elementwise_fma(c2, s, c1);
-  q = __builtin_elementwise_fma(q, s, c0);
-  float y0, y1;
-  asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(y0) : "v"(q), "v"(x0));
-  asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(y1) : "v"(q), "v"(x1));
-  x0 = x0 * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(y0));
-  x1 = x1 * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(y1));
-}
-template <bool F16, int GV>
-__device__ __forceinline__ void gelu4(f32x4& v) {
-  if constexpr (GV == 2) {
-    float a = v[0], b = v[1], c = v[2], d = v[3];
-    gelu2_pk(a, b);
-    gelu2_pk(c, d);
-    v = f32x4{a, b, c, d};
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = gelu_fast8<F16, GV>(v[e]);
-  }
 }
 
 // acc[mi][ni] (f32x4) of lane l: row m = m0 + wr*128 + mi*16 + (l&15),
@@ -188,7 +158,10 @@ __device__ __forceinline__ void g8_piece(f32x4 (&a)[4], const __amdgpu_buffer_rs
   for (int ni = 0; ni < 4; ++ni) {
     const int c0 = (ni >> 1) * 32 + (ni & 1) * 16 + wq * 4;         // first of this lane's 4 columns inside the wave's 64
     f32x4 v = a[ni] + *(const f32x4*)(bias_lds + c0 * 4);
-    if constexpr (KIND == G8_GELU_BF16) gelu4<F16, (LAB >> 9) & 3>(v);
+    if constexpr (KIND == G8_GELU_BF16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_fast8<F16>(v[e]);
+    }
     if constexpr (KIND == G8_SCALE_BF16) v *= *(const f32x4*)(gam_lds + c0 * 4);
     const int chunk = (ni >> 1) * 4 + (ni & 1) * 2 + (wq >> 1);
     *(u32x2*)(stg + wrow * 128 + ((chunk ^ (wrow & 7)) << 4) + (wq & 1) * 8) = pack4_h<F16>(v);   // 2 x v_cvt_pk (RNE)
@@ -221,7 +194,10 @@ __device__ __forceinline__ void g8_piece_reg(f32x4 (&a)[4], const __amdgpu_buffe
   for (int ni = 0; ni < 4; ++ni) {
     const int c0 = (ni >> 1) * 32 + (ni & 1) * 16 + wq * 4;
     f32x4 v = a[ni] + *(const f32x4*)(bias_lds + c0 * 4);
-    if constexpr (KIND == G8_GELU_BF16) gelu4<F16, (LAB >> 9) & 3>(v);
+    if constexpr (KIND == G8_GELU_BF16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_fast8<F16>(v[e]);
+    }
     if constexpr (KIND == G8_SCALE_BF16) v *= *(const f32x4*)(gam_lds + c0 * 4);
     pk[ni] = pack4_h<F16>(v);
     a[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -621,8 +597,6 @@ extern "C" int ec_lab_gemm8(const void* A, const void* W, const float* bias, voi
     case 1000: k = gemm8_bf16_kernel<1, 1, true, 0>; break;     // the shipped fp16 instantiations: qkv / proj (bias)
     case 2000: k = gemm8_bf16_kernel<2, 4, true, 0>; break;     // fc2 / proj with LayerScale (gamma = the bias vector here)
     case 3000: k = gemm8_bf16_kernel<3, 3, true, 0>; break;     // fc1 + GELU
-    case 3512: k = gemm8_bf16_kernel<3, 3, true, 512>; break;   // ... degree-2 polynomial
-    case 4024: k = gemm8_bf16_kernel<3, 3, true, 1024>; break;  // ... packed-fp16 polynomial
     default: set_error("ec_lab_gemm8: variant not instantiated"); return -1;
   }
   hipStream_t st = (hipStream_t)stream;

@@ -635,6 +635,8 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
   const int d = m->d, E = m->E, K = m->K, HW = m->HW, nh = m->cfg.nhead;
   const int Mk = io.nb * K;
   const bool chain = layer_chains(m, L);
+  // the un-chained path normalises from `tmp` into io.x: a token state left in `tmp` by a chained predecessor would alias its scratch
+  EC_REQUIRE(chain || io.x != tmp, EC_ERR_STATE, "decoder layer: token state aliases the layer scratch (chained layer followed by an un-chained one)");
   // current / other buffer of the token state (ping-pong only in chain mode with x_alt)
   float* xc = io.x; long lxc = io.ldx;
   float* xo = (chain && io.x_alt) ? io.x_alt : io.x; long lxo = (chain && io.x_alt) ? io.ldx_alt : io.ldx;

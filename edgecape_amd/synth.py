@@ -184,34 +184,26 @@ def make_weights(arch="dinov2_vits14", seed=0):
 
 
 def msra_target(joints_xy, visible, image_size, heatmap_size=64, sigma=1):
-    """MSRA gaussian heatmaps: restates TopDownGenerateTargetFewShot._msra_generate_target
-    (reference EdgeCape/datasets/pipelines/top_down_transform.py:165-194, biased branch)."""
-    K = len(joints_xy)
-    W = H = heatmap_size
-    target = np.zeros((K, H, W), np.float32)
-    weight = np.zeros((K, 1), np.float32)
-    tmp = sigma * 3
-    stride = np.array([image_size / W, image_size / H], np.float32)
-    size = 2 * tmp + 1
-    x = np.arange(0, size, 1, np.float32)
-    y = x[:, None]
-    x0 = y0 = size // 2
-    g = np.exp(-((x - x0) ** 2 + (y - y0) ** 2) / (2 * sigma ** 2))
-    for j in range(K):
-        weight[j] = visible[j]
-        mu_x = int(joints_xy[j][0] / stride[0] + 0.5)
-        mu_y = int(joints_xy[j][1] / stride[1] + 0.5)
-        ul = [int(mu_x - tmp), int(mu_y - tmp)]
-        br = [int(mu_x + tmp + 1), int(mu_y + tmp + 1)]
-        if ul[0] >= W or ul[1] >= H or br[0] < 0 or br[1] < 0:
-            weight[j] = 0
-        if weight[j] > 0.5:
-            g_x = max(0, -ul[0]), min(br[0], W) - ul[0]
-            g_y = max(0, -ul[1]), min(br[1], H) - ul[1]
-            img_x = max(0, ul[0]), min(br[0], W)
-            img_y = max(0, ul[1]), min(br[1], H)
-            target[j][img_y[0]:img_y[1], img_x[0]:img_x[1]] = g[g_y[0]:g_y[1], g_x[0]:g_x[1]]
-    return target, weight
+    """Synthetic-input helper: MSRA gaussian heatmaps [K, hm, hm] + weights [K, 1] of the keypoints (the kind of target the
+    reference's pipeline feeds the model; oracle/pipeline_oracle.py is the line-by-line restatement the tests pin to the
+    reference).  Vectorised: every heatmap cell looks its value up in the (2*3*sigma+1)^2 float32 patch centred on the cell
+    int(x / stride + 0.5) of its keypoint; cells outside the patch, invisible keypoints and keypoints whose whole patch lies
+    outside the map are zero."""
+    from .preprocess import gaussian_7x7
+    joints_xy = np.asarray(joints_xy)
+    K, hm, r = len(joints_xy), heatmap_size, 3 * sigma
+    patch = gaussian_7x7(sigma)
+    stride = np.float32(image_size / hm)
+    mu = (joints_xy[:, :2] / stride + 0.5).astype(np.int64)                      # int(): truncation toward zero
+    inside = (mu[:, 0] - r < hm) & (mu[:, 1] - r < hm) & (mu[:, 0] + r + 1 >= 0) & (mu[:, 1] + r + 1 >= 0)
+    weight = (np.asarray(visible, np.float32).reshape(K) * inside).astype(np.float32)
+    cells = np.arange(hm)
+    dx = cells[None, :] - mu[:, 0:1] + r                                         # patch column of every map column, per keypoint
+    dy = cells[None, :] - mu[:, 1:2] + r
+    okx, oky = (dx >= 0) & (dx <= 2 * r), (dy >= 0) & (dy <= 2 * r)
+    vals = patch[np.clip(dy, 0, 2 * r)[:, :, None], np.clip(dx, 0, 2 * r)[:, None, :]]
+    target = np.where(oky[:, :, None] & okx[:, None, :] & (weight > 0.5)[:, None, None], vals, np.float32(0)).astype(np.float32)
+    return target, weight[:, None]
 
 
 def random_skeleton(rng, n_kp):

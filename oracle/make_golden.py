@@ -365,6 +365,11 @@ def round2_fixtures(ns):
 
 
 def main():
+    if "--round3" in sys.argv:          # HF cross-check of the 24-block / 16-head restatement (cfg5's backbone, ViT-L/14 @384)
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        hf_backbone_fixture("bb_hf_vitl14_384", "dinov2_vitl14", 384, 303)
+        return
     if "--round2" in sys.argv:          # only the fixtures added in round 2 (the others are unchanged)
         torch.manual_seed(0)
         torch.set_num_threads(8)
@@ -375,6 +380,7 @@ def main():
     # HF first: the torchvision stub installed for the reference import confuses transformers' import probes
     hf_backbone_fixture("bb_hf_vits14_224", "dinov2_vits14", 224, 301)
     hf_backbone_fixture("bb_hf_vitb14_256", "dinov2_vitb14", 256, 302)
+    hf_backbone_fixture("bb_hf_vitl14_384", "dinov2_vitl14", 384, 303)
     ns = ref_stubs.install()
     for case in HEAD_CASES:
         head_fixture(ns, *case)

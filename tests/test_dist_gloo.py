@@ -157,6 +157,86 @@ def test_world2_collect_results_edge_cases(case):
         assert [o[1] for o in out] == ["ValueError", "ValueError"] and "same on every rank" in out[0][2]
 
 
+class _FakeLib:
+    """ec_profile / ec_profile_read of the C ABI (the QKV launch timers bench.py arms): 12 launches of 1 ms per step."""
+
+    def __init__(self):
+        self.armed = 0
+
+    def ec_profile(self, h, on, n):
+        self.armed = n if on else 0
+        return 0
+
+    def ec_profile_read(self, h, tot, nl):
+        tot._obj.value, nl._obj.value = 1.0 * self.armed, self.armed
+        return 0
+
+
+class _FakeEngine:
+    """Stands in for edgecape_amd.engine.HipEngine in bench.main() on CPU: same constructor keys and the methods bench.py calls;
+    the 'keypoints' of pair i are a deterministic function of the query image, so every rank's shard gives different outputs."""
+    K, dec_layers = 100, 3
+
+    def __init__(self, sd, arch, image_size, max_batch, max_shots, backbone_precision, head_precision):
+        self.lib, self.h, self.calls = _FakeLib(), None, 0
+
+    @staticmethod
+    def _edges(skeletons, bs):
+        return np.zeros((0, 2), np.int32), np.zeros(bs + 1, np.int32)
+
+    def _outputs(self, bs):
+        import torch
+        return dict(output_kpts=torch.zeros(self.dec_layers, bs, self.K, 2)), None
+
+    def forward_resident(self, iq, is_, ts, ms, edges, off, outputs):
+        self.calls += 1
+        m = iq.reshape(iq.shape[0], -1).mean(1)
+        outputs[0]["output_kpts"][:] = (0.5 + 0.1 * m)[None, :, None, None]
+        return outputs[0]
+
+
+def _worker_bench(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import io
+    import json
+    from contextlib import redirect_stdout
+    import edgecape_amd.engine as engine
+    engine.HipEngine = _FakeEngine
+    import bench
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "3", "--warmup", "1", "--batch", "4", "--image-size", "56", "--arch", "dinov2_vits14"]
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        res = bench.main()
+    lines = [ln for ln in buf.getvalue().splitlines() if ln.strip()]
+    q.put((rank, res, [json.loads(ln) for ln in lines]))
+
+
+def test_world2_bench_main_runs_its_distributed_branches():
+    """bench.py main() itself with WORLD_SIZE = 2 on gloo and a stand-in engine: the N > 1 branches (per-rank shard by global pair
+    index, timed region with the counter all-reduce, max over ranks, result assembled and printed by rank 0 only, CPU legs skipped)
+    execute here before an 8-GPU driver run does it for the first time.  Contract: apis/test.py:154-198 + the bench contract."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bench, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, res0, printed0), (r1, res1, printed1) = out
+    assert res1 is None and printed1 == []                      # only rank 0 reports
+    assert len(printed0) == 1 and printed0[0] == res0           # ONE JSON line
+    assert res0["n_gpus"] == 2 and res0["steps"] == 3 and res0["warmup"] == 1 and res0["scaling"] == "weak"
+    assert res0["config"]["global_batch"] == 8 and res0["config"]["parallelism"].startswith("dp2")
+    assert res0["value"] > 0 and abs(res0["value"] - 2 * 4 * 3 / (res0["ms_per_step"] * 3e-3)) / res0["value"] < 0.01   # whole-job aggregate
+    assert res0["roofline"]["launches_timed"] == 3 * 12 and res0["roofline"]["avg_launch_ms"] == 1.0
+    assert "cpu_baseline" not in res0 and "episode_cached" not in res0 and "bf16_mode" not in res0   # rank-0-only legs are N = 1 only
+    assert set(res0["pck_vs_synthetic_gt"]) >= {"PCK@0.2"}
+
+
 def test_shard_indices_is_distributed_sampler():
     from edgecape_amd import apis
     from torch.utils.data.distributed import DistributedSampler

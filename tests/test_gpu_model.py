@@ -77,9 +77,9 @@ def test_backbone_vs_oracle(arch, image_size):
     assert np.array_equal(tok.reshape(3, g, g, -1).transpose(0, 3, 1, 2), got)
 
 
-@pytest.mark.parametrize("arch,image_size", [("dinov2_vits14", 224)])
+@pytest.mark.parametrize("arch,image_size", [("dinov2_vits14", 224), ("dinov2_vitb14", 256), ("dinov2_vitl14", 384)])
 def test_backbone_vs_hf_golden(arch, image_size):
-    name = {"dinov2_vits14": "bb_hf_vits14_224", "dinov2_vitb14": "bb_hf_vitb14_256"}[arch]
+    name = {"dinov2_vits14": "bb_hf_vits14_224", "dinov2_vitb14": "bb_hf_vitb14_256", "dinov2_vitl14": "bb_hf_vitl14_384"}[arch]
     gold, meta = load_golden(name)
     sd = synth.make_backbone_weights(arch, seed=meta["weight_seed"])
     sd.update(synth.make_head_weights(C=synth.ARCHS[arch]["C"], seed=1))

@@ -13,7 +13,10 @@ Modes (backbone / head):
   bf16x3 / bf16x3  "parity mode": every MFMA operand split hi+lo bf16 - fp32-class; must meet 1e-3 outright, no flips.
   fp16   / bf16x3  headline throughput mode: IEEE fp16 operands at the bf16 MFMA rate; continuous error ~1e-4.
   bf16   / bf16x3  the north-star's literal bf16 tiles: continuous error ~1e-3, reported and bounded, not parity-grade.
-CPU emulation of the operand rounding on 256 pairs (oracle/precision_study.py) predicts: bf16 95 flips, fp16 11, bf16x3 0.
+CPU emulation of the operand rounding on 256 pairs (oracle/precision_study.py, ViT-S) predicted: bf16 95 flips, fp16 11, bf16x3 0.
+MEASURED on MI355X at cfg2, 256 pairs x 2 weight seeds (round 3, test_headline_conformance_at_scale, record
+profiles/r03_conformance_fp16_mixed.json): fp16 backbone + mixed head 0 flips of 20 503 valid keypoints, max |d| 1.63e-4, nothing
+above 1e-3; bf16x3 / bf16x3 (256 pairs) max |d| 8.2e-6 (profiles/r03_conformance_bf16x3.json).
 """
 import functools
 
@@ -99,11 +102,14 @@ def test_headline_mode_fp16(name):
     argmax near-ties may flip (emulation: 0.15 % of the valid keypoints with random weights)."""
     s = _run(name, "fp16", "bf16x3")
     print(name, "fp16/bf16x3", s)
-    assert s["max_clean"] < 1e-3, s                       # every sample without an argmax flip is inside the north-star tolerance
-    assert s["p99"] < 5e-4 and s["median"] < 2e-5
-    assert s["flip_frac"] <= 0.01
-    assert s["clean_samples"] >= 0.75 * CFG[name]["bs"]
-    assert s["pck_vs_oracle"] >= 0.98                     # north star: PCK@0.2 within +-0.1 (here against the oracle's own answers)
+    # observed on all three configs: 0 flips, max |d| 1.4-1.6e-4 (round 2 and 3); at scale: test_headline_conformance_at_scale
+    assert s["max_clean"] < 5e-4, s                       # every sample without an argmax flip: 2x inside the north-star tolerance
+    assert s["p99"] < 2e-4 and s["median"] < 2e-5
+    assert s["flips"] <= 1, s                             # one near-tie may flip on another box; it moves ONE sample
+    assert s["clean_samples"] >= CFG[name]["bs"] - 1
+    if s["flips"] == 0:
+        assert s["max_all"] < 5e-4 and s["frac_gt_1e3"] == 0.0
+    assert s["pck_vs_oracle"] >= 0.99                     # north star: PCK@0.2 within +-0.1 (here against the oracle's own answers)
 
 
 @pytest.mark.parametrize("name", ["cfg2", "cfg4", "cfg5"])
@@ -115,12 +121,75 @@ def test_headline_mode_fp16_mixed_head(name):
     s = _run(name, "fp16", "mixed")
     s0 = _run(name, "fp16", "bf16x3")
     print(name, "fp16/mixed", s, "\n     fp16/bf16x3", s0)
-    assert s["max_clean"] < 1e-3, s
-    assert s["p99"] < 5e-4 and s["median"] < 2e-5
-    assert s["flips"] <= s0["flips"]                      # the encoder / proposal path is bit-identical to the bf16x3 head's
-    assert s["clean_samples"] >= 0.75 * CFG[name]["bs"]
-    assert s["pck_vs_oracle"] >= 0.98
-    assert s["adj_err"] < 1e-3
+    assert s["max_clean"] < 5e-4, s
+    assert s["p99"] < 2e-4 and s["median"] < 2e-5
+    assert s["flips"] <= s0["flips"] and s["flips"] <= 1  # the encoder / proposal path is bit-identical to the bf16x3 head's
+    assert s["clean_samples"] >= CFG[name]["bs"] - 1
+    if s["flips"] == 0:
+        assert s["max_all"] < 5e-4 and s["frac_gt_1e3"] == 0.0
+    assert s["pck_vs_oracle"] >= 0.99
+    assert s["adj_err"] < 1e-4
+
+
+def conformance_at_scale(n_batches=8, wseeds=(0, 1), backbone="fp16", head="mixed", name="cfg2"):
+    """The headline precision against the oracle on n_batches x bs pairs per weight seed (cfg2: 8 x 32 = 256 pairs, 2 seeds): the
+    MEASURED rate of argmax flips and of keypoints outside 1e-3, instead of one lucky 32-pair sample.  Returns one stats dict per
+    weight seed plus the pooled one.  (Also run by tools/conformance.py, which writes the record under profiles/.)"""
+    from edgecape_amd.engine import HipEngine
+    from oracle import edgecape_oracle as orc   # the checker
+    c = CFG[name]
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    per_seed, pooled_got, pooled_ref, pooled_valid = [], [], [], []
+    for ws in wseeds:
+        w = synth.make_weights(c["arch"], seed=ws)
+        eng = HipEngine(w, arch=c["arch"], image_size=c["H"], max_batch=c["bs"], max_shots=c["S"], backbone_precision=backbone, head_precision=head)
+        gots, refs, valids = [], [], []
+        for b in range(n_batches):
+            batch = synth.make_pairs(c["bs"], c["S"], c["H"], seed=c["iseed"] + 17 * ws + b, fixed_n_kp=False)
+            mask = batch["target_weight_s"][0].copy()
+            for tw in batch["target_weight_s"]:
+                mask = mask * tw
+            _, out = orc.forward_test(w, batch, synth.ARCHS[c["arch"]]["heads"])
+            o = eng.forward(batch["img_q"], batch["img_s"], batch["target_s"], mask, [m["sample_skeleton"][0] for m in batch["img_metas"]])
+            torch.cuda.synchronize()
+            gots.append({k: o[k].cpu().numpy() for k in ("output_kpts", "similarity_map", "adj")})
+            refs.append({k: out[k].numpy() for k in ("output_kpts", "similarity_map", "adj")})
+            valids.append(mask[:, :, 0] > 0)
+        del eng
+        cat = lambda L, k, ax: np.concatenate([x[k] for x in L], ax)
+        got = dict(output_kpts=cat(gots, "output_kpts", 1), similarity_map=cat(gots, "similarity_map", 0), adj=cat(gots, "adj", 0))
+        ref = dict(output_kpts=cat(refs, "output_kpts", 1), similarity_map=cat(refs, "similarity_map", 0), adj=cat(refs, "adj", 0))
+        valid = np.concatenate(valids, 0)
+        st = stats(got, ref, valid, c["H"])
+        st["weight_seed"], st["pairs"] = ws, int(valid.shape[0])
+        per_seed.append(st)
+        pooled_got.append(got); pooled_ref.append(ref); pooled_valid.append(valid)
+    cat = lambda L, k, ax: np.concatenate([x[k] for x in L], ax)
+    pooled = stats(dict(output_kpts=cat(pooled_got, "output_kpts", 1), similarity_map=cat(pooled_got, "similarity_map", 0), adj=cat(pooled_got, "adj", 0)),
+                   dict(output_kpts=cat(pooled_ref, "output_kpts", 1), similarity_map=cat(pooled_ref, "similarity_map", 0), adj=cat(pooled_ref, "adj", 0)),
+                   np.concatenate(pooled_valid, 0), c["H"])
+    pooled["pairs"] = int(sum(v.shape[0] for v in pooled_valid))
+    return per_seed, pooled
+
+
+def test_headline_conformance_at_scale():
+    """cfg2, fp16 backbone + mixed head (the bench default), 256 pairs x 2 weight seeds vs the oracle.  Gates = the observed rates
+    with head-room (profiles/r03_conformance_fp16_mixed.json): the share of valid keypoints whose proposal argmax flips and the
+    share outside 1e-3 are MEASURED quantities of this mode; every flip-free sample must be inside the tolerance outright."""
+    per_seed, pooled = conformance_at_scale()
+    print("conformance", per_seed, pooled)
+    # observed (profiles/r03_conformance_fp16_mixed.json, MI355X, round 3): 0 flips of 20 503 valid keypoints, max |d| 1.63e-4 over ALL
+    # of them, p99 8.7e-5, median 3.0e-6, nothing above 1e-3, PCK@0.2 vs the oracle's answers 1.0 - on both weight seeds
+    assert pooled["pairs"] >= 512
+    assert pooled["max_clean"] < 5e-4, pooled                       # continuous part of the error: 3x head-room on the observed, 2x inside the tolerance
+    assert pooled["p99"] < 2e-4 and pooled["median"] < 1e-5
+    assert pooled["flips"] <= 2, pooled                             # an argmax near-tie may flip on another box / clock: <= 1e-4 of the keypoints
+    assert pooled["frac_gt_1e3"] <= 2e-3, pooled                    # (one flipped sample moves its ~40 valid keypoints: 2 flips = 0.4 %)
+    if pooled["flips"] == 0:
+        assert pooled["max_all"] < 5e-4 and pooled["frac_gt_1e3"] == 0.0 and pooled["pck_vs_oracle"] == 1.0
+    assert pooled["pck_vs_oracle"] >= 0.998
+    for st in per_seed:
+        assert st["max_clean"] < 5e-4 and st["flips"] <= 2, st
 
 
 def test_bf16_mode_cfg2_bounded():

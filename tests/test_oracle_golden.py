@@ -79,7 +79,7 @@ def test_detector_matches_reference(name):
     assert np.all(res["preds"][..., 2] == 1)  # head.py:374
 
 
-@pytest.mark.parametrize("name", ["bb_hf_vits14_224", "bb_hf_vitb14_256"])
+@pytest.mark.parametrize("name", ["bb_hf_vits14_224", "bb_hf_vitb14_256", "bb_hf_vitl14_384"])
 def test_backbone_matches_hf(name):
     gold, meta = load_golden(name)
     arch = meta["arch"]

@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""Measured conformance of a precision mode against the CPU oracle at scale (cfg2: 256 pairs x 2 weight seeds): argmax flips,
+share of keypoints outside 1e-3, error quantiles.  Writes the record that README / DESIGN quote and the gates of
+tests/test_gpu_precision_modes.py::test_headline_conformance_at_scale are set from.
+    python tools/conformance.py [--backbone fp16 --head mixed --batches 8 --seeds 0,1] --out profiles/r03_conformance_fp16_mixed.json"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_gpu_precision_modes as T  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--backbone", default="fp16")
+ap.add_argument("--head", default="mixed")
+ap.add_argument("--batches", type=int, default=8)
+ap.add_argument("--seeds", default="0,1")
+ap.add_argument("--out", default=None)
+a = ap.parse_args()
+per_seed, pooled = T.conformance_at_scale(a.batches, tuple(int(x) for x in a.seeds.split(",")), a.backbone, a.head)
+rec = dict(config="cfg2: 1-shot, batch 32, 256x256, ViT-B/14", backbone=a.backbone, head=a.head, oracle="oracle/edgecape_oracle.py (fp32 CPU)",
+           tolerance="1e-3 abs on output_kpts of valid keypoints", per_weight_seed=per_seed, pooled=pooled)
+print(json.dumps(rec, indent=1))
+if a.out:
+    with open(a.out, "w") as f:
+        json.dump(rec, f, indent=1)

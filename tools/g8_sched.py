@@ -25,7 +25,7 @@ from edgecape_amd import build
 # name, M, N, K, lab code of the shipped fp16 instantiation (ec_gemm8.hip ec_lab_gemm8)
 SHAPES = [("qkv", 20800, 2304, 768, 1000), ("proj", 20800, 768, 768, 2000), ("fc1", 20800, 3072, 768, 3000), ("fc2", 20800, 768, 3072, 2000)]
 # extra lab instantiations timed beside the shipped one (ec_lab_gemm8 codes)
-VARIANTS = {"fc1": [(3512, "gelu: degree-2 polynomial"), (4024, "gelu: packed-fp16 polynomial")]}
+VARIANTS = {}   # e.g. {"fc1": [(code, "label")]} for lab instantiations added to ec_lab_gemm8
 GRID_SIZES = (256, 248, 246, 240, 224, 192)
 
 
