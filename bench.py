@@ -141,12 +141,18 @@ def main():
             "roofline": {"bound": "mfma", "kernel": f"backbone QKV GEMM M={Mq} K={Kq} N={Nq} ({args.precision})",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "flops_per_launch": qkv_flops, "avg_launch_ms": round(qkv_ms, 5), "launches_timed": args.steps * depth,
+                         # context, not the judged peak: what a pure register-operand MFMA loop sustains on this chip with random
+                         # (not zero) fp16 operands - the power-management ceiling of real data (tools/mfma_power_probe.hip)
+                         "mfma_sustained_random_operands_tflops": [1710, 1951], "mfma_probe_source": "profiles/r03_mfma_power_probe.txt",
                          **pmc_traffic(args, bs, S, H, arch, build.source_hash())},
             "pck_vs_synthetic_gt": {k: round(v, 4) for k, v in pck.items()},
             # every switch that changes what the library runs (README "Runtime switches"): none set = the shipped defaults
             "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("EC_")},
             "library_source_hash": build.source_hash()[:16],
         }
+        conf = conformance_record(args, bs, S, H, arch)
+        if conf:
+            result["conformance_at_scale"] = conf
         if world == 1 and not args.no_episode:
             result["episode_cached"] = episode_mode(args, eng, synth, batch, bs, S, H)
         if not args.no_cpu_baseline and world == 1:
@@ -167,13 +173,36 @@ def main():
     return result
 
 
+def conformance_record(args, bs, S, H, arch):
+    """The MEASURED conformance of this precision mode at scale (tools/conformance.py on the GPU box: 256 pairs x 2 weight seeds
+    against the CPU oracle; committed under profiles/): argmax flips and the share of keypoints outside 1e-3 are rates of the
+    mode, not of the 32-pair `parity_sample` of one run.  Only reported for the configuration it was measured on (cfg2)."""
+    path = os.path.join(ROOT, "profiles", f"r03_conformance_{args.precision}_{args.head_precision}.json")
+    if (bs, S, H, arch) != (32, 1, 256, "dinov2_vitb14") or not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    p = d["pooled"]
+    return {"pairs": p["pairs"], "weight_seeds": [s_["weight_seed"] for s_ in d["per_weight_seed"]], "valid_keypoints": p["n_valid"],
+            "argmax_flips": p["flips"], "flip_rate": p["flip_frac"], "max_abs_kpt_err": p["max_all"], "p99_abs_kpt_err": p["p99"],
+            "frac_gt_1e-3": p["frac_gt_1e3"], "pck@0.2_hip_vs_oracle_pred": p["pck_vs_oracle"], "tolerance": 1e-3,
+            "source": os.path.relpath(path, ROOT)}
+
+
+def pmc_path(bs, S, H, arch, precision):
+    """PMC summary of the north-star kernel for a workload: profiles/qkv_gemm_pmc.json for the headline configuration (cfg2, fp16),
+    profiles/qkv_gemm_pmc_<arch>_<H>_b<bs>_s<S>_<precision>.json for any other (both written by tools/refresh_pmc.py)."""
+    if (bs, S, H, arch, precision) == (32, 1, 256, "dinov2_vitb14", "fp16"):
+        return os.path.join(ROOT, "profiles", "qkv_gemm_pmc.json")
+    return os.path.join(ROOT, "profiles", f"qkv_gemm_pmc_{arch}_{H}_b{bs}_s{S}_{precision}.json")
+
+
 def pmc_traffic(args, bs, S, H, arch, source_hash):
     """`traffic` cannot be measured from inside the process: it comes from the committed rocprofv3 --pmc summary of THIS command
     (profiles/qkv_gemm_pmc.json, written by tools/refresh_pmc.py on the GPU box: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2
     read correction, MI355X_MICROARCH.md §HBM).  It is only reported when that summary was collected on this workload AND on this
     library: the summary carries the sha256 of the kernel sources it measured (edgecape_amd.build.source_hash); any edit of a
     kernel makes it stale and `traffic` null until tools/refresh_pmc.py is run again."""
-    path = os.path.join(ROOT, "profiles", "qkv_gemm_pmc.json")
+    path = pmc_path(bs, S, H, arch, args.precision)
     if not os.path.exists(path):
         return {"traffic": None, "traffic_note": "no PMC summary (tools/refresh_pmc.py)"}
     d = json.load(open(path))
@@ -183,7 +212,7 @@ def pmc_traffic(args, bs, S, H, arch, source_hash):
         return {"traffic": None, "traffic_note": f"PMC summary is for workload {d.get('workload')}"}
     return {"traffic": d["traffic_bytes_per_launch"], "traffic_unit": "bytes/launch (L2 miss traffic incl. Infinity-Cache hits)",
             "algorithmic_bytes": d["algorithmic_bytes_per_launch"], "traffic_over_algorithmic": round(d["traffic_bytes_per_launch"] / d["algorithmic_bytes_per_launch"], 3),
-            "mfma_util_pmc": d.get("mfma_util"), "traffic_source": "profiles/qkv_gemm_pmc.json"}
+            "mfma_util_pmc": d.get("mfma_util"), "traffic_source": os.path.relpath(path, ROOT)}
 
 
 def episode_mode(args, eng, synth, batch, bs, S, H, steps=5):

@@ -288,7 +288,9 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   // (round 3, measured and removed: a per-tile ROTATION of the K walk, so that the workgroups sharing an operand panel are at
   // different K positions, and a start stagger over the slots.  Neither changes FETCH_SIZE / TCC_MISS on any of the four block
   // shapes - workgroups that request the same line in lock-step are merged by the L2 - and rotation costs 3-17 % of the time
-  // because it widens the working set; profiles/r03_g8_sched_sweep.txt, r03_g8_sched_pmc.csv.)
+  // because it widens the working set; the stagger de-phases the chip-wide store bursts of the tile seams but costs its own delay
+  // on the critical workgroups, net +1.5 / +2.2 / +4.6 % at 3 / 6 / 12 k cycles (interleaved medians);
+  // profiles/r03_g8_sched_sweep.txt, r03_g8_sched_pmc.csv, r03_g8_stagger_ab.txt.)
   int ls_kt = 0, ls_tile = t_first;
   auto set_rows = [&](int t) {
     const int m0 = (LAB & 2) ? 0 : (t / ntn) << 8, n0 = (LAB & 2) ? 0 : (t % ntn) << 8;

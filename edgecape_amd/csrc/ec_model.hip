@@ -1457,6 +1457,8 @@ int ec_finalize(ec_handle m) {
     if ((rc = make_norm(m, p + "norm1", &e.n1)) || (rc = make_norm(m, p + "norm2", &e.n2))) return rc;
   }
   if ((rc = make_norm(m, hp + "transformer.decoder.norm", &m->dec_norm))) return rc;
+  // (round 3, measured and not adopted: the decoder's helper chain - ref_point_head, keypoint branches - in single-pass fp16 under
+  // the mixed head: step +0.3 % = noise, median |d kpt| 3.0e-6 -> 4.4e-6; these small MLPs stay bf16x3)
   if ((rc = make_lin(m, hp + "transformer.decoder.ref_point_head.layers.0.weight", hp + "transformer.decoder.ref_point_head.layers.0.bias", &m->rp0, false))) return rc;
   if ((rc = make_lin(m, hp + "transformer.decoder.ref_point_head.layers.1.weight", hp + "transformer.decoder.ref_point_head.layers.1.bias", &m->rp1, false))) return rc;
   const std::string pg = hp + "transformer.proposal_generator.";

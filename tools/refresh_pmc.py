@@ -97,8 +97,12 @@ def main():
         "mean_duration_us_profiled": round(dur_ns / 1e3, 2),
         "effective_clock_ghz": round(gui / 8.0 / dur_ns, 3) if dur_ns > 0 else None,
     }
-    with open(os.path.join(args.out, "qkv_gemm_pmc.json"), "w") as f:
+    sys.path.insert(0, ROOT)
+    import bench
+    name = os.path.basename(bench.pmc_path(args.batch, args.shots, args.image_size, args.arch, args.precision))
+    with open(os.path.join(args.out, name), "w") as f:
         json.dump(out, f, indent=1)
+    os.replace(os.path.join(args.out, "qkv_gemm_pmc_kernels.csv"), os.path.join(args.out, name.replace(".json", "_kernels.csv")))
     print(json.dumps(out, indent=1))
 
 
