@@ -61,7 +61,10 @@ def main():
         for (kn, cn), (n, v, dur) in rocpd_pmc.summarise(dbs[0]).items():
             merged[(rocpd_pmc.short(kn), cn)] = (n, v / n, dur / n)
     rows = sorted(merged.items())
-    with open(os.path.join(args.out, "qkv_gemm_pmc_kernels.csv"), "w") as f:
+    sys.path.insert(0, ROOT)
+    import bench
+    name = os.path.basename(bench.pmc_path(args.batch, args.shots, args.image_size, args.arch, args.precision))
+    with open(os.path.join(args.out, name.replace(".json", "_kernels.csv")), "w") as f:
         f.write("Kernel,Counter,Dispatches,MeanValuePerDispatch,MeanDurationNs\n")
         for (kn, cn), (n, v, dur) in rows:
             f.write(f'"{kn}",{cn},{n},{v:.3f},{dur:.1f}\n')
@@ -97,12 +100,8 @@ def main():
         "mean_duration_us_profiled": round(dur_ns / 1e3, 2),
         "effective_clock_ghz": round(gui / 8.0 / dur_ns, 3) if dur_ns > 0 else None,
     }
-    sys.path.insert(0, ROOT)
-    import bench
-    name = os.path.basename(bench.pmc_path(args.batch, args.shots, args.image_size, args.arch, args.precision))
     with open(os.path.join(args.out, name), "w") as f:
         json.dump(out, f, indent=1)
-    os.replace(os.path.join(args.out, "qkv_gemm_pmc_kernels.csv"), os.path.join(args.out, name.replace(".json", "_kernels.csv")))
     print(json.dumps(out, indent=1))
 
 
