@@ -198,7 +198,7 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
           } else if (S.act == ACT_GELU) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = gelu_fast32(v[e]);
           }
           if (S.resid) v += presid[mi][j];
           if (S.resid_keep) v += keep[mi][j];
@@ -483,6 +483,11 @@ int run_chain(const ChainP& p, hipStream_t st) {
     EC_HIP(hipMemsetAsync(d_tr, 0, 64 * sizeof(unsigned), st));
     ChainP q = p;
     q.trace = d_tr;
+    static const int warm = atoi(getenv("EC_CHAIN_TRACE"));   // 2: run the launch once untraced first (weights warm in the L2s)
+    if (warm == 2) {
+      hipLaunchKernelGGL(chain_kernel<false>, grid, dim3(512), p.lds_bytes, st, p);
+      EC_HIP(hipStreamSynchronize(st));
+    }
     hipLaunchKernelGGL(chain_kernel<true>, grid, dim3(512), p.lds_bytes, st, q);
     EC_LAUNCH_CHECK();
     EC_HIP(hipStreamSynchronize(st));

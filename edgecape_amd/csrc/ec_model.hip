@@ -517,6 +517,8 @@ struct LayerIO {
   hipEvent_t wait_ca[2] = {nullptr, nullptr};
   hipEvent_t wait_kv = nullptr;   // pre-projected K|V ready: waited for AFTER the query projection, right before the cross attention
   hipEvent_t wait_sa = nullptr;   // adjacency / attention bias ready: waited for after the self-attention input projection
+  hipEvent_t sa_done = nullptr;   // the layer's self-attention was launched beforehand on another stream (run_self_attention): skip it,
+                                  // wait for this event before the first chain reads its output
   // row-chain mode (ec_chain.hip): the layer's last chain (ffn2 + norm3) also produces what the NEXT consumers of x need
   bool qkv_ready = false;          // this layer's self-attention input projection was produced by the previous layer's last chain
   const Lin* next_sa_in = nullptr; // next layer's self-attention input projection -> qkv
@@ -629,6 +631,20 @@ static bool layer_chains(const ec_model* m, const DecLayer& L) {
          (L.ca_q.K == m->d || L.ca_q.K == 2 * m->d) && lds_ffn2 <= 160 * 1024;   // (ViT-L skeleton layers, F = 1024: separate launches)
 }
 
+// Self attention over the K keypoint tokens of every sample (hd = d/nh = 32; encoder_decoder.py:596-603): qkv [nb*K, 3d] -> att [nb*K, d].
+static int run_self_attention(ec_model* m, const LayerIO& io, const float* qkv, float* att, hipStream_t st) {
+  const int d = m->d, K = m->K, nh = m->cfg.nhead;
+  AttnP a;
+  a.Q = qkv; a.K = qkv + d; a.V = qkv + 2 * d; a.O = att;
+  a.ldq = a.ldk = a.ldv = 3 * d; a.ldo = d;
+  a.sQ = a.sK = a.sV = (long)K * 3 * d; a.sO = (long)K * d;
+  a.kmask = io.kmask_fixed; a.mask_start = 0; a.mask_len = K; a.mask_mod = io.bs;
+  a.bias = io.bias;
+  a.B = io.nb; a.H = nh; a.Lq = K; a.Lk = K; a.hd = d / nh;
+  a.split = m->head_split ? 1 : 0;   // head throughput mode: bf16x3 MFMAs
+  return attention(a, st);
+}
+
 static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool biased, bool two_way, float* qkv, float* att,
                          float* tmp, float* qc, float* kv, float* y, float* z, float* qimg, float* kvk, float* attimg,
                          float* tmpimg, int F, hipStream_t st) {
@@ -644,24 +660,18 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
   auto hop = [&]() { std::swap(xc, xo); std::swap(lxc, lxo); };
   EC_REQUIRE(chain || (!io.qkv_ready && !io.next_sa_in && !io.kvk_in_chain), EC_ERR_STATE, "chain hand-offs on a layer that does not chain");
   // ---- self attention over the K keypoint tokens (hd = d/nh = 32)
-  if (!io.qkv_ready) RUN(linear(io.x, io.ldx, false, L.sa_in, qkv, 3 * d, false, Mk, ACT_NONE, st));
-  {
-    AttnP a;
-    a.Q = qkv; a.K = qkv + d; a.V = qkv + 2 * d; a.O = att;
-    a.ldq = a.ldk = a.ldv = 3 * d; a.ldo = d;
-    a.sQ = a.sK = a.sV = (long)K * 3 * d; a.sO = (long)K * d;
-    a.kmask = io.kmask_fixed; a.mask_start = 0; a.mask_len = K; a.mask_mod = io.bs;
-    a.bias = io.bias;
-    a.B = io.nb; a.H = nh; a.Lq = K; a.Lk = K; a.hd = d / nh;
-    a.split = m->head_split ? 1 : 0;   // head throughput mode: bf16x3 MFMAs
+  EC_REQUIRE(!io.sa_done || (chain && io.qkv_ready), EC_ERR_STATE, "pre-launched self attention needs the chained input projection");
+  if (!io.sa_done) {
+    if (!io.qkv_ready) RUN(linear(io.x, io.ldx, false, L.sa_in, qkv, 3 * d, false, Mk, ACT_NONE, st));
     if (io.wait_sa) EC_HIP(hipStreamWaitEvent(st, io.wait_sa, 0));
-    RUN(attention(a, st));
+    RUN(run_self_attention(m, io, qkv, att, st));
   }
   if (chain) {
     // x = norm1(x + out_proj(att)); qc = q_proj([x | qpe]) - one launch (encoder_decoder.py:596-611)
     // (with the ping-pong token state the layer's input buffer is first overwritten by the SECOND chain; waiting for the helper lane only
     //  there was measured: no gain - 6.82-6.84 vs 6.81-6.84 ms, decoder layers 212-231 vs 201-222 us - so the wait stays here)
     if (io.wait_x) EC_HIP(hipStreamWaitEvent(st, io.wait_x, 0));
+    if (io.sa_done) EC_HIP(hipStreamWaitEvent(st, io.sa_done, 0));
     for (hipEvent_t e : io.wait_ca)
       if (e) EC_HIP(hipStreamWaitEvent(st, e, 0));
     ChainBuild cb;
@@ -1026,6 +1036,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     return 0;
   };
   hipEvent_t const ev_fork = m->ev_aux[0], ev_x = m->ev_aux[1], ev_qpe = m->ev_aux[2], ev_kv = m->ev_aux[3], ev_done = m->ev_aux[4];
+  hipEvent_t const ev_sa = m->ev_aux[5];
   const int nL = (int)m->dec.size();
   RUN(fork(ev_fork));
   {  // the decoder never updates the image memory (two_way_attn=False, encoder_decoder.py:638): project K|V of the image
@@ -1089,6 +1100,12 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
   RUN(tl_mark(m, "Q.adjwait", st));
   float* dx = m->d_qin;                       // token state: left half of d_qin, ping-ponging with d_tmp under two-workgroup chains
   long dx_ld = 2 * d;
+  // Round 3: the CRITICAL chain of a layer boundary stays on ONE stream.  Layer l+1's first chain needs qpe_{l+1}, i.e. the
+  // five-stage helper chain on x_{l+1} (~45 us) - that, not the token self-attention, is what the boundary waits for; with the helper
+  // chain on the helper stream every boundary paid two cross-stream hand-offs (~12 + ~16 us of signal latency, r03_step_trace.txt).
+  // Now the helper chain runs on st right behind the layer, and what has slack moves to ax instead: layer l+1's self-attention
+  // (its q|k|v were produced by layer l's last chain), dec_norm -> hs[l] and the output keypoint branch.
+  bool sa_prelaunched = false;                // this layer's self-attention already runs on ax (ev_sa)
   for (int li = 0; li < nL; ++li) {
     const DecLayer& Ld = m->dec[li];
     float* bi = pts + (long)li * Mk * 2;
@@ -1106,8 +1123,9 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     if (li == 0 && ss.dec_bias) io.wait_sa = wait_adj;
     if (ovd) {
       io.wait_x = li > 0 ? ev_x : nullptr;
-      io.wait_ca[0] = ev_qpe;
+      io.wait_ca[0] = sa_prelaunched ? nullptr : ev_qpe;   // (pre-launched: qpe was written on st itself)
       io.wait_kv = li == 0 ? ev_kv : nullptr;
+      io.sa_done = sa_prelaunched ? ev_sa : nullptr;
     }
     const bool ch = layer_chains(m, Ld);
     io.qkv_ready = li > 0 && ch && layer_chains(m, m->dec[li - 1]) && chain_ok(Ld.sa_in);
@@ -1131,6 +1149,15 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
                            chain_ok(m->rp0) && chain_ok(m->rp1) && kb.l0.K == d && kb.l0.N == d && kb.l2.K == d && kb.l2.N == d &&
                            kb.l4.K == d && kb.l4.N == d && m->rp0.K == d && m->rp0.N == d && m->rp1.K == d && d == 256 &&
                            kb.l0.h1 == m->rp0.h1 && kb.l0.h1 == m->rp1.h1 && kb.l0.h1 == kb.l2.h1 && kb.l0.h1 == kb.l4.h1;
+    // next layer's self-attention on the helper stream, right behind this layer's last chain (which produced its q|k|v)
+    static const bool pre_off = getenv("EC_DEC_PRE") && atoi(getenv("EC_DEC_PRE")) == 0;   // A/B switch
+    sa_prelaunched = !pre_off && ovd && kpt_chain && ss.dec_bias && ch && layer_chains(m, m->dec[li + 1]) && chain_ok(m->dec[li + 1].sa_in);
+    if (sa_prelaunched) {
+      LayerIO nio = io;
+      nio.bias = ss.dec_bias + (size_t)(li + 1) * bs * nh * K * K;
+      RUN(run_self_attention(m, nio, m->d_qkv, m->d_att, ax));
+      EC_HIP(hipEventRecord(ev_sa, ax));
+    }
     if (kpt_chain) {
       ChainBuild cb;
       const int b0 = cb.buf(d), b1 = cb.buf(d);
@@ -1150,8 +1177,8 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
       ChainStage& S5 = cb.add();
       chain_lin(S5, m->rp1);
       S5.a_off = b0; S5.out = m->d_qin + d; S5.ldo = 2 * d;
-      RUN(cb.run(Mk, ax));
-      RUN(mark(ev_qpe));
+      RUN(cb.run(Mk, sa_prelaunched ? st : ax));
+      if (!sa_prelaunched) RUN(mark(ev_qpe));
       RUN(ln(dx, dx_ld, hs, d, false, m->dec_norm, Mk, d, 1e-5f, ax));
       RUN(mark(ev_x));                     // x_{l+1} has been read (chain and dec_norm): layer l+1 may overwrite it
     } else if (!kpt_chain_off && li + 1 == nL) {
