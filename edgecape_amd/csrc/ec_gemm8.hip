@@ -291,6 +291,9 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   // because it widens the working set; the stagger de-phases the chip-wide store bursts of the tile seams but costs its own delay
   // on the critical workgroups, net +1.5 / +2.2 / +4.6 % at 3 / 6 / 12 k cycles (interleaved medians);
   // profiles/r03_g8_sched_sweep.txt, r03_g8_sched_pmc.csv, r03_g8_stagger_ab.txt.)
+  // (round 3, measured and removed: a K SERPENTINE - every second tile of a workgroup walks K backwards, so that a round starts on the
+  // K-tiles the previous one ended on - cuts the weight-panel re-reads by 8-9 % (QKV 129 -> 119 MB, fc1 199 -> 182 MB per launch) and
+  // changes the time by +1.8 % / +0.3 % (noise); profiles/r03_g8_serpentine_ab.txt.)
   int ls_kt = 0, ls_tile = t_first;
   auto set_rows = [&](int t) {
     const int m0 = (LAB & 2) ? 0 : (t / ntn) << 8, n0 = (LAB & 2) ? 0 : (t % ntn) << 8;

@@ -280,6 +280,36 @@ def test_gemm8_race_screen(lib, M, N, K):
         assert torch.equal(o, outs[0])
 
 
+@pytest.mark.parametrize("kind", ["bias", "gelu", "scale"])
+def test_linear_h16_fp16_saturates(lib, kind):
+    """fp16 outputs of the 8-phase kernel saturate at +-65504 (ec_common.h pack4_h / f2h, round 3) instead of overflowing to inf: an
+    activation outlier of a real checkpoint (DINOv2 has outlier channels in the MLP hidden layer) must not turn into NaN in the next
+    LayerNorm / softmax.  Operands scaled so that a sizeable share of the results lies beyond the fp16 range."""
+    M, N, K = 2048, 512, 256
+    g = torch.Generator().manual_seed(5)
+    A = (torch.randn(M, K, generator=g) * 400.0)
+    W = torch.randn(N, K, generator=g)
+    b = torch.randn(N, generator=g)
+    gam = (torch.rand(N, generator=g) + 0.5) if kind == "scale" else None
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
+    ref = Ad.half().double() @ Wd.half().double().T + bd.double()
+    if kind == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    if kind == "scale":
+        ref = ref * gam.cuda().double()
+    buf = torch.empty(M * N, device="cuda", dtype=torch.float16)
+    _chk(lib, lib.ec_op_linear_h16(_p(Ad), _p(Wd), _p(bd), _p(gam.cuda()) if gam is not None else None, _p(buf), M, N, K,
+                                   2 if kind == "gelu" else 0, 3, 1, None))
+    torch.cuda.synchronize()
+    got = buf.view(M, N).double()
+    assert torch.isfinite(got).all()
+    big = ref.abs() > 65504.0
+    assert big.float().mean().item() > 0.002                                   # the case does exercise the overflow
+    assert torch.all(got[big].abs() == 65504.0) and torch.all(torch.sign(got[big]) == torch.sign(ref[big]))
+    ok = ref.abs() < 60000.0
+    assert ((got[ok] - ref[ok]).abs() <= ref[ok].abs() * 2.0 ** -10 + 0.05).all()
+
+
 @pytest.mark.parametrize("prec", [1, 3])
 @pytest.mark.parametrize("M,N,K,kind", [(20800, 2304, 768, "bias"), (20800, 768, 768, "scale"), (4099, 3072, 768, "gelu"), (4099, 768, 3072, "scale"),
                                         (2600, 1152, 384, "bias"), (2600, 384, 1536, "scale"), (1300, 1536, 384, "gelu"), (5840, 1024, 1024, "bias")])
