@@ -51,6 +51,7 @@ struct ChainP {
   // v_mfma_f32_16x16x32_f16 per product.  Half the weight bytes - which is what bounds the kernel - and a third of the MFMAs.
   int h1 = 0;
   ChainStage st[CH_MAX_STAGES];
+  int trace_stage = -1;        // TRACE: stage whose K loop / epilogue is stamped finely into trace[64..127]
   unsigned* trace = nullptr;   // EC_CHAIN_TRACE=1 (debug instantiation): s_memtime stamps of one mid-grid workgroup's wave 0
 };
 

@@ -72,6 +72,12 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
     }
   };
   stamp();
+  int fi = 0;   // fine stamps of stage p.trace_stage: trace[64 + fi]
+  auto fstamp = [&](bool on) __attribute__((always_inline)) {
+    if constexpr (TRACE) {
+      if (tr_on && on && fi < 63) p.trace[64 + fi++] = (unsigned)__builtin_amdgcn_s_memtime();
+    }
+  };
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int slab = blockIdx.x / p.split, part = blockIdx.x - slab * p.split;
@@ -205,6 +211,7 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
           acc[mi][j] = v;
         }
       }
+      fstamp(s == p.trace_stage);   // F: part 1 done (bias / act / resid)
       if (ln) {
         // LayerNorm over the N = 256 columns of the (only) pass - every wave is here: mean, then centred squares
         float mean[2], rstd[2];
@@ -255,6 +262,7 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
           for (int mi = 0; mi < 2; ++mi) acc[mi][j] = (acc[mi][j] - mean[mi]) * rstd[mi] * lg[j] + lb[j];
         }
       }
+      fstamp(s == p.trace_stage);   // F: LayerNorm done
       const bool kp_sine = S.kp_w && S.kp_dim_t;
       if (S.kp_w) {
         // keypoint-branch tail (see ChainStage): two dot products per row over the 256 columns - 4 columns x 2 fragments per lane, the
@@ -341,6 +349,7 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
         }
       }
       load_bias(f0_next);   // the next pass's, a whole pass ahead
+      fstamp(s == p.trace_stage);   // F: part 2 done (stores, LDS write-back)
     };
 
     WBatch b0, b1;
@@ -355,6 +364,10 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
     // The first weight batch and the first pass's epilogue operands are requested BEFORE the stage's input is staged: they
     // land under the staging and its two barriers instead of in front of the first MFMA / inside the epilogue.
     stamp();   // stage start
+    // (round 3, measured and reverted: requesting BOTH register buffers here.  EC_CHAIN_TRACE_STAGE stamps: a batch takes ~2 400
+    //  cycles to arrive whether it carries 16 or 48 MFMAs; with two batches in flight at the stage start the first barrier simply
+    //  waits for both - "loads + barrier" 3 000 -> 4 500-5 000 cycles, K loop -1 000, whole chains +2...+6 k cycles, and the second
+    //  buffer's longer live range spills 8 VGPRs.  The batches arrive at the CU's ~53 B/clk one behind the other.)
     load_batch(b0, 0);
     load_bias(pass_of(0) * 16 + wave * 2);
     if (S.resid) {
@@ -404,11 +417,13 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
       load_batch(b1, i + 1);
       __builtin_amdgcn_sched_barrier(0);
       compute_batch(b0, batch_of(bi) << 2);
+      fstamp(s == p.trace_stage);   // F: batch computed
       step();
       if (++i >= T) break;
       load_batch(b0, i + 1);
       __builtin_amdgcn_sched_barrier(0);
       compute_batch(b1, batch_of(bi) << 2);
+      fstamp(s == p.trace_stage);   // F: batch computed
       step();
       ++i;
     }
@@ -479,10 +494,11 @@ int run_chain(const ChainP& p, hipStream_t st) {
   static const bool trace = getenv("EC_CHAIN_TRACE") != nullptr;
   if (trace) {   // diagnostics: per-stage cycle counts of one workgroup (synchronises the stream: not for timing runs)
     unsigned* d_tr = nullptr;
-    EC_HIP(hipMalloc((void**)&d_tr, 64 * sizeof(unsigned)));
-    EC_HIP(hipMemsetAsync(d_tr, 0, 64 * sizeof(unsigned), st));
+    EC_HIP(hipMalloc((void**)&d_tr, 128 * sizeof(unsigned)));
+    EC_HIP(hipMemsetAsync(d_tr, 0, 128 * sizeof(unsigned), st));
     ChainP q = p;
     q.trace = d_tr;
+    q.trace_stage = getenv("EC_CHAIN_TRACE_STAGE") ? atoi(getenv("EC_CHAIN_TRACE_STAGE")) : -1;
     static const int warm = atoi(getenv("EC_CHAIN_TRACE"));   // 2: run the launch once untraced first (weights warm in the L2s)
     if (warm == 2) {
       hipLaunchKernelGGL(chain_kernel<false>, grid, dim3(512), p.lds_bytes, st, p);
@@ -491,7 +507,7 @@ int run_chain(const ChainP& p, hipStream_t st) {
     hipLaunchKernelGGL(chain_kernel<true>, grid, dim3(512), p.lds_bytes, st, q);
     EC_LAUNCH_CHECK();
     EC_HIP(hipStreamSynchronize(st));
-    unsigned h[64];
+    unsigned h[128];
     EC_HIP(hipMemcpy(h, d_tr, sizeof(h), hipMemcpyDeviceToHost));
     (void)hipFree(d_tr);
     fprintf(stderr, "[chain trace] rows %d stages %d split %d h1 %d:", p.rows, p.n_stages, p.split, p.h1);
@@ -501,6 +517,12 @@ int run_chain(const ChainP& p, hipStream_t st) {
               t[2] - t[1], t[3] - t[2]);
     }
     fprintf(stderr, " | total %u (entry -> first stage %u)\n", h[4 * p.n_stages] - h[0], h[1] - h[0]);
+    if (q.trace_stage >= 0 && q.trace_stage < p.n_stages) {   // fine stamps: deltas from "input staged" of that stage
+      fprintf(stderr, "[chain fine] stage %d (N%d K%d):", q.trace_stage, p.st[q.trace_stage].N, p.st[q.trace_stage].K);
+      unsigned prev = h[1 + 4 * q.trace_stage + 2];
+      for (int i = 64; i < 128 && h[i]; ++i) { fprintf(stderr, " %u", h[i] - prev); prev = h[i]; }
+      fprintf(stderr, "\n");
+    }
     return 0;
   }
   hipLaunchKernelGGL(chain_kernel<false>, grid, dim3(512), p.lds_bytes, st, p);
