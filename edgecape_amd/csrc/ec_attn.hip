@@ -673,18 +673,9 @@ int attention(const AttnP& p, hipStream_t st) {
   }
   if (!p.bf16) {
     EC_REQUIRE(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldv % 4 == 0 && p.ldo % 4 == 0, -1, "attention: strides must be multiples of 4");
-    // few workgroups (Lq = 100 keypoint queries: one 128-query block per (batch, head) = 1 workgroup per CU): use 2-wave
-    // workgroups of 64 queries so two of them share a CU and one computes while the other stages its K/V tile
-    static const bool allow_narrow = getenv("EC_ATTN_NARROW") != nullptr;   // measured slower on MI355X (80 vs 65 us at Lq=100, Lk=324)
-    const bool narrow = allow_narrow && (long)grid.x * grid.y * grid.z < 1024 && p.Lq > 32;
-    if (narrow) {
-      grid.x = (p.Lq + 63) / 64;
-      if (p.hd == 64) hipLaunchKernelGGL((attn_f32_kernel<64, 2>), grid, dim3(128), 0, st, p);
-      else hipLaunchKernelGGL((attn_f32_kernel<32, 2>), grid, dim3(128), 0, st, p);
-    } else {
-      if (p.hd == 64) hipLaunchKernelGGL((attn_f32_kernel<64, 4>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((attn_f32_kernel<32, 4>), grid, dim3(256), 0, st, p);
-    }
+    // (2-wave workgroups of 64 queries for the few-workgroup case, Lq = 100, measured slower - 80 vs 65 us at Lk = 324 - removed in round 3)
+    if (p.hd == 64) hipLaunchKernelGGL((attn_f32_kernel<64, 4>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_f32_kernel<32, 4>), grid, dim3(256), 0, st, p);
     EC_LAUNCH_CHECK();
     return 0;
   }

@@ -565,9 +565,8 @@ int gemm_nt(const GemmP& p, hipStream_t st) {
   // CUs: pick the tile minimising  ceil(tiles / CUs) * tile_area / efficiency.  256x256 only pays for the big backbone
   // GEMMs (fp32 parity mode) where operand re-reads dominate.
   static const int force = getenv("EC_GEMM_TILE") ? atoi(getenv("EC_GEMM_TILE")) : 0;
-  // NS-deep stage ring: measured NEUTRAL on MI355X for the head's shapes (kp 3200x256x256: 8.0 vs 8.2 us; 10368x256x768: 30 vs
-  // 37 us) - those kernels sit at the per-launch floor, not at the load latency - so the 2-stage ring stays the default.
-  static const bool deep = getenv("EC_GEMM_DEEP") && atoi(getenv("EC_GEMM_DEEP")) != 0;
+  // (a larger stage ring measured neutral on the head's shapes - kp 3200x256x256: 8.0 vs 8.2 us; 10368x256x768: 30 vs 37 us: those
+  // kernels sit at the per-launch floor, not at the load latency - and was removed in round 3: the 2-stage ring is the only form)
   static int ncu_dev[64] = {};
   int dev = 0;
   EC_HIP(hipGetDevice(&dev));
@@ -596,11 +595,11 @@ int gemm_nt(const GemmP& p, hipStream_t st) {
   }
   if (p.ab_bf16) {
     switch (sel) {
-      case 0: return (deep ? launch_cfg<GM_BF16, 256, 256, 2, 4, 2>(p, st, 1) : launch_cfg<GM_BF16, 256, 256, 2, 4, 2>(p, st, 1));
-      case 1: return (deep ? launch_cfg<GM_BF16, 256, 128, 4, 2, 3>(p, st, 1) : launch_cfg<GM_BF16, 256, 128, 4, 2, 2>(p, st, 1));
-      case 2: return (deep ? launch_cfg<GM_BF16, 128, 128, 2, 2, 4>(p, st, 1) : launch_cfg<GM_BF16, 128, 128, 2, 2, 2>(p, st, 2));
-      case 3: return (deep ? launch_cfg<GM_BF16, 128, 64, 2, 2, 3>(p, st, 2) : launch_cfg<GM_BF16, 128, 64, 2, 2, 2>(p, st, 3));
-      default: return (deep ? launch_cfg<GM_BF16, 64, 64, 2, 2, 4>(p, st, 2) : launch_cfg<GM_BF16, 64, 64, 2, 2, 2>(p, st, 4));
+      case 0: return launch_cfg<GM_BF16, 256, 256, 2, 4, 2>(p, st, 1);
+      case 1: return launch_cfg<GM_BF16, 256, 128, 4, 2, 2>(p, st, 1);
+      case 2: return launch_cfg<GM_BF16, 128, 128, 2, 2, 2>(p, st, 2);
+      case 3: return launch_cfg<GM_BF16, 128, 64, 2, 2, 2>(p, st, 3);
+      default: return launch_cfg<GM_BF16, 64, 64, 2, 2, 2>(p, st, 4);
     }
   }
   if (p.split == 2) {   // fp16x1: the single-pass form of the head's mixed precision
@@ -620,19 +619,19 @@ int gemm_nt(const GemmP& p, hipStream_t st) {
     if (force == 64256) return launch_cfg<GM_SPLIT, 64, 256, 2, 2, 2>(p, st, 2);
     if (force == 1281) return launch_cfg<GM_SPLIT, 128, 128, 4, 1, 2>(p, st, 2);
     switch (sel) {
-      case 0: return (deep ? launch_cfg<GM_SPLIT, 256, 256, 2, 4, 2>(p, st, 1) : launch_cfg<GM_SPLIT, 256, 256, 2, 4, 2>(p, st, 1));
-      case 1: return (deep ? launch_cfg<GM_SPLIT, 256, 128, 4, 2, 3>(p, st, 1) : launch_cfg<GM_SPLIT, 256, 128, 4, 2, 2>(p, st, 1));
-      case 2: return (deep ? launch_cfg<GM_SPLIT, 128, 128, 2, 2, 4>(p, st, 1) : launch_cfg<GM_SPLIT, 128, 128, 2, 2, 2>(p, st, 2));
-      case 3: return (deep ? launch_cfg<GM_SPLIT, 128, 64, 2, 2, 3>(p, st, 2) : launch_cfg<GM_SPLIT, 128, 64, 2, 2, 2>(p, st, 3));
-      default: return (deep ? launch_cfg<GM_SPLIT, 64, 64, 2, 2, 4>(p, st, 2) : launch_cfg<GM_SPLIT, 64, 64, 2, 2, 2>(p, st, 4));
+      case 0: return launch_cfg<GM_SPLIT, 256, 256, 2, 4, 2>(p, st, 1);
+      case 1: return launch_cfg<GM_SPLIT, 256, 128, 4, 2, 2>(p, st, 1);
+      case 2: return launch_cfg<GM_SPLIT, 128, 128, 2, 2, 2>(p, st, 2);
+      case 3: return launch_cfg<GM_SPLIT, 128, 64, 2, 2, 2>(p, st, 3);
+      default: return launch_cfg<GM_SPLIT, 64, 64, 2, 2, 2>(p, st, 4);
     }
   }
   switch (sel) {
-    case 0: return (deep ? launch_cfg<GM_F32, 256, 256, 2, 4, 2>(p, st, 1) : launch_cfg<GM_F32, 256, 256, 2, 4, 2>(p, st, 1));
-    case 1: return (deep ? launch_cfg<GM_F32, 256, 128, 4, 2, 3>(p, st, 1) : launch_cfg<GM_F32, 256, 128, 4, 2, 2>(p, st, 1));
-    case 2: return (deep ? launch_cfg<GM_F32, 128, 128, 2, 2, 4>(p, st, 1) : launch_cfg<GM_F32, 128, 128, 2, 2, 2>(p, st, 2));
-    case 3: return (deep ? launch_cfg<GM_F32, 128, 64, 2, 2, 3>(p, st, 2) : launch_cfg<GM_F32, 128, 64, 2, 2, 2>(p, st, 3));
-    default: return (deep ? launch_cfg<GM_F32, 64, 64, 2, 2, 4>(p, st, 2) : launch_cfg<GM_F32, 64, 64, 2, 2, 2>(p, st, 4));
+    case 0: return launch_cfg<GM_F32, 256, 256, 2, 4, 2>(p, st, 1);
+    case 1: return launch_cfg<GM_F32, 256, 128, 4, 2, 2>(p, st, 1);
+    case 2: return launch_cfg<GM_F32, 128, 128, 2, 2, 2>(p, st, 2);
+    case 3: return launch_cfg<GM_F32, 128, 64, 2, 2, 2>(p, st, 3);
+    default: return launch_cfg<GM_F32, 64, 64, 2, 2, 2>(p, st, 4);
   }
 }
 
@@ -690,10 +689,9 @@ void split_pack_weights_h1(const float* W, long n_rows, long K, float* out) {
 
 int bgemm_small(const BgemmP& p, hipStream_t st) {
   EC_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0 && p.batch > 0, -1, "bgemm_small: empty problem");
-  static const bool valu_only = getenv("EC_BGEMM_VALU") != nullptr;   // A/B switch
   const bool aligned = p.lda % 4 == 0 && p.sA % 4 == 0 && ((uintptr_t)p.A % 16) == 0 &&
                        (!p.transB || (p.ldb % 4 == 0 && p.sB % 4 == 0 && ((uintptr_t)p.B % 16) == 0));
-  if (aligned && !valu_only) {   // 16-byte operand loads need 4-float aligned rows (K = 100: yes; the demos' odd K: VALU kernel below)
+  if (aligned) {   // 16-byte operand loads need 4-float aligned rows (K = 100: yes; the demos' odd K: VALU kernel below)
     dim3 g((p.N + 127) / 128, (p.M + 31) / 32, p.batch);
     if (p.transB) hipLaunchKernelGGL(bgemm_mfma_kernel<true>, g, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(bgemm_mfma_kernel<false>, g, dim3(256), 0, st, p);

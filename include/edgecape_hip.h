@@ -95,9 +95,9 @@ typedef struct ec_outputs {
 } ec_outputs;
 
 const char* ec_last_error(void);
-/* ABI version of the library (EC_ABI_VERSION of the header it was built from): bumped whenever a struct layout, an enum value
+/* ABI version of the library (EC_ABI_VERSION of the header it was built from): bumped whenever a struct layout, an enum value, the set of entry points
    or a signature changes, so a binding can refuse a stale prebuilt library instead of calling it with mismatched layouts. */
-#define EC_ABI_VERSION 2
+#define EC_ABI_VERSION 3
 int ec_version(void);
 /* sizeof(ec_config) / sizeof(ec_outputs) as the library was compiled: a binding compares them with its own mirrors. */
 int ec_abi_sizes(int* config_bytes, int* outputs_bytes);
