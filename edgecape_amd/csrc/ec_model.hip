@@ -131,7 +131,7 @@ struct ec_model {
   int32_t *d_edges = nullptr, *d_off = nullptr; int edges_cap = 0;
   int32_t *h_edges = nullptr, *h_off = nullptr;   // pinned staging of the skeleton edge lists
   hipEvent_t ev_edges = nullptr;
-  float *Wp, *pooled, *sk, *valid, *binary, *adj_r1, *adj1, *P, *kn, *kp_ref, *attn_adj;
+  float *pooled, *sk, *valid, *binary, *adj_r1, *adj1, *P, *kn, *kp_ref, *attn_adj;
   uint8_t *kmask, *kmask_fixed;
   float *s_mem, *s_x, *s_tmp, *s_qkv, *s_att, *s_qc, *s_kv, *s_y, *s_z, *s_qimg, *s_kvk, *s_attimg, *s_tmpimg;
   bf16_t* s_mem16 = nullptr;   // fp16 copy of the skeleton head's image memory, written by norm4 (head mixed precision)
@@ -536,8 +536,7 @@ struct LayerIO {
 static int project_image_kv(ec_model* m, const DecLayer& L, const float* mem, long s_mem, int nb, float* kv, hipStream_t st,
                             const bf16_t* mem16 = nullptr) {
   const int d = m->d, E = m->E, HW = m->HW;
-  static const bool kv16_off = getenv("EC_KV16") && atoi(getenv("EC_KV16")) == 0;   // A/B switch
-  if (mem16 && !kv16_off && L.ca_kv.wf16 && L.ca_kv.h1 && s_mem == (long)HW * d && (long)nb * HW >= 1024) {
+  if (mem16 && L.ca_kv.wf16 && L.ca_kv.h1 && s_mem == (long)HW * d && (long)nb * HW >= 1024) {
     // single-pass fp16 layer, contiguous image rows and an fp16 copy of them at hand (norm4 wrote it): one [nb * HW, 2E] problem on the
     // backbone's 8-phase 16-bit GEMM (fp32 output + positional table) - the same products and fp32 accumulation as the fp16x1 path of
     // gemm_nt, which rounds A to fp16 in registers
@@ -562,8 +561,7 @@ static int project_image_kv(ec_model* m, const DecLayer& L, const float* mem, lo
 // needs the image memory; the rest needs the layer's final token state x.  `x_read` (optional) is recorded once x has been read.
 static int image_update_q(ec_model* m, const DecLayer& L, const float* mem, int nb, float* qimg, hipStream_t st,
                           const bf16_t* mem16 = nullptr) {
-  static const bool kv16_off = getenv("EC_KV16") && atoi(getenv("EC_KV16")) == 0;
-  if (mem16 && !kv16_off && L.i2t_q.wf16 && L.i2t_q.h1 && (long)nb * m->HW >= 1024) {   // (see project_image_kv)
+  if (mem16 && L.i2t_q.wf16 && L.i2t_q.h1 && (long)nb * m->HW >= 1024) {   // (see project_image_kv)
     GemmP q;
     q.A = mem16; q.lda = m->d; q.ab_bf16 = 1; q.h_f16 = 1;
     q.B = L.i2t_q.wf16; q.ldb = m->d; q.bias = L.i2t_q.b;
@@ -604,8 +602,7 @@ struct ChainBuild {
     p.rows = rows; p.lds_bytes = top;
     p.h1 = p.st[0].h1;   // one arithmetic per chain (run_chain checks that every stage was packed for it)
     // two workgroups per slab while that still fits one round of the chip and there is a stage to deal out
-    static const bool no_split = getenv("EC_CHAIN_SPLIT") && atoi(getenv("EC_CHAIN_SPLIT")) == 0;   // A/B switch
-    p.split = (may_split && !no_split && p.n_stages > 1 && ((rows + CH_BM - 1) / CH_BM) * 2 <= 256) ? 2 : 1;
+    p.split = (may_split && p.n_stages > 1 && ((rows + CH_BM - 1) / CH_BM) * 2 <= 256) ? 2 : 1;
     return run_chain(p, st);
   }
 };
@@ -847,21 +844,10 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
   }
 
   // (2) support keypoint pooling + query_proj (head.py:175-188)
-  static const bool pool_dense = getenv("EC_POOL_DENSE") != nullptr;   // A/B: tap-weight matrix + dense batched GEMM
-  for (int s = 0; s < S; ++s) {
-    if (!pool_dense) {
-      RUN(pool_gather(target_s[s], mask_s, 1.f / (float)S, fs[s], m->pooled, s == 0 ? 0.f : 1.f, bs, K, m->cfg.heatmap_size, g, C, st));
-      continue;
-    }
-    RUN(pool_weights(target_s[s], mask_s, 1.f / (float)S, m->Wp, bs, K, m->cfg.heatmap_size, g, st));
-    BgemmP p;
-    p.A = m->Wp; p.lda = HW; p.sA = (long)K * HW;
-    p.B = fs[s]; p.ldb = C; p.sB = (long)HW * C; p.transB = 0;
-    p.C = m->pooled; p.ldc = C; p.sC = (long)K * C;
-    p.M = K; p.N = C; p.K = HW; p.batch = bs;
-    p.beta = s == 0 ? 0.f : 1.f;
-    RUN(bgemm_small(p, st));
-  }
+  // (one fused kernel per shot: tap weights of the 18x18 grid from the heatmap, then the weighted sum of the non-zero cells' feature
+  //  rows; the round-1 form - tap-weight matrix + dense batched GEMM - was removed in round 3)
+  for (int s = 0; s < S; ++s)
+    RUN(pool_gather(target_s[s], mask_s, 1.f / (float)S, fs[s], m->pooled, s == 0 ? 0.f : 1.f, bs, K, m->cfg.heatmap_size, g, C, st));
   RUN(linear(m->pooled, C, false, m->query_proj, ss.sk, d, false, Mk, ACT_NONE, st));
   m->taps["support_keypoints"] = {ss.sk, (long)Mk * d};
   RUN(tl_mark(m, "S.pooled", st));
@@ -1526,7 +1512,7 @@ int ec_finalize(ec_handle m) {
   const size_t Mk = (size_t)bs * K, Mi = (size_t)bs * HW, KK = (size_t)K * K;
   const int Fs = m->cfg.skel_ffn_dim, Fd = m->cfg.ffn_dim;
 #define WS(ptr, count) if ((rc = dalloc(m, &m->ptr, (size_t)(count)))) return rc
-  WS(Wp, Mk * HW); WS(pooled, Mk * C); WS(sk, Mk * d); WS(valid, Mk); WS(kmask, Mk); WS(kmask_fixed, Mk);
+  WS(pooled, Mk * C); WS(sk, Mk * d); WS(valid, Mk); WS(kmask, Mk); WS(kmask_fixed, Mk);
   WS(binary, bs * KK); WS(adj_r1, bs * KK); WS(adj1, bs * KK); WS(P, bs * KK); WS(kn, Mk * d); WS(kp_ref, Mk * d);
   WS(attn_adj, 5 * bs * KK);
   WS(s_mem, S * Mi * d); WS(s_x, S * Mk * d); WS(s_tmp, S * Mk * d); WS(s_qkv, S * Mk * 3 * d); WS(s_att, S * Mk * E);
@@ -1546,19 +1532,15 @@ int ec_finalize(ec_handle m) {
     m->overlap = !(ov && atoi(ov) == 0);
     m->timeline = getenv("EC_TIMELINE") != nullptr;
     if (m->overlap) {
-      // the support lane is the longer one (pooling + three two-way layers before the decoder can start): EC_SIDE_PRIO=1 gives it
-      // and its image lane the high stream priority (measured: no effect - the lanes hold one kernel in flight each)
-      int lo = 0, hi = 0;
-      EC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      const int prio = getenv("EC_SIDE_PRIO") ? hi : 0;
-      EC_HIP(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, prio));
+      // (a high stream priority for the support lane, the longer one, measured nothing - the lanes hold one kernel in flight each)
+      EC_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
       EC_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
       EC_HIP(hipEventCreateWithFlags(&m->ev_sk, hipEventDisableTiming));
       EC_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
       m->overlap_dec = !(ov && atoi(ov) == 1);   // EC_OVERLAP=1: support-side overlap only
       if (m->overlap_dec) {
         EC_HIP(hipStreamCreateWithFlags(&m->aux, hipStreamNonBlocking));
-        EC_HIP(hipStreamCreateWithPriority(&m->side2, hipStreamNonBlocking, prio));
+        EC_HIP(hipStreamCreateWithFlags(&m->side2, hipStreamNonBlocking));
         for (hipEvent_t& e : m->ev_aux) EC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (hipEvent_t& e : m->ev_sup) EC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       }

@@ -195,62 +195,8 @@ __device__ inline void bilinear_src(int dst, float scale, int in_size, int& i0, 
   l1 = s - (float)i0;
 }
 
-__global__ __launch_bounds__(256) void pool_weights_kernel(const float* target, const float* mask_s, float inv_shots,
-                                                           float* Wp, int K, int hm, int g) {
-  extern __shared__ float sm[];
-  float* t = sm;                 // hm*hm
-  float* tmp = t + hm * hm;      // g*hm : tmp[cy][x]
-  float* red = tmp + g * hm;     // 4
-  const int bk = blockIdx.x;     // b*K + k
-  const int tid = threadIdx.x;
-  const float msk = mask_s[bk];
-  float* out = Wp + (long)bk * g * g;
-  if (msk == 0.f) {   // padded keypoint slot: the pooled feature is multiplied by mask_s = 0 (head.py:187) -> weights 0, skip the heatmap
-    for (int cell = tid; cell < g * g; cell += 256) out[cell] = 0.f;
-    return;
-  }
-  const float* src = target + (long)bk * hm * hm;
-  float s = 0.f;
-  for (int i = tid; i < hm * hm; i += 256) {
-    const float v = src[i];
-    t[i] = v;
-    s += v;
-  }
-  s = wave_sum(s);
-  if ((tid & 63) == 0) red[tid >> 6] = s;
-  __syncthreads();
-  const float total = red[0] + red[1] + red[2] + red[3];
-  const float scale = (float)g / (float)hm;
-  for (int i = tid; i < g * hm; i += 256) tmp[i] = 0.f;
-  __syncthreads();
-  // tmp[cy][x] = sum_y wy(cy, y) t[y][x]   (thread per x column, serial over y: deterministic)
-  for (int x = tid; x < hm; x += 256) {
-    for (int y = 0; y < hm; ++y) {
-      int y0, y1; float ly;
-      bilinear_src(y, scale, g, y0, y1, ly);
-      const float v = t[y * hm + x];
-      tmp[y0 * hm + x] += (1.f - ly) * v;
-      tmp[y1 * hm + x] += ly * v;
-    }
-  }
-  __syncthreads();
-  const float norm = msk * inv_shots / (total + 1e-8f);
-  for (int cell = tid; cell < g * g; cell += 256) {
-    const int cy = cell / g, cx = cell % g;
-    float acc = 0.f;
-    for (int x = 0; x < hm; ++x) {
-      int x0, x1; float lx;
-      bilinear_src(x, scale, g, x0, x1, lx);
-      float w = 0.f;
-      if (x0 == cx) w += 1.f - lx;
-      if (x1 == cx) w += lx;
-      if (w != 0.f) acc += w * tmp[cy * hm + x];
-    }
-    out[cell] = acc * norm;
-  }
-}
-
-// Fused support-keypoint pooling (head.py:175-186): the same tap weights as pool_weights_kernel, then the pooled feature
+// Fused support-keypoint pooling (head.py:175-186): the heatmap's bilinear tap weights over the g x g token grid (the adjoint of
+// the reference's resize, normalised by the heatmap sum), then the pooled feature
 //   pooled[b,k,:] (+)= sum_cell w[cell] * F[b,cell,:]
 // directly, visiting only the non-zero weights in cell order.  The targets of this pipeline are Gaussian blobs (sigma 2 on the
 // 64x64 heatmap = ~4x4 of the 18x18 token grid), so ~16-30 of the 324 cells are non-zero and the dense [K,HW]@[HW,C]
@@ -879,15 +825,6 @@ int nchw_to_tokens(const float* src, float* dst, int n, int C, int HW, hipStream
 }
 int tokens_to_nchw(const float* src, float* dst, int n, int C, int HW, hipStream_t st) {
   hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 32), cdiv(HW, 32), n), dim3(256), 0, st, src, dst, HW, C);
-  EC_LAUNCH_CHECK();
-  return 0;
-}
-
-int pool_weights(const float* target, const float* mask_s, float inv_shots, float* Wp, int bs, int K, int hm, int g,
-                 hipStream_t st) {
-  const size_t lds = (size_t)(hm * hm + g * hm + 4) * sizeof(float);
-  EC_REQUIRE(lds <= 64 * 1024, -1, "pool_weights: heatmap too large for LDS");
-  hipLaunchKernelGGL(pool_weights_kernel, dim3(bs * K), dim3(256), lds, st, target, mask_s, inv_shots, Wp, K, hm, g);
   EC_LAUNCH_CHECK();
   return 0;
 }
