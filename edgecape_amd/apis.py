@@ -132,10 +132,25 @@ def _per_sample(result):
         yield {"preds": preds[i:i + 1], "boxes": boxes[i:i + 1], "bbox_ids": [bid], "image_paths": [path]}
 
 
-def single_gpu_test(model, data_loader):
-    """apis/test.py:14-47.  Returns the list of per-sample result dicts in loader order."""
+def single_gpu_test(model, data_loader, pipelined=False):
+    """apis/test.py:14-47.  Returns the list of per-sample result dicts in loader order.
+
+    pipelined=True (models with submit() / collect(), i.e. edgecape_amd.detector.EdgeCape): batch i+1 is submitted before batch i is
+    collected, so batch i's decoder phase and host decode overlap batch i+1's backbone (ec_forward_pipelined); same results, same
+    order - the reference's loop (apis/test.py:31-33) only needs them in order."""
     model.eval()
     out = []
+    if pipelined and hasattr(model, "submit"):
+        pending = None
+        for data in data_loader:
+            data = {k: v for k, v in data.items() if k != "return_loss"}
+            ticket = model.submit(**data)
+            if pending is not None:
+                out.extend(_per_sample(model.collect(pending)))
+            pending = ticket
+        if pending is not None:
+            out.extend(_per_sample(model.collect(pending)))
+        return out
     for data in data_loader:
         out.extend(_per_sample(model(return_loss=False, **data)))
     return out
@@ -213,14 +228,14 @@ def collect_results(local_results, size, device=None, all_ranks=False):
     return ordered[:size]                                 # "the dataloader may pad some samples"
 
 
-def multi_gpu_test(model, data_loader, size=None, tmpdir=None, gpu_collect=True, all_ranks=False):
+def multi_gpu_test(model, data_loader, size=None, tmpdir=None, gpu_collect=True, all_ranks=False, pipelined=False):
     """apis/test.py:50-91.  `data_loader` yields this rank's shard; `size` defaults to len(data_loader.dataset)."""
     if size is None:
         ds = getattr(data_loader, "dataset", None)
         if ds is None:
             raise ValueError("multi_gpu_test needs `size` (len(dataset)) when the loader has no .dataset")
         size = len(ds)
-    return collect_results(single_gpu_test(model, data_loader), size, all_ranks=all_ranks)
+    return collect_results(single_gpu_test(model, data_loader, pipelined=pipelined), size, all_ranks=all_ranks)
 
 
 def gather_predictions(local_preds, n_total, device=None):

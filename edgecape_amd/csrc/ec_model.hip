@@ -96,6 +96,12 @@ struct ec_model {
   hipEvent_t ev_aux[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_sup[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool overlap_dec = false;
+  // ec_forward_pipelined (round 3): the decoder phase of a pipelined call runs on its own stream `dq` and is NOT joined at the end of
+  // the call - it overlaps the next call's backbone; whatever touches the head workspace next (any entry point) first makes its
+  // stream wait for ev_dq_done.  dq_active: the call being enqueued is a pipelined one; dq_pending: a decoder may still be running.
+  hipStream_t dq = nullptr;
+  hipEvent_t ev_dq_start = nullptr, ev_dq_done = nullptr;
+  bool dq_active = false, dq_pending = false;
   // EC_TIMELINE=1: timed HIP events at the head's milestones on every stream, printed (us from the head's start) after a
   // device sync at the end of the call - the unprofiled picture of which lane is critical (rocprofv3 makes the head host-bound)
   bool timeline = false;
@@ -1079,6 +1085,12 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
   RUN(fork(ev_fork));                      // proposals (pts[0]) and the encoder output are final
   RUN(ref_point_embed(pts));
   RUN(mark(ev_qpe));
+  const bool deferred = m->dq_active && m->dq != nullptr;
+  if (deferred) {   // pipelined call: the decoder phase on its own stream (see ec_model::dq)
+    EC_HIP(hipEventRecord(m->ev_dq_start, st));
+    EC_HIP(hipStreamWaitEvent(m->dq, m->ev_dq_start, 0));
+    st = m->dq;
+  }
   RUN(copy3d(m->d_qin, 2 * d, (long)K * 2 * d, kp, d, s_tok, bs, K, d, st));
   // adjacency / Markov stack from the support side: first needed by layer 0's self-attention kernel (bias, key mask) - its input
   // projection runs before the wait.  Without the precomputed bias stack the bias MLP itself reads attn_adj: wait here.
@@ -1194,6 +1206,10 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     EC_HIP(hipStreamWaitEvent(st, ev_done, 0));
   }
   RUN(tl_mark(m, "Q.end", st));
+  if (deferred) {
+    EC_HIP(hipEventRecord(m->ev_dq_done, m->dq));
+    m->dq_pending = true;
+  }
   m->taps["hs"] = {m->d_hs, (long)m->dec.size() * Mk * d};
   return 0;
 }
@@ -1222,7 +1238,7 @@ static SupportState workspace_support(ec_model* m, const ec_outputs* out) {
 // returns, so drain the helper streams before reporting the error.
 static int join_on_error(ec_model* m, int rc) {
   if (rc == 0) return 0;
-  for (hipStream_t s : {m->side, m->side2, m->aux})
+  for (hipStream_t s : {m->side, m->side2, m->aux, m->dq})
     if (s) (void)hipStreamSynchronize(s);
   return rc;
 }
@@ -1243,6 +1259,16 @@ static int run_head(ec_model* m, const float* fq, const float* const* fs, const 
   RUN(join_on_error(m, run_head_support(m, fs, target_s, mask_s, bs, S, st, ss)));
   RUN(join_on_error(m, run_head_query(m, fq, bs, st, out, ss)));
   return tl_dump(m);
+}
+
+// A pipelined call's decoder may still own the head workspace (and write its caller's outputs): every entry point that touches the
+// head makes its stream wait for it first.  Cheap when nothing is pending.
+static int wait_pending_decoder(ec_model* m, hipStream_t st) {
+  if (m->dq && m->dq_pending) {
+    EC_HIP(hipStreamWaitEvent(st, m->ev_dq_done, 0));
+    m->dq_pending = false;
+  }
+  return 0;
 }
 
 static int upload_edges(ec_model* m, const int32_t* edges, const int32_t* off, int bs, hipStream_t st) {
@@ -1342,6 +1368,8 @@ int ec_destroy(ec_handle m) {
   if (m->h_off) (void)hipHostFree(m->h_off);
   if (m->ev_edges) (void)hipEventDestroy(m->ev_edges);
   for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
+  if (m->dq) { (void)hipStreamSynchronize(m->dq); (void)hipStreamDestroy(m->dq); }
+  for (hipEvent_t e : {m->ev_dq_start, m->ev_dq_done}) if (e) (void)hipEventDestroy(e);
   if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
   for (hipEvent_t e : {m->ev_fork, m->ev_sk, m->ev_join}) if (e) (void)hipEventDestroy(e);
   if (m->aux) { (void)hipStreamSynchronize(m->aux); (void)hipStreamDestroy(m->aux); }
@@ -1531,6 +1559,10 @@ int ec_finalize(ec_handle m) {
     const char* ov = getenv("EC_OVERLAP");
     m->overlap = !(ov && atoi(ov) == 0);
     m->timeline = getenv("EC_TIMELINE") != nullptr;
+    // the decoder stream of the pipelined entry point (ec_forward_pipelined)
+    EC_HIP(hipStreamCreateWithFlags(&m->dq, hipStreamNonBlocking));
+    EC_HIP(hipEventCreateWithFlags(&m->ev_dq_start, hipEventDisableTiming));
+    EC_HIP(hipEventCreateWithFlags(&m->ev_dq_done, hipEventDisableTiming));
     if (m->overlap) {
       // (a high stream priority for the support lane, the longer one, measured nothing - the lanes hold one kernel in flight each)
       EC_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
@@ -1573,6 +1605,7 @@ int ec_head(ec_handle m, const float* fq, const float* const* fs, int layout, co
   RUN(check_head_args(m, bs, S, out));
   EC_REQUIRE(fq && fs && target_s && mask_s, EC_ERR_ARG, "null input");
   hipStream_t st = (hipStream_t)stream;
+  RUN(wait_pending_decoder(m, st));
   RUN(upload_edges(m, edges, off, bs, st));
   const size_t per = (size_t)bs * m->HW * m->C;
   std::vector<const float*> fsp(S);
@@ -1590,11 +1623,13 @@ int ec_head(ec_handle m, const float* fq, const float* const* fs, int layout, co
   return run_head(m, fqp, fsp.data(), target_s, mask_s, bs, S, st, out);
 }
 
-int ec_forward(ec_handle m, const float* img_q, const float* const* img_s, const float* const* target_s, const float* mask_s,
-               const int32_t* edges, const int32_t* off, int bs, int S, void* stream, const ec_outputs* out) {
+static int forward_impl(ec_handle m, const float* img_q, const float* const* img_s, const float* const* target_s, const float* mask_s,
+                        const int32_t* edges, const int32_t* off, int bs, int S, void* stream, const ec_outputs* out, bool pipelined) {
   RUN(check_head_args(m, bs, S, out));
   EC_REQUIRE(img_q && img_s && target_s && mask_s, EC_ERR_ARG, "null input");
   hipStream_t st = (hipStream_t)stream;
+  struct Scope { ec_model* m; ~Scope() { m->dq_active = false; } } scope{m};
+  m->dq_active = pipelined;
   RUN(upload_edges(m, edges, off, bs, st));
   const size_t per = (size_t)bs * m->HW * m->C;
   // EdgeCape.extract_features (EdgeCape.py:186-191): the same backbone on the query and on every support image
@@ -1604,9 +1639,27 @@ int ec_forward(ec_handle m, const float* img_q, const float* const* img_s, const
     srcs[1 + s] = img_s[s];
     fsp[s] = m->feat + (1 + s) * per;
   }
-  RUN(run_backbone(m, srcs.data(), 1 + S, bs, m->feat, st));
+  RUN(run_backbone(m, srcs.data(), 1 + S, bs, m->feat, st));   // (beside the previous pipelined call's decoder, if one is pending)
   m->taps["feature_q"] = {m->feat, (long)per};
+  RUN(wait_pending_decoder(m, st));                            // ... which owns the head workspace until it is done
   return run_head(m, m->feat, fsp.data(), target_s, mask_s, bs, S, st, out);
+}
+
+int ec_forward(ec_handle m, const float* img_q, const float* const* img_s, const float* const* target_s, const float* mask_s,
+               const int32_t* edges, const int32_t* off, int bs, int S, void* stream, const ec_outputs* out) {
+  return forward_impl(m, img_q, img_s, target_s, mask_s, edges, off, bs, S, stream, out, false);
+}
+
+// Pipelined forward (header): as ec_forward, but the decoder phase is left running on the library's decoder stream.
+int ec_forward_pipelined(ec_handle m, const float* img_q, const float* const* img_s, const float* const* target_s, const float* mask_s,
+                         const int32_t* edges, const int32_t* off, int bs, int S, void* stream, const ec_outputs* out) {
+  return forward_impl(m, img_q, img_s, target_s, mask_s, edges, off, bs, S, stream, out, true);
+}
+
+int ec_pipeline_flush(ec_handle m, void* stream) {
+  EC_REQUIRE(m && m->finalized, EC_ERR_STATE, "model not finalized");
+  if (m->dq && m->dq_pending) EC_HIP(hipStreamWaitEvent((hipStream_t)stream, m->ev_dq_done, 0));   // (dq_pending stays: see header)
+  return EC_OK;
 }
 
 // ---- support-side episode cache -------------------------------------------------------------
@@ -1650,6 +1703,7 @@ int ec_support_encode(ec_handle m, ec_support_t c, const float* const* img_s, co
   EC_REQUIRE(img_s && target_s && mask_s, EC_ERR_ARG, "null input");
   EC_REQUIRE(n_episodes > 0 && n_episodes <= c->cap && S > 0 && S <= m->cfg.max_shots, EC_ERR_ARG, "n_episodes / S exceed the configured maxima");
   hipStream_t st = (hipStream_t)stream;
+  RUN(wait_pending_decoder(m, st));
   RUN(upload_edges(m, edges, off, n_episodes, st));
   const size_t per = (size_t)n_episodes * m->HW * m->C;
   std::vector<const float*> fsp(S);
@@ -1669,6 +1723,7 @@ int ec_forward_cached(ec_handle m, ec_support_t c, const float* img_q, const int
   for (int b = 0; b < bs; ++b)
     EC_REQUIRE(episode_of_query[b] >= 0 && episode_of_query[b] < c->n, EC_ERR_ARG, "episode index out of range");
   hipStream_t st = (hipStream_t)stream;
+  RUN(wait_pending_decoder(m, st));
   EC_HIP(hipMemcpyAsync(c->d_idx, episode_of_query, (size_t)bs * 4, hipMemcpyHostToDevice, st));
   RUN(run_backbone(m, &img_q, 1, bs, m->feat, st));
   SupportState ws = workspace_support(m, out);

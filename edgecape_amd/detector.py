@@ -139,6 +139,51 @@ class EdgeCape:
         result["skeleton"] = skeleton
         return result
 
+    # ---- pipelined evaluation (ec_forward_pipelined): submit batch i+1 before collecting batch i --------------------
+    def submit(self, img_s, target_s, target_weight_s, img_q, target_q=None, target_weight_q=None, img_metas=None, vis_offset=True,
+               **kwargs):
+        """First half of forward_test for a back-to-back loop (apis.single_gpu_test(pipelined=True)): enqueue the device work of one
+        batch through ec_forward_pipelined and the device -> host copies of its results on a copy stream that waits for THIS
+        batch's decoder only; returns a ticket for collect().  The batch's decoder then overlaps the next submit()'s backbone."""
+        height, width = img_q.shape[-2:]
+        if height != width:
+            raise ValueError("square inputs only")
+        bs, K = img_q.shape[0], target_s[0].shape[1]
+        mask_s = torch.as_tensor(target_weight_s[0]).float()
+        for tw in target_weight_s:
+            mask_s = mask_s * torch.as_tensor(tw).float()
+        eng = self._engine(height, bs, len(img_s), K)
+        iq = eng._dev(img_q)
+        is_ = [eng._dev(x) for x in img_s]
+        ts = [eng._dev(t) for t in target_s]
+        ms = eng._dev(mask_s).reshape(bs, K)
+        edges, off = eng._edges([m["sample_skeleton"][0] for m in img_metas], bs)
+        outputs = eng._outputs(bs)
+        o = eng.forward_pipelined(iq, is_, ts, ms, edges, off, outputs)
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream()
+        cs = self._copy_stream
+        cs.wait_stream(torch.cuda.current_stream())      # phase 1 of this call (proposals, adjacency) ...
+        eng.pipeline_flush(cs)                           # ... and its decoder, not the next call's backbone
+        with torch.cuda.stream(cs):
+            host = [t.to("cpu", non_blocking=True) for t in (o["output_kpts"], o["initial_proposals"], o["adj"][0])]
+            done = torch.cuda.Event()
+            done.record(cs)
+        return dict(host=host, done=done, keep=(iq, is_, ts, ms, o), img_metas=img_metas, size=[width, height], vis_offset=vis_offset)
+
+    def collect(self, ticket):
+        """Second half: wait for the ticket's copies and build the reference's result dict (forward_test's host part)."""
+        ticket["done"].synchronize()
+        layers, proposals, skeleton = (h.numpy() for h in ticket["host"])
+        img_metas = ticket["img_metas"]
+        result = self.decode(img_metas, layers[-1], img_size=ticket["size"])
+        if ticket["vis_offset"]:
+            result["points"] = np.concatenate((proposals[None], layers), 0)
+        result["sample_image_file"] = [m["sample_image_file"] for m in img_metas]
+        result["skeleton"] = skeleton
+        ticket["keep"] = None
+        return result
+
     def decode(self, img_metas, output, img_size, **kwargs):
         """TwoStageHead.decode + transform_preds (head.py:324-387, post_transforms.py:150-194) for the whole batch at once:
         normalised [bs,K,2] coordinates -> pixels of the model input -> pixels of the source image through each query's

@@ -209,6 +209,22 @@ class HipEngine:
                                        C.byref(eo)))
         return o
 
+    def forward_pipelined(self, iq, is_, ts, ms, edges, off, outputs):
+        """ec_forward_pipelined on resident tensors: as forward_resident, but the decoder phase of this call stays in flight on the
+        library's decoder stream and overlaps the next call's backbone.  `outputs` (a pair from _outputs()) must not be shared with the
+        next call if its results are read after that call was enqueued; they are complete after pipeline_flush() on the reading
+        stream (or once the current stream has passed the next call's backbone)."""
+        o, eo = outputs
+        _lib.check(self.lib.ec_forward_pipelined(self.h, iq.data_ptr(), self._ptr_array(is_), self._ptr_array(ts), ms.data_ptr(),
+                                                 edges.ctypes.data, off.ctypes.data, iq.shape[0], len(is_), _lib.current_stream(),
+                                                 C.byref(eo)))
+        return o
+
+    def pipeline_flush(self, stream=None):
+        """Make `stream` (default: torch's current stream) wait for the decoder of the most recent pipelined call; no host sync."""
+        st = _lib.current_stream() if stream is None else stream.cuda_stream
+        _lib.check(self.lib.ec_pipeline_flush(self.h, st))
+
     # ---- support-side episode cache (include/edgecape_hip.h: ec_support_*) ---------------------------
     def support_encode(self, img_s, target_s, mask_s, skeletons, cache=None):
         """Run the support side once per episode: support backbone features, pooled support tokens, SkeletonPredictor.

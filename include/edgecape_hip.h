@@ -24,7 +24,8 @@
  *     (a hipStream_t passed as void*; NULL = the legacy default stream).
  *   - a handle is not thread-safe; use one handle per stream.  ec_forward / ec_head fork internal helper streams (support
  *     lane, image lane, decoder helper lane) off `stream` and join them back before returning control of `stream`'s order:
- *     everything the call enqueues is complete when `stream` reaches the end of the call's work.
+ *     everything the call enqueues is complete when `stream` reaches the end of the call's work (ec_forward_pipelined is the
+ *     one exception, see there).
  *   - layouts: images NCHW fp32; heatmaps [bs,K,hm,hm] fp32; features token-major [n,HW,C] fp32
  *     (EC_LAYOUT_TOKENS) or the reference's NCHW (EC_LAYOUT_NCHW).
  */
@@ -126,6 +127,23 @@ int ec_head(ec_handle h, const float* feature_q_dev, const float* const* feature
 int ec_forward(ec_handle h, const float* img_q_dev, const float* const* img_s_dev,
                const float* const* target_s_dev, const float* mask_s_dev, const int32_t* edges,
                const int32_t* edge_offsets, int bs, int S, void* stream, const ec_outputs* out);
+
+/* Pipelined forward for back-to-back batches (the reference's evaluation loop, EdgeCape/apis/test.py:31-33, only needs the results
+ * in order).  Same arguments and results as ec_forward, different completion rule: the backbone and the first phase of the head run
+ * on `stream` as usual, but the head's last phase - the decoder layers and keypoint branches, ~0.55 ms of dependent small kernels on
+ * an otherwise idle chip - is enqueued on a stream owned by the library and is NOT joined: it runs beside the NEXT call's backbone.
+ *   - the outputs of call i (output_kpts_dev, out_points_dev; the other outputs are written before the call's work on `stream`
+ *     ends) are complete once a stream has passed an ec_pipeline_flush(h, that_stream) issued after call i, or once `stream` has passed
+ *     the backbone of the next ec_forward / ec_forward_pipelined / ec_head call on this handle (every entry point that touches the head
+ *     first waits for a pending decoder);
+ *   - the output buffers of call i must stay valid until then, and consecutive calls must not share output buffers if the caller
+ *     reads call i's results after enqueuing call i+1; inputs may be released as for ec_forward (when `stream` has passed the call).
+ * ec_pipeline_flush enqueues, on ANY stream, a wait for the decoder of the most recent pipelined call (no host synchronisation):
+ * a copy stream can so fetch call i's results without waiting for call i+1's backbone.  Measured: cfg2 +5 % pairs/s. */
+int ec_forward_pipelined(ec_handle h, const float* img_q_dev, const float* const* img_s_dev,
+                         const float* const* target_s_dev, const float* mask_s_dev, const int32_t* edges,
+                         const int32_t* edge_offsets, int bs, int S, void* stream, const ec_outputs* out);
+int ec_pipeline_flush(ec_handle h, void* stream);
 
 /* ---- support-side episode cache --------------------------------------------------------
  * The reference pairs ONE support set with 15 queries (EdgeCape/datasets/datasets/mp100/test_dataset.py:93-97) and

@@ -141,6 +141,12 @@ def test_eval_loop_real_model_vs_oracle(tmp_path):
 
     res_hip = apis.single_gpu_test(model, loader())
     assert hip_library_loaded()
+    # the pipelined loop (submit batch i+1 before collecting batch i, ec_forward_pipelined): identical records, same order
+    res_pipe = apis.single_gpu_test(model, loader(), pipelined=True)
+    assert len(res_pipe) == len(res_hip)
+    for a, b in zip(res_pipe, res_hip):
+        assert a["bbox_ids"] == b["bbox_ids"] and a["image_paths"] == b["image_paths"]
+        assert np.array_equal(a["preds"], b["preds"]) and np.array_equal(a["boxes"], b["boxes"])
     res_ref = apis.single_gpu_test(OracleModel(), loader())
     assert len(res_hip) == len(res_ref) == 8 and all(r["preds"].shape == (1, 100, 3) and r["boxes"].shape == (1, 6) for r in res_hip)
     gt = {}
@@ -158,3 +164,61 @@ def test_eval_loop_real_model_vs_oracle(tmp_path):
         assert a["bbox_ids"] == b["bbox_ids"] and a["image_paths"] == b["image_paths"] and np.array_equal(a["boxes"], b["boxes"])
         m = gt[int(a["bbox_ids"][0])]["mask"]
         assert np.abs(a["preds"][0, m, :2] - b["preds"][0, m, :2]).max() < 0.3 if m.any() else True
+
+
+@pytest.mark.parametrize("S", [1, 5])
+def test_forward_pipelined_bit_equal(S):
+    """ec_forward_pipelined (decoder phase of call i beside the backbone of call i+1) against ec_forward on the same batches: every
+    output of every batch bit-equal, with alternating output sets, results fetched through a copy stream behind ec_pipeline_flush,
+    and with plain ec_forward / ec_head calls mixed into the sequence (every entry point waits for a pending decoder)."""
+    from edgecape_amd.engine import HipEngine
+    arch, H, bs = "dinov2_vits14", 224, 4
+    sd = synth.make_weights(arch, seed=3)
+    eng = HipEngine(sd, arch=arch, image_size=H, max_batch=bs, max_shots=S, backbone_precision="fp16", head_precision="mixed")
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    batches = []
+    for i in range(5):
+        b = synth.make_pairs(bs, S, H, seed=900 + i, fixed_n_kp=False)
+        mask = b["target_weight_s"][0].copy()
+        for tw in b["target_weight_s"]:
+            mask = mask * tw
+        e, o = eng._edges([m["sample_skeleton"][0] for m in b["img_metas"]], bs)
+        batches.append(dict(iq=dev(b["img_q"]), is_=[dev(x) for x in b["img_s"]], ts=[dev(x) for x in b["target_s"]],
+                            ms=dev(mask.reshape(bs, -1)), edges=e, off=o))
+    keys = ("output_kpts", "initial_proposals", "similarity_map", "adj", "attn_adj", "out_points")
+    ref = []
+    for b in batches:                                           # the unpipelined answers
+        o, _ = outs = eng._outputs(bs)
+        eng.forward_resident(b["iq"], b["is_"], b["ts"], b["ms"], b["edges"], b["off"], outs)
+        torch.cuda.synchronize()
+        ref.append({k: o[k].clone() for k in keys})
+    copy_stream = torch.cuda.Stream()
+    sets = [eng._outputs(bs) for _ in range(2)]
+    got, events = [], []
+    for i, b in enumerate(batches):
+        outs = sets[i & 1]
+        if i >= 2:                                              # the set is about to be reused: its previous results were copied out
+            events[i - 2].synchronize()
+        eng.forward_pipelined(b["iq"], b["is_"], b["ts"], b["ms"], b["edges"], b["off"], outs)
+        copy_stream.wait_stream(torch.cuda.current_stream())
+        eng.pipeline_flush(copy_stream)
+        with torch.cuda.stream(copy_stream):
+            got.append({k: outs[0][k].to("cpu", non_blocking=True) for k in keys})
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+            events.append(ev)
+    torch.cuda.synchronize()
+    for i in range(len(batches)):
+        for k in keys:
+            assert torch.equal(got[i][k], ref[i][k].cpu()), (i, k)
+    # mixed sequence: pipelined, plain, pipelined, flush on the compute stream
+    o0, o1, o2 = eng._outputs(bs), eng._outputs(bs), eng._outputs(bs)
+    b0, b1, b2 = batches[0], batches[1], batches[2]
+    eng.forward_pipelined(b0["iq"], b0["is_"], b0["ts"], b0["ms"], b0["edges"], b0["off"], o0)
+    eng.forward_resident(b1["iq"], b1["is_"], b1["ts"], b1["ms"], b1["edges"], b1["off"], o1)
+    eng.forward_pipelined(b2["iq"], b2["is_"], b2["ts"], b2["ms"], b2["edges"], b2["off"], o2)
+    eng.pipeline_flush()
+    torch.cuda.current_stream().synchronize()
+    for o, r in ((o0, ref[0]), (o1, ref[1]), (o2, ref[2])):
+        for k in keys:
+            assert torch.equal(o[0][k], r[k]), k
