@@ -194,6 +194,11 @@ class _FakeEngine:
         outputs[0]["output_kpts"][:] = (0.5 + 0.1 * m)[None, :, None, None]
         return outputs[0]
 
+    forward_pipelined = forward_resident          # (the stand-in has no decoder to defer)
+
+    def pipeline_flush(self, stream=None):
+        self.flushed = getattr(self, "flushed", 0) + 1
+
 
 def _worker_bench(rank, world, port, q):
     sys.path.insert(0, ROOT)
@@ -234,6 +239,7 @@ def test_world2_bench_main_runs_its_distributed_branches():
     assert res0["value"] > 0 and abs(res0["value"] - 2 * 4 * 3 / (res0["ms_per_step"] * 3e-3)) / res0["value"] < 0.01   # whole-job aggregate
     assert res0["roofline"]["launches_timed"] == 3 * 12 and res0["roofline"]["avg_launch_ms"] == 1.0
     assert "cpu_baseline" not in res0 and "episode_cached" not in res0 and "bf16_mode" not in res0   # rank-0-only legs are N = 1 only
+    assert res0["pipelined"] is True and "unpipelined" not in res0
     assert set(res0["pck_vs_synthetic_gt"]) >= {"PCK@0.2"}
 
 

@@ -31,6 +31,7 @@ def _check(line, with_cpu):
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert d["value"] > 0 and abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) / d["value"] < 0.02      # pairs per step / step time
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert isinstance(d["pipelined"], bool)
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and 0 < r["frac"] < 1
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["launches_timed"] == 3 * 12
@@ -64,3 +65,17 @@ def test_bench_under_torchrun_one_rank():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
     _check(lines[0], with_cpu=False)
+
+
+@pytest.mark.gpu
+def test_bench_unpipelined_flag_and_companion_run():
+    """--no-pipeline times ec_forward; the default line times ec_forward_pipelined and carries the ec_forward figure beside it."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline"] + [a for a in SMALL if a != "--no-alt"]
+    out = subprocess.run(base, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["pipelined"] is True and d["unpipelined"]["value"] > 0 and d["unpipelined"]["ms_per_step"] > 0 and "bf16_mode" in d
+    out = subprocess.run(base + ["--no-pipeline", "--no-alt"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["pipelined"] is False and "unpipelined" not in d
