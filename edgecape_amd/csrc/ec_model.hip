@@ -101,6 +101,7 @@ struct ec_model {
   // stream wait for ev_dq_done.  dq_active: the call being enqueued is a pipelined one; dq_pending: a decoder may still be running.
   hipStream_t dq = nullptr;
   hipEvent_t ev_dq_start = nullptr, ev_dq_done = nullptr;
+  hipEvent_t ev_feat_read = nullptr;   // the support lane's last read of the backbone features (image_project): see run_head
   bool dq_active = false, dq_pending = false;
   // EC_TIMELINE=1: timed HIP events at the head's milestones on every stream, printed (us from the head's start) after a
   // device sync at the end of the call - the unprofiled picture of which lane is critical (rocprofv3 makes the head host-bound)
@@ -842,6 +843,7 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
   }
   for (int s = 0; s < S; ++s)
     RUN(linear(fs[s], C, false, m->image_project, m->s_mem + (long)s * Mi * d, d, false, Mi, ACT_NONE, s2));
+  if (m->ev_feat_read) EC_HIP(hipEventRecord(m->ev_feat_read, s2));   // (with the pooling on st: the lane's last read of fs)
   if (nsk > 0) {
     RUN(project_image_kv(m, m->skel[0], m->s_mem, (long)HW * d, nb, m->s_kv, s2));
     if (ov2) EC_HIP(hipEventRecord(ev_kv, s2));
@@ -1254,6 +1256,10 @@ static int run_head(ec_model* m, const float* fq, const float* const* fs, const 
     RUN(join_on_error(m, run_head_support(m, fs, target_s, mask_s, bs, S, m->side, ss, m->ev_sk)));
     EC_HIP(hipEventRecord(m->ev_join, m->side));
     RUN(join_on_error(m, run_head_query(m, fq, bs, st, out, ss, m->ev_sk, m->ev_join)));   // st joins the side stream before the decoder
+    // A pipelined call leaves the support lane and the decoder running when `st` moves on to the next backbone, which ends by
+    // overwriting the feature buffer: `st` must at least have seen the lanes' reads of the features and of the caller's inputs
+    // (heatmaps / masks: pooling and adj_build, both in front of ev_sk, which the query lane waited for; features: image_project).
+    if (m->dq_active) EC_HIP(hipStreamWaitEvent(st, m->ev_feat_read, 0));
     return tl_dump(m);
   }
   RUN(join_on_error(m, run_head_support(m, fs, target_s, mask_s, bs, S, st, ss)));
@@ -1369,7 +1375,7 @@ int ec_destroy(ec_handle m) {
   if (m->ev_edges) (void)hipEventDestroy(m->ev_edges);
   for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
   if (m->dq) { (void)hipStreamSynchronize(m->dq); (void)hipStreamDestroy(m->dq); }
-  for (hipEvent_t e : {m->ev_dq_start, m->ev_dq_done}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {m->ev_dq_start, m->ev_dq_done, m->ev_feat_read}) if (e) (void)hipEventDestroy(e);
   if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
   for (hipEvent_t e : {m->ev_fork, m->ev_sk, m->ev_join}) if (e) (void)hipEventDestroy(e);
   if (m->aux) { (void)hipStreamSynchronize(m->aux); (void)hipStreamDestroy(m->aux); }
@@ -1560,9 +1566,12 @@ int ec_finalize(ec_handle m) {
     m->overlap = !(ov && atoi(ov) == 0);
     m->timeline = getenv("EC_TIMELINE") != nullptr;
     // the decoder stream of the pipelined entry point (ec_forward_pipelined)
+    // (round 3, measured: helper / decoder streams created with a non-default priority - least OR most urgent - wreck the pipelined
+    //  step: 6.4 -> 9.6 / 11.2 ms, QKV 0.38 -> 0.34 / 0.22 of peak; profiles/r03_lane_priority_probe.txt.  Default priority only.)
     EC_HIP(hipStreamCreateWithFlags(&m->dq, hipStreamNonBlocking));
     EC_HIP(hipEventCreateWithFlags(&m->ev_dq_start, hipEventDisableTiming));
     EC_HIP(hipEventCreateWithFlags(&m->ev_dq_done, hipEventDisableTiming));
+    EC_HIP(hipEventCreateWithFlags(&m->ev_feat_read, hipEventDisableTiming));
     if (m->overlap) {
       // (a high stream priority for the support lane, the longer one, measured nothing - the lanes hold one kernel in flight each)
       EC_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
