@@ -186,6 +186,7 @@ struct GemmP {
   int split = 0;    // 1 = bf16x3: A fp32, B pre-split into [32 hi | 32 lo] bf16 per 32-k block (split_pack_weights);
                     // 2 = fp16x1: A fp32 rounded to fp16 in registers, B [32 fp16 | unused] per 32-k block (split_pack_weights_h1)
   int tag = 0;      // kernel-symbol tag (profiling only): 1 qkv, 2 proj, 3 fc1, 4 fc2
+  int* sched = nullptr;   // 8-phase kernel only: device int[9], all zero between launches - DYNAMIC tile schedule (ec_gemm8.hip); nullptr: static
 };
 int gemm_nt(const GemmP& p, hipStream_t st);
 // host: W [N,K] fp32 -> bf16x3 packing of the same byte size: per row, per 32-k block, 32 hi bf16 then 32 lo bf16

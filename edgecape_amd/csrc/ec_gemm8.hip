@@ -53,7 +53,8 @@ constexpr int G8_KT = 4 * G8_HALF;        // K-tile: A-h0 | B-h0 | B-h1 | A-h1
 constexpr int G8_STAGE = 2 * G8_KT;       // 8 x 2 KiB: per-wave output staging (one 16-row x 64-column piece at a time)
 constexpr int G8_BIAS = G8_STAGE + 8 * 2048;    // 2 tile parities x 8 waves x 256 B: this wave's 64 bias values (LDS-DMA, one tile ahead)
 constexpr int G8_GAMMA = G8_BIAS + 2 * 8 * 256;  // same for the LayerScale vector
-constexpr int G8_LDS = G8_GAMMA + 2 * 8 * 256;   // 152 KiB
+constexpr int G8_SCHED = G8_GAMMA + 2 * 8 * 256;  // two ints: the dynamic schedule's hand-over slots (tile parity)
+constexpr int G8_LDS = G8_SCHED + 64;            // 152 KiB + 64 B
 constexpr int G8_AHEAD = 5;               // half-tiles the load stream runs ahead
 
 #define G8_SB() __builtin_amdgcn_sched_barrier(0)
@@ -272,7 +273,44 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   const int w0 = xcd * gq + min(xcd, gr);                                // workgroups on the XCDs before this one
   const int t_begin = (int)((long)ntiles * w0 / gridDim.x), t_end = (int)((long)ntiles * (w0 + nslot) / gridDim.x);
   const int t_first = t_begin + slot;
-  if (t_first >= t_end) return;                 // whole workgroup leaves: no barrier has been executed yet
+  // DYNAMIC schedule (round 3; p.sched != nullptr, the host passes it only for more tiles than workgroups): the first tile of a
+  // workgroup is the static one, every further tile is taken from its XCD's counter - tile t_begin + nslot + atomicAdd(sched[xcd], 1) -
+  // so the XCD's tiles are still walked in row-major order, but a workgroup that starts late (its CU was held by another stream's
+  // kernel when the launch began: ec_forward_pipelined runs the head beside the backbone) simply takes fewer of them instead of making
+  // the whole launch late by its delay.  The load stream crosses tile boundaries and the bias slice is staged a tile ahead, so the
+  // schedule is known TWO tiles ahead: t (computing), t_nxt, and t_nn, which wave 0 fetches during tile t with a SCALAR atomic
+  // (s_atomic_add: the value returns into an SGPR and is counted by lgkmcnt - the vector-memory queue with its counted waits and
+  // the 256 VGPRs of the loop are not touched), collects seven phases later where no LDS read is outstanding, and hands to the
+  // other waves through an LDS slot.
+  // The last workgroup to leave re-arms the counters (sched[8] counts leavers) for the next launch on the stream.
+  // (compiled into the bias and bias + GELU kinds only - QKV and fc1, the multi-round shapes of the backbone; the LayerScale kind of
+  //  proj / fc2, one tile per workgroup, has no register to spare for it)
+  constexpr bool DYN_OK = KIND == G8_BIAS_BF16 || KIND == G8_GELU_BF16;
+  const bool dyn = DYN_OK && p.sched != nullptr;
+  // A workgroup is counted as a leaver as soon as it knows that it will not ask again (its last answer was past the range), i.e.
+  // during its last tile's K loop, not at its end: the count's round trip is off the launch's tail.  left_s: the scalar atomic's
+  // operand (1) / return value (the number of earlier leavers).
+  int left_s = 1;
+  bool left = false;
+  auto sched_rearm = [&](int old) {             // the last leaver zeroes the counters for the next launch on the stream
+    if (old == (int)gridDim.x - 1 && tid == 0) {
+#pragma unroll
+      for (int x = 0; x < 9; ++x) __hip_atomic_store(p.sched + x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  if (t_first >= t_end) {                       // whole workgroup leaves: no barrier has been executed yet
+    if (dyn) {
+      int old = 0;
+      if (tid == 0) old = __hip_atomic_fetch_add(p.sched + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sched_rearm(__builtin_amdgcn_readfirstlane(old));
+    }
+    return;
+  }
+  int t_nxt = t_first + nslot, t_nn = t_first + 2 * nslot;
+  int* const sched_lds = (int*)(smem + G8_SCHED);
+  int fetch_s = 1;                              // wave 0: operand (1) and return value of the scalar atomic in flight
+  int pro_v = 0;                                // second tile of this workgroup: asked for now, handed over behind the prologue's drain
+  if (dyn && tid == 0) pro_v = __hip_atomic_fetch_add(p.sched + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   // ---- load stream (LDS-DMA) state -------------------------------------------------------------------------------
   // wave w stages row-group w (16 rows) of every half-tile as two pieces of 8 rows (2 wave-instructions of 1 KiB).
@@ -325,7 +363,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   auto advance = [&]() {
     if (++ls_kt == nk) {
       ls_kt = 0;
-      ls_tile += nslot;
+      ls_tile = t_nxt;
       if (ls_tile < t_end) set_rows(ls_tile);
     }
   };
@@ -349,7 +387,12 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   issue(rsA, vo0, lda8, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue half-tiles have landed (this wave's part)
   lab_steady = true;
+  if (dyn && tid == 0) sched_lds[0] = t_begin + nslot + pro_v;
   G8_BAR();
+  if (dyn) {                                         // second tile of this workgroup (fetched by thread 0 at the top)
+    t_nxt = __builtin_amdgcn_readfirstlane(sched_lds[0]);
+    t_nn = t_end;
+  }
   if (wr == 1) G8_BAR();                             // stagger: group 1 runs one barrier behind group 0
 
   // ---- fragment read addresses ------------------------------------------------------------------------------------
@@ -396,7 +439,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   };
 
   int it = 0;                                          // tile counter of this workgroup (bias parity)
-  for (int t = t_first; t < t_end; t += nslot, ++it) {
+  for (int t = t_first; t < t_end; t = t_nxt, t_nxt = t_nn, t_nn = dyn ? t_end : t_nxt + nslot, ++it) {
     const int m0 = (t / ntn) << 8, n0 = (t % ntn) << 8;
     for (int kt2 = 0; kt2 < nk; kt2 += 2) {
 #pragma unroll
@@ -419,6 +462,14 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
           if (seam) g8_wait_vm<6 + NST>(); else g8_wait_vm<6>();
         } else {
           if (!head) g8_wait_vm<6>();                    // first K-tile after a drained seam: nothing to wait for
+        }
+        if (dyn) {
+          if (head) {                                    // wave 0 asks for the tile after next
+            fetch_s = 1;
+            if (wave == 0 && t_nxt < t_end) asm volatile("s_atomic_add %0, %1, 0x0 glc" : "+s"(fetch_s) : "s"(p.sched + xcd) : "memory");
+          } else if (buf == 0 && kt2 == 2) {             // ... and everybody picks it up in the third K-tile (written in phase 3 below)
+            t_nn = __builtin_amdgcn_readfirstlane(sched_lds[(it + 1) & 1]);
+          }
         }
         G8_BAR();
         __builtin_amdgcn_s_setprio(1);
@@ -463,7 +514,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
           if (head) {                                                              // third phase of a tile
             // the NEXT tile's bias slice, a whole tile ahead (unconditional so that the counts below are uniform: past the last
             // tile the current slice is staged again into the other parity)
-            stage_bias(t + nslot < t_end ? t + nslot : t, (it + 1) & 1);
+            stage_bias(t_nxt < t_end ? t_nxt : t, (it + 1) & 1);
             if constexpr (NODRAIN) { if (seam) g8_wait_vm<6 + NST + NB>(); else g8_wait_vm<6 + NB>(); }
           } else g8_wait_vm<6>();
         } else {
@@ -487,6 +538,17 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
           if (head) g8_wait_vm<6 + NB>(); else g8_wait_vm<6>();    // (the seam's stores are older than the piece this waits for)
         } else {
           g8_wait_vm<6>();
+        }
+        if (dyn && buf == 1 && kt2 == 0 && wave == 0) {
+          // second K-tile of the tile, seven phases behind the request; this phase has no LDS reads of its own, so lgkmcnt(0) only
+          // waits for the scalar atomic (if at all)
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(fetch_s));
+          const int nn = t_nxt < t_end ? t_begin + nslot + fetch_s : t_end;
+          if (g8_lane_now() == 0) sched_lds[(it + 1) & 1] = nn;
+          if (nn >= t_end && !left) {                    // no further request from this workgroup: count it now
+            left = true;
+            asm volatile("s_atomic_add %0, %1, 0x20 glc" : "+s"(left_s) : "s"(p.sched) : "memory");
+          }
         }
         G8_BAR();
         __builtin_amdgcn_s_setprio(1);
@@ -517,6 +579,10 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   }
   if (wr == 0) G8_BAR();   // balances group 1's extra barrier at the start
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stream's tail pieces must land before the LDS is released
+  if (dyn && wave == 0) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(left_s));   // (requested at least ten K-tiles ago)
+    sched_rearm(left_s);
+  }
 }
 
 
@@ -566,7 +632,9 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
   const long ntiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   long grid = ds.ncu;
   if (ntiles < grid) grid = ntiles;
-  hipLaunchKernelGGL(table[p.h_f16 ? 1 : 0][kind][p.tag], dim3((unsigned)grid), dim3(512), G8_LDS, st, p);
+  GemmP q = p;
+  if (ntiles <= grid || grid < 8 || p.K < 256 || (kind != G8_BIAS_BF16 && kind != G8_GELU_BF16)) q.sched = nullptr;   // one tile per workgroup: nothing to deal out (K >= 256: the hand-over spans three K-tiles)
+  hipLaunchKernelGGL(table[p.h_f16 ? 1 : 0][kind][p.tag], dim3((unsigned)grid), dim3(512), G8_LDS, st, q);
   EC_LAUNCH_CHECK();
   return 1;
 }

@@ -102,15 +102,21 @@ struct ec_model {
   hipStream_t dq = nullptr;
   hipEvent_t ev_dq_start = nullptr, ev_dq_done = nullptr;
   hipEvent_t ev_feat_read = nullptr;   // the support lane's last read of the backbone features (image_project): see run_head
+  hipEvent_t ev_feat_read_p = nullptr, ev_feat_read_q = nullptr;   // ... the pooling's (support lane) and input_proj's (query lane)
+  bool pipe_full = true;               // the WHOLE head of a pipelined call runs beside the next backbone (run_head); EC_PIPE_FULL=0: only its decoder phase
   bool dq_active = false, dq_pending = false;
+  bool feat_read_pending = false;      // FULL mode: the ev_feat_read* events have to be waited for before the feature buffer is rewritten
   // EC_TIMELINE=1: timed HIP events at the head's milestones on every stream, printed (us from the head's start) after a
   // device sync at the end of the call - the unprofiled picture of which lane is critical (rocprofv3 makes the head host-bound)
   bool timeline = false;
+  bool timeline_defer = false;   // EC_TIMELINE=2: no device sync inside pipelined calls; the marks of all calls are printed by ec_pipeline_flush
   std::vector<std::pair<const char*, hipEvent_t>> tl;
   std::unordered_map<std::string, Tensor> tensors;
   std::vector<void*> owned;  // every hipMalloc'd pointer
   std::unordered_map<std::string, std::pair<const float*, long>> taps;
-  bool prof_on = false;            // ec_profile: HIP events around every backbone QKV GEMM launch
+  bool prof_on = false;            // ec_profile: HIP events around the backbone QKV GEMM launches
+  int prof_mode = 0;               // 1: every launch; 2: ONE launch per backbone pass, the block rotating with the pass (see ec_profile)
+  size_t prof_pass = 0;            // backbone passes since the profile was armed
   std::vector<hipEvent_t> prof_ev;
   size_t prof_used = 0;
 
@@ -139,6 +145,13 @@ struct ec_model {
   int32_t *h_edges = nullptr, *h_off = nullptr;   // pinned staging of the skeleton edge lists
   hipEvent_t ev_edges = nullptr;
   float *pooled, *sk, *valid, *binary, *adj_r1, *adj1, *P, *kn, *kp_ref, *attn_adj;
+  // dynamic tile schedule of the multi-round backbone GEMMs (QKV, fc1; GemmP::sched, ec_gemm8.hip): used by pipelined calls, whose
+  // backbone shares the chip with the previous call's head (+0.75 % there; alone on the chip the static walk is 1.5-2 % faster per
+  // launch).  EC_G8_DYN=0: never, =1: every call
+  int* g8_sched = nullptr;
+  int g8_dyn_mode = 2;
+  int32_t *tap_n = nullptr, *tap_i = nullptr; float* tap_w = nullptr;   // compacted pooling taps per (shot, pair, keypoint): pool_taps / pool_apply
+  hipEvent_t ev_inputs = nullptr, ev_call = nullptr;   // FULL mode: the caller's heatmaps / masks have been read; the call's inputs are ready
   uint8_t *kmask, *kmask_fixed;
   float *s_mem, *s_x, *s_tmp, *s_qkv, *s_att, *s_qc, *s_kv, *s_y, *s_z, *s_qimg, *s_kvk, *s_attimg, *s_tmpimg;
   bf16_t* s_mem16 = nullptr;   // fp16 copy of the skeleton head's image memory, written by norm4 (head mixed precision)
@@ -160,8 +173,9 @@ static int tl_mark(ec_model* m, const char* name, hipStream_t st) {
   m->tl.push_back({name, e});
   return 0;
 }
-static int tl_dump(ec_model* m) {
+static int tl_dump(ec_model* m, bool at_flush = false) {
   if (!m->timeline || m->tl.empty()) return 0;
+  if (m->timeline_defer && m->dq_active && !at_flush) return 0;   // EC_TIMELINE=2: pipelined calls accumulate, ec_pipeline_flush prints
   EC_HIP(hipDeviceSynchronize());
   fprintf(stderr, "[timeline]");
   for (size_t i = 0; i < m->tl.size(); ++i) {
@@ -403,9 +417,9 @@ static int build_dec_layer(ec_model* m, const std::string& P, bool biased, bool 
 // ---- thin launch helpers -------------------------------------------------------------------------
 static int linear(const void* A, long lda, bool a16, const Lin& W, void* C, long ldc, bool c16, int M, int act, hipStream_t st,
                   const float* gamma = nullptr, const float* resid = nullptr, long ldr = 0, const float* table = nullptr,
-                  long ldt = 0, int period = 1, const float* aux = nullptr, long ldaux = 0, int tag = 0) {
+                  long ldt = 0, int period = 1, const float* aux = nullptr, long ldaux = 0, int tag = 0, int* sched = nullptr) {
   GemmP p;
-  p.tag = tag;
+  p.tag = tag; p.sched = sched;
   p.A = A; p.lda = lda; p.ab_bf16 = a16 ? 1 : 0; p.h_f16 = (a16 && W.w16_is_f16) ? 1 : 0;
   p.split = (!a16 && W.ws) ? (W.h1 ? 2 : 1) : 0;   // head in bf16x3 mode: every head Lin carries a split-packed copy (h1: fp16x1)
   p.B = a16 ? (const void*)W.w16 : W.wsel(p.split); p.ldb = W.K;
@@ -463,11 +477,12 @@ static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_
   // The attention branch y1 is NOT written into x by norm2 (it only normalises x + y1): the next norm1 adds both pending
   // branches, x <- (x + y1) + y2, the same two fp32 additions in the same order.  22 instead of 24 bytes per element and block.
   const void *pend = nullptr, *pend2 = nullptr;   // branch outputs not yet added to x (attention branch, MLP branch)
+  int* const sched = (m->g8_dyn_mode == 1 || (m->g8_dyn_mode == 2 && m->dq_active)) ? m->g8_sched : nullptr;
   for (size_t i = 0; i < m->blocks.size(); ++i) {
     const BBlock& b = m->blocks[i];
     RUN(ln(m->bb_x, C, m->bb_xn, C, hfmt, b.n1, (int)M, C, 1e-6f, st, 0, pend, C, pend2));
     pend = pend2 = nullptr;
-    const bool prof = m->prof_on && m->prof_used + 2 <= m->prof_ev.size();
+    const bool prof = m->prof_on && (m->prof_mode != 2 || i == m->prof_pass % m->blocks.size()) && m->prof_used + 2 <= m->prof_ev.size();
     if (prof) EC_HIP(hipEventRecord(m->prof_ev[m->prof_used++], st));
     {
       GemmP p;
@@ -477,6 +492,7 @@ static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_
       p.B = h16 ? (const void*)b.qkv.w16 : b.qkv.wsel(m->bb_split); p.ldb = C;
       p.C = m->bb_qkv; p.ldc = 3 * C; p.c_bf16 = h16; p.bias = b.qkv.b;
       p.M = (int)M; p.N = 3 * C; p.K = C;
+      p.sched = sched;
       RUN(gemm_nt(p, st));
     }
     if (prof) EC_HIP(hipEventRecord(m->prof_ev[m->prof_used++], st));
@@ -491,7 +507,7 @@ static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_
     if (h16) {
       RUN(linear(m->bb_att, C, true, b.proj, m->bb_y, C, true, (int)M, ACT_NONE, st, b.ls1, nullptr, 0, nullptr, 0, 1, nullptr, 0, 2));
       RUN(ln(m->bb_x, C, m->bb_xn, C, hfmt, b.n2, (int)M, C, 1e-6f, st, 0, m->bb_y, C, nullptr, false));
-      RUN(linear(m->bb_xn, C, true, b.fc1, m->bb_h, 4 * C, true, (int)M, ACT_GELU, st, nullptr, nullptr, 0, nullptr, 0, 1, nullptr, 0, 3));
+      RUN(linear(m->bb_xn, C, true, b.fc1, m->bb_h, 4 * C, true, (int)M, ACT_GELU, st, nullptr, nullptr, 0, nullptr, 0, 1, nullptr, 0, 3, sched));
       RUN(linear(m->bb_h, 4 * C, true, b.fc2, m->bb_y2, C, true, (int)M, ACT_NONE, st, b.ls2, nullptr, 0, nullptr, 0, 1, nullptr, 0, 4));
       pend = m->bb_y; pend2 = m->bb_y2;
     } else {
@@ -500,6 +516,14 @@ static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_
       RUN(linear(m->bb_xn, C, false, b.fc1, m->bb_h, 4 * C, false, (int)M, ACT_GELU, st, nullptr, nullptr, 0, nullptr, 0, 1, nullptr, 0, 3));
       RUN(linear(m->bb_h, 4 * C, false, b.fc2, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls2, m->bb_x, C, nullptr, 0, 1, nullptr, 0, 4));
     }
+  }
+  if (m->prof_on) ++m->prof_pass;
+  // (pipelined calls, FULL mode: the previous call's head may still be reading the feature buffer - see run_head)
+  if (m->feat_read_pending && (feat_out == nullptr || feat_out == m->feat)) {
+    EC_HIP(hipStreamWaitEvent(st, m->ev_feat_read, 0));
+    EC_HIP(hipStreamWaitEvent(st, m->ev_feat_read_p, 0));
+    EC_HIP(hipStreamWaitEvent(st, m->ev_feat_read_q, 0));
+    m->feat_read_pending = false;
   }
   RUN(ln(m->bb_x, C, feat_out ? feat_out : m->feat, C, 0, m->bnorm, (int)M, C, 1e-6f, st, T, pend, C, pend2, false, hfmt));
   return 0;
@@ -816,8 +840,11 @@ struct SupportState {
 };
 
 // Support half of TwoStageHead.forward (head.py:175-200): pooling + query_proj + SkeletonPredictor.
+// part (FULL mode of a pipelined call, see run_head): 0 everything; 1 only what reads the caller's heatmaps / masks (adjacency build,
+// pooling tap lists: no backbone output needed - enqueued BEFORE the call's backbone); 2 everything else (the pooling as a gather
+// over the tap lists).
 static int run_head_support(ec_model* m, const float* const* fs, const float* const* target_s, const float* mask_s, int bs, int S,
-                            hipStream_t st, const SupportState& ss, hipEvent_t ev_sk = nullptr) {
+                            hipStream_t st, const SupportState& ss, hipEvent_t ev_sk = nullptr, int part = 0) {
   const int C = m->C, d = m->d, K = m->K, HW = m->HW, g = m->g;
   const int Fs = m->cfg.skel_ffn_dim, hops1 = m->cfg.max_hops + 1;
   const int Mk = bs * K, Mi = bs * HW;
@@ -829,17 +856,24 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
   const bool ov2 = m->overlap_dec && m->side2 != nullptr;
   hipStream_t s2 = ov2 ? m->side2 : st;
   hipEvent_t const ev_x = m->ev_sup[0], ev_xr = m->ev_sup[1], ev_kv = m->ev_sup[2], ev_f = m->ev_sup[3], ev_adjb = m->ev_sup[4];
+  const int nb = S * bs;
+  const int nsk = (int)m->skel.size();
+  if (part == 1) {
+    RUN(adj_build(m->d_edges, m->d_off, mask_s, ss.valid, ss.kmask, ss.kmask_fixed, m->binary, m->adj_r1, bs, K, st));
+    for (int s = 0; s < S; ++s)
+      RUN(pool_taps(target_s[s], mask_s, 1.f / (float)S, m->tap_n + (long)s * Mk, m->tap_i + (long)s * Mk * HW, m->tap_w + (long)s * Mk * HW,
+                    bs, K, m->cfg.heatmap_size, g, st));
+    return 0;
+  }
   if (ov2) {
     EC_HIP(hipEventRecord(ev_f, st));
     EC_HIP(hipStreamWaitEvent(s2, ev_f, 0));
-  }
-  const int nb = S * bs;
-  const int nsk = (int)m->skel.size();
-  // adjacency from the skeleton edges + key masks (skeleton.py:58-75): needs only the edges and the keypoint mask, so with the helper
-  // lane it runs there FIRST, beside the pooling chain, instead of between query_proj and the first layer on the critical lane
-  if (ov2) {
-    RUN(adj_build(m->d_edges, m->d_off, mask_s, ss.valid, ss.kmask, ss.kmask_fixed, m->binary, m->adj_r1, bs, K, s2));
-    EC_HIP(hipEventRecord(ev_adjb, s2));
+    if (part == 0) {
+      // adjacency from the skeleton edges + key masks (skeleton.py:58-75): needs only the edges and the keypoint mask, so with the helper
+      // lane it runs there FIRST, beside the pooling chain, instead of between query_proj and the first layer on the critical lane
+      RUN(adj_build(m->d_edges, m->d_off, mask_s, ss.valid, ss.kmask, ss.kmask_fixed, m->binary, m->adj_r1, bs, K, s2));
+      EC_HIP(hipEventRecord(ev_adjb, s2));
+    }
   }
   for (int s = 0; s < S; ++s)
     RUN(linear(fs[s], C, false, m->image_project, m->s_mem + (long)s * Mi * d, d, false, Mi, ACT_NONE, s2));
@@ -854,20 +888,27 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
   // (2) support keypoint pooling + query_proj (head.py:175-188)
   // (one fused kernel per shot: tap weights of the 18x18 grid from the heatmap, then the weighted sum of the non-zero cells' feature
   //  rows; the round-1 form - tap-weight matrix + dense batched GEMM - was removed in round 3)
-  for (int s = 0; s < S; ++s)
-    RUN(pool_gather(target_s[s], mask_s, 1.f / (float)S, fs[s], m->pooled, s == 0 ? 0.f : 1.f, bs, K, m->cfg.heatmap_size, g, C, st));
+  for (int s = 0; s < S; ++s) {
+    if (part == 2)
+      RUN(pool_apply(m->tap_n + (long)s * Mk, m->tap_i + (long)s * Mk * HW, m->tap_w + (long)s * Mk * HW, fs[s], m->pooled,
+                     s == 0 ? 0.f : 1.f, bs, K, m->cfg.heatmap_size, g, C, st));
+    else
+      RUN(pool_gather(target_s[s], mask_s, 1.f / (float)S, fs[s], m->pooled, s == 0 ? 0.f : 1.f, bs, K, m->cfg.heatmap_size, g, C, st));
+  }
+  if (m->ev_feat_read_p) EC_HIP(hipEventRecord(m->ev_feat_read_p, st));
   RUN(linear(m->pooled, C, false, m->query_proj, ss.sk, d, false, Mk, ACT_NONE, st));
   m->taps["support_keypoints"] = {ss.sk, (long)Mk * d};
   RUN(tl_mark(m, "S.pooled", st));
+  if (part == 2) {}   // (adjacency build: part 1, earlier on this stream)
+  else if (ov2) EC_HIP(hipStreamWaitEvent(st, ev_adjb, 0));
+  else RUN(adj_build(m->d_edges, m->d_off, mask_s, ss.valid, ss.kmask, ss.kmask_fixed, m->binary, m->adj_r1, bs, K, st));
+  if (ev_sk) EC_HIP(hipEventRecord(ev_sk, st));   // support tokens + key masks are ready: the encoder may start
 
   // (3) skeleton head (skeleton.py:58-161).  Two lanes: the token path of every layer (self-attention, token->image cross
   // attention, GCN feed-forward) stays on st; everything that only touches the image memory - image_project, each layer's K|V
   // and image-query projections, and the image->token update of the previous layer - runs on the helper stream s2, so layer
   // i+1's self-attention block overlaps layer i's image update.  Hand-offs: ev_x (x_{i+1} final -> image update may read it),
   // ev_xr (image update has read x -> LN1 of layer i+1 may overwrite it), ev_kv (K|V of layer i ready -> cross attention).
-  if (ov2) EC_HIP(hipStreamWaitEvent(st, ev_adjb, 0));
-  else RUN(adj_build(m->d_edges, m->d_off, mask_s, ss.valid, ss.kmask, ss.kmask_fixed, m->binary, m->adj_r1, bs, K, st));
-  if (ev_sk) EC_HIP(hipEventRecord(ev_sk, st));   // support tokens + key masks are ready: the encoder may start
   for (int s = 0; s < S; ++s) RUN(copy2d(m->s_x + (long)s * Mk * d, d, ss.sk, d, Mk, d, st));
   float* sx = m->s_x;                         // token state: ping-pongs with s_tmp under two-workgroup row chains (LayerIO::x_alt)
   long sx_ld = d;
@@ -970,53 +1011,12 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
   float* sim = out->similarity_map_dev;
   float* attn_adj = ss.attn_adj;
   float* pts = out->out_points_dev ? out->out_points_dev : m->d_pts;
-
-  // (1) input_proj on the query features, written straight into the encoder token buffer [bs, L, d] (rows 0..HW-1)
-  {
-    GemmP p;
-    p.A = fq; p.lda = C; p.sA = (long)HW * C;
-    p.split = m->input_proj.ws ? 1 : 0; p.B = m->input_proj.wsel(p.split); p.ldb = C; p.bias = m->input_proj.b;
-    p.C = m->e_x; p.ldc = d; p.sC = (long)L * d;
-    p.M = HW; p.N = d; p.K = C; p.batch = bs;
-    RUN(gemm_nt(p, st));
-  }
-  RUN(tl_mark(m, "Q.inproj", st));
-  if (wait_sk) EC_HIP(hipStreamWaitEvent(st, wait_sk, 0));
-  RUN(copy3d(m->e_x + (long)HW * d, d, (long)L * d, ss.sk, d, (long)K * d, bs, K, d, st));
-
-  // (4) encoder (encoder_decoder.py:276-310, 461-483) over [bs, L = HW + K, d]
   const int Me = bs * L;
-  for (size_t i = 0; i < m->enc.size(); ++i) {
-    const EncLayer& e = m->enc[i];
-    RUN(add_table(m->e_x, d, m->pos_cat, d, L, Me, d, st));   // src = src + pos, every layer, feeds q,k,v
-    RUN(linear(m->e_x, d, false, e.in, m->e_qkv, 3 * d, false, Me, ACT_NONE, st));
-    AttnP a;
-    a.Q = m->e_qkv; a.K = m->e_qkv + d; a.V = m->e_qkv + 2 * d; a.O = m->e_att;
-    a.ldq = a.ldk = a.ldv = 3 * d; a.ldo = d;
-    a.sQ = a.sK = a.sV = (long)L * 3 * d; a.sO = (long)L * d;
-    a.kmask = ss.kmask; a.mask_start = HW; a.mask_len = K; a.mask_mod = 0;
-    a.B = bs; a.H = nh; a.Lq = L; a.Lk = L; a.hd = d / nh;
-    a.split = m->head_split ? 1 : 0;   // head throughput mode: bf16x3 MFMAs
-    RUN(attention(a, st));
-    // The row-wise rest of the layer (encoder_decoder.py:470-483) as separate launches.  (Round 2 ran it as ONE row chain behind a
-    // switch: the encoder alone got 25-30 % faster, but its 424 CU-filling workgroups of ~80 us starved the support lane beside it,
-    // which is the critical one - the step was 0.5-1 % slower; removed in round 3)
-    {
-      RUN(linear(m->e_att, d, false, e.out, m->e_tmp, d, false, Me, ACT_NONE, st, nullptr, m->e_x, d));
-      RUN(ln(m->e_tmp, d, m->e_x, d, false, e.n1, Me, d, 1e-5f, st));
-      RUN(linear(m->e_x, d, false, e.l1, m->e_h, Fd, false, Me, ACT_RELU, st));
-      RUN(linear(m->e_h, Fd, false, e.l2, m->e_tmp, d, false, Me, ACT_NONE, st, nullptr, m->e_x, d));
-      RUN(ln(m->e_tmp, d, m->e_x, d, false, e.n2, Me, d, 1e-5f, st));
-    }
-    RUN(tl_mark(m, i == 0 ? "Q.enc0" : i == 1 ? "Q.enc1" : "Q.enc2", st));
-  }
-  m->taps["enc"] = {m->e_x, (long)Me * d};
   float* mem = m->e_x;                       // image tokens of sample b: rows b*L .. b*L+HW-1
   float* kp = m->e_x + (long)HW * d;         // keypoint tokens: rows b*L+HW ..
   const long s_tok = (long)L * d;
-
   // ---- helper stream (see the stream plan at (6)); the decoder's image K|V projection only needs the encoder output, so it
-  // starts here, beside the proposal generator
+  // starts beside the proposal generator
   const bool ovd = m->overlap_dec;
   hipStream_t ax = ovd ? m->aux : st;
   auto fork = [&](hipEvent_t e) -> int {   // ax continues after everything enqueued on st so far
@@ -1032,9 +1032,10 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
   hipEvent_t const ev_fork = m->ev_aux[0], ev_x = m->ev_aux[1], ev_qpe = m->ev_aux[2], ev_kv = m->ev_aux[3], ev_done = m->ev_aux[4];
   hipEvent_t const ev_sa = m->ev_aux[5];
   const int nL = (int)m->dec.size();
-  RUN(fork(ev_fork));
-  {  // the decoder never updates the image memory (two_way_attn=False, encoder_decoder.py:638): project K|V of the image
-     // tokens for ALL decoder layers in one GEMM (stacked weights [nL*2E, d], stacked positional tables [HW, nL*2E])
+  const bool deferred = m->dq_active && m->dq != nullptr;
+  auto image_kv_all = [&]() -> int {
+    // the decoder never updates the image memory (two_way_attn=False, encoder_decoder.py:638): project K|V of the image
+    // tokens for ALL decoder layers in one GEMM (stacked weights [nL*2E, d], stacked positional tables [HW, nL*2E])
     GemmP p;
     p.A = mem; p.lda = d; p.sA = s_tok;
     p.split = m->dec_kv_all.ws ? (m->dec_kv_all.h1 ? 2 : 1) : 0; p.B = m->dec_kv_all.wsel(p.split); p.ldb = d;
@@ -1042,9 +1043,94 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     p.table = m->dec_kv_table; p.ldt = (long)nL * 2 * E; p.period = HW;
     p.M = HW; p.N = nL * 2 * E; p.K = d; p.batch = bs;
     RUN(gemm_nt(p, ax));
+    RUN(mark(ev_kv));
+    return tl_mark(m, "A.kv", ax);
+  };
+  auto ref_point_embed = [&](const float* bi) -> int {   // qpe = ref_point_head(sine(b))  (encoder_decoder.py:363-371)
+    RUN(sincos_coords(bi, m->dim_t, m->d_sc, d, Mk, d / 2, ax));
+    RUN(linear(m->d_sc, d, false, m->rp0, m->d_rp, d, false, Mk, ACT_GELU, ax));
+    RUN(linear(m->d_rp, d, false, m->rp1, m->d_qin + d, 2 * d, false, Mk, ACT_NONE, ax));
+    return 0;
+  };
+
+  // (1) input_proj on the query features, written straight into the encoder token buffer [bs, L, d] (rows 0..HW-1)
+  {
+    GemmP p;
+    p.A = fq; p.lda = C; p.sA = (long)HW * C;
+    p.split = m->input_proj.ws ? 1 : 0; p.B = m->input_proj.wsel(p.split); p.ldb = C; p.bias = m->input_proj.b;
+    p.C = m->e_x; p.ldc = d; p.sC = (long)L * d;
+    p.M = HW; p.N = d; p.K = C; p.batch = bs;
+    RUN(gemm_nt(p, st));
   }
-  RUN(mark(ev_kv));
-  RUN(tl_mark(m, "A.kv", ax));
+  if (m->dq_active && m->ev_feat_read_q) EC_HIP(hipEventRecord(m->ev_feat_read_q, st));
+  RUN(tl_mark(m, "Q.inproj", st));
+  if (wait_sk) EC_HIP(hipStreamWaitEvent(st, wait_sk, 0));
+  RUN(copy3d(m->e_x + (long)HW * d, d, (long)L * d, ss.sk, d, (long)K * d, bs, K, d, st));
+
+  // (4) encoder (encoder_decoder.py:276-310, 461-483) over [bs, L = HW + K, d]
+  bool enc_qkv_ready = false;   // the previous layer's row chain already produced src + pos and this layer's in-proj
+  for (size_t i = 0; i < m->enc.size(); ++i) {
+    const EncLayer& e = m->enc[i];
+    if (!enc_qkv_ready) {
+      RUN(add_table(m->e_x, d, m->pos_cat, d, L, Me, d, st));   // src = src + pos, every layer, feeds q,k,v
+      RUN(linear(m->e_x, d, false, e.in, m->e_qkv, 3 * d, false, Me, ACT_NONE, st));
+    }
+    enc_qkv_ready = false;
+    AttnP a;
+    a.Q = m->e_qkv; a.K = m->e_qkv + d; a.V = m->e_qkv + 2 * d; a.O = m->e_att;
+    a.ldq = a.ldk = a.ldv = 3 * d; a.ldo = d;
+    a.sQ = a.sK = a.sV = (long)L * 3 * d; a.sO = (long)L * d;
+    a.kmask = ss.kmask; a.mask_start = HW; a.mask_len = K; a.mask_mod = 0;
+    a.B = bs; a.H = nh; a.Lq = L; a.Lk = L; a.hd = d / nh;
+    a.split = m->head_split ? 1 : 0;   // head throughput mode: bf16x3 MFMAs
+    RUN(attention(a, st));
+    // The row-wise rest of the layer (encoder_decoder.py:470-483) as ONE row chain: x1 = norm1(x + out_proj(att)); y = relu(linear1(x1));
+    // x = norm2(x1 + linear2(y)) (+ pos -> the next layer's in-proj).  x1 stays in registers (keep) and LDS, y [32, F] in LDS; att is
+    // staged into y's buffer (dead by then).  7 launches per layer become 2 and the encoder alone gets 25-30 % faster.  Round 2 measured
+    // it 0.5-1 % SLOWER for the step, because its 424 CU-filling workgroups starved the support lane beside it, then the critical one;
+    // under ec_forward_pipelined (round 3) the query lane is what the caller's stream waits for - the support lane and the decoder run
+    // beside the next backbone - so the encoder's time counts and the support lane's does not.  EC_ENC_CHAIN=0: separate launches.
+    static const bool enc_chain_on = !(getenv("EC_ENC_CHAIN") && atoi(getenv("EC_ENC_CHAIN")) == 0);
+    const bool enc_chain = enc_chain_on && m->head_chain && chain_ok(e.out) && chain_ok(e.l1) && chain_ok(e.l2) && e.out.K == d &&
+                           e.l1.K == d && e.l2.N == d && CH_LDS0 + chain_layout_bytes(Fd) + chain_layout_bytes(d) <= 160 * 1024;
+    if (enc_chain) {
+      ChainBuild cb;
+      const int by = cb.buf(Fd), bx = cb.buf(d);
+      ChainStage& A = cb.add();
+      chain_lin(A, e.out);
+      A.g_in = m->e_att; A.ld_in = d; A.g_k = d; A.g_off = by; A.a_off = by;
+      A.resid = m->e_x; A.ldr = d; A.ln_w = e.n1.w; A.ln_b = e.n1.b; A.eps = 1e-5f;
+      A.s_off = bx; A.keep = 1;
+      ChainStage& B = cb.add();
+      chain_lin(B, e.l1);
+      B.a_off = bx; B.act = ACT_RELU; B.s_off = by;
+      ChainStage& Cc = cb.add();
+      chain_lin(Cc, e.l2);
+      Cc.a_off = by; Cc.resid_keep = 1; Cc.ln_w = e.n2.w; Cc.ln_b = e.n2.b; Cc.eps = 1e-5f;
+      Cc.out = m->e_x; Cc.ldo = d;
+      if (i + 1 < m->enc.size() && chain_ok(m->enc[i + 1].in) && m->enc[i + 1].in.K == d) {
+        // ... and the head of the next layer: src = x + pos (stored, and the operand of) its self-attention in-proj
+        Cc.post_table = m->pos_cat; Cc.ldpt = d; Cc.post_period = L;
+        Cc.s_off = bx;
+        ChainStage& D = cb.add();
+        chain_lin(D, m->enc[i + 1].in);
+        D.a_off = bx;
+        D.out = m->e_qkv; D.ldo = 3 * d;
+        enc_qkv_ready = true;
+      }
+      RUN(cb.run(Me, st));
+    } else {
+      RUN(linear(m->e_att, d, false, e.out, m->e_tmp, d, false, Me, ACT_NONE, st, nullptr, m->e_x, d));
+      RUN(ln(m->e_tmp, d, m->e_x, d, false, e.n1, Me, d, 1e-5f, st));
+      RUN(linear(m->e_x, d, false, e.l1, m->e_h, Fd, false, Me, ACT_RELU, st));
+      RUN(linear(m->e_h, Fd, false, e.l2, m->e_tmp, d, false, Me, ACT_NONE, st, nullptr, m->e_x, d));
+      RUN(ln(m->e_tmp, d, m->e_x, d, false, e.n2, Me, d, 1e-5f, st));
+    }
+    RUN(tl_mark(m, i == 0 ? "Q.enc0" : i == 1 ? "Q.enc1" : "Q.enc2", st));
+  }
+  m->taps["enc"] = {m->e_x, (long)Me * d};
+  RUN(fork(ev_fork));
+  RUN(image_kv_all());
 
   // (5) proposal generator (encoder_decoder.py:49-112)
   {
@@ -1078,20 +1164,14 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
   //        kpt_branch[l](hs[l]) -> output_kpts[l]   (head.py:216-220)
   // while st runs layer l+1's self-attention block; st waits for "x_{l+1} no longer read" before LN1 overwrites x and for
   // qpe_{l+1} before the cross-attention query projection.
-  auto ref_point_embed = [&](const float* bi) -> int {   // qpe = ref_point_head(sine(b))  (encoder_decoder.py:363-371)
-    RUN(sincos_coords(bi, m->dim_t, m->d_sc, d, Mk, d / 2, ax));
-    RUN(linear(m->d_sc, d, false, m->rp0, m->d_rp, d, false, Mk, ACT_GELU, ax));
-    RUN(linear(m->d_rp, d, false, m->rp1, m->d_qin + d, 2 * d, false, Mk, ACT_NONE, ax));
-    return 0;
-  };
   RUN(fork(ev_fork));                      // proposals (pts[0]) and the encoder output are final
   RUN(ref_point_embed(pts));
   RUN(mark(ev_qpe));
-  const bool deferred = m->dq_active && m->dq != nullptr;
-  if (deferred) {   // pipelined call: the decoder phase on its own stream (see ec_model::dq)
+  if (deferred) {   // pipelined call: the decoder phase on its own stream (see ec_model::dq; FULL mode: st is that stream already)
     EC_HIP(hipEventRecord(m->ev_dq_start, st));
     EC_HIP(hipStreamWaitEvent(m->dq, m->ev_dq_start, 0));
     st = m->dq;
+    if (!ovd) ax = st;   // (no helper stream: the helper-lane work follows the decoder onto its stream)
   }
   RUN(copy3d(m->d_qin, 2 * d, (long)K * 2 * d, kp, d, s_tok, bs, K, d, st));
   // adjacency / Markov stack from the support side: first needed by layer 0's self-attention kernel (bias, key mask) - its input
@@ -1253,6 +1333,21 @@ static int run_head(ec_model* m, const float* fq, const float* const* fs, const 
   if (m->overlap) {
     EC_HIP(hipEventRecord(m->ev_fork, st));
     EC_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+    if (m->dq_active && m->dq && m->pipe_full) {   // (m->overlap holds: forward_impl's `full`)
+      // Pipelined call, FULL mode (round 3): the whole head of call i - both lanes of phase 1 and the decoder - leaves the caller's
+      // stream, which goes straight on to the next backbone.  The query lane runs on the decoder stream from its first kernel; a head
+      // waits for the previous call's head (it owns the head workspace) on ITS streams, not on the caller's.  What the caller's stream
+      // still waits for: the lanes' reads of the caller's inputs (heatmaps / masks: pooling and adj_build, in front of ev_sk), and -
+      // in front of the next backbone's last LayerNorm, run_backbone - their reads of the feature buffer.
+      EC_HIP(hipStreamWaitEvent(m->dq, m->ev_fork, 0));
+      if (m->dq_pending) EC_HIP(hipStreamWaitEvent(m->dq, m->ev_dq_done, 0));   // (the support lane waited for it in run_head_pre)
+      RUN(join_on_error(m, run_head_support(m, fs, target_s, mask_s, bs, S, m->side, ss, m->ev_sk, 2)));
+      EC_HIP(hipEventRecord(m->ev_join, m->side));
+      RUN(join_on_error(m, run_head_query(m, fq, bs, m->dq, out, ss, m->ev_sk, m->ev_join)));
+      EC_HIP(hipStreamWaitEvent(st, m->ev_inputs, 0));   // recorded beside the backbone, long ago: the caller may reuse its inputs
+      m->feat_read_pending = true;
+      return tl_dump(m);
+    }
     RUN(join_on_error(m, run_head_support(m, fs, target_s, mask_s, bs, S, m->side, ss, m->ev_sk)));
     EC_HIP(hipEventRecord(m->ev_join, m->side));
     RUN(join_on_error(m, run_head_query(m, fq, bs, st, out, ss, m->ev_sk, m->ev_join)));   // st joins the side stream before the decoder
@@ -1267,12 +1362,25 @@ static int run_head(ec_model* m, const float* fq, const float* const* fs, const 
   return tl_dump(m);
 }
 
+// FULL mode of a pipelined call, before its backbone is enqueued: what reads the caller's heatmaps / masks runs on the support lane's
+// stream beside the backbone - behind the previous call's head, which owns the head workspace until its decoder is done.
+static int run_head_pre(ec_model* m, const float* const* target_s, const float* mask_s, int bs, int S, hipStream_t st, const ec_outputs* out) {
+  const SupportState ss = workspace_support(m, out);
+  EC_HIP(hipEventRecord(m->ev_call, st));              // the caller's inputs (and the edge upload) are ready in `st`'s order
+  EC_HIP(hipStreamWaitEvent(m->side, m->ev_call, 0));
+  if (m->dq_pending) EC_HIP(hipStreamWaitEvent(m->side, m->ev_dq_done, 0));
+  RUN(join_on_error(m, run_head_support(m, nullptr, target_s, mask_s, bs, S, m->side, ss, nullptr, 1)));
+  EC_HIP(hipEventRecord(m->ev_inputs, m->side));
+  return 0;
+}
+
 // A pipelined call's decoder may still own the head workspace (and write its caller's outputs): every entry point that touches the
 // head makes its stream wait for it first.  Cheap when nothing is pending.
 static int wait_pending_decoder(ec_model* m, hipStream_t st) {
   if (m->dq && m->dq_pending) {
     EC_HIP(hipStreamWaitEvent(st, m->ev_dq_done, 0));
     m->dq_pending = false;
+    m->feat_read_pending = false;   // (the decoder waited for the whole support lane)
   }
   return 0;
 }
@@ -1375,7 +1483,7 @@ int ec_destroy(ec_handle m) {
   if (m->ev_edges) (void)hipEventDestroy(m->ev_edges);
   for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
   if (m->dq) { (void)hipStreamSynchronize(m->dq); (void)hipStreamDestroy(m->dq); }
-  for (hipEvent_t e : {m->ev_dq_start, m->ev_dq_done, m->ev_feat_read}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {m->ev_dq_start, m->ev_dq_done, m->ev_feat_read, m->ev_feat_read_p, m->ev_feat_read_q, m->ev_inputs, m->ev_call}) if (e) (void)hipEventDestroy(e);
   if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
   for (hipEvent_t e : {m->ev_fork, m->ev_sk, m->ev_join}) if (e) (void)hipEventDestroy(e);
   if (m->aux) { (void)hipStreamSynchronize(m->aux); (void)hipStreamDestroy(m->aux); }
@@ -1542,10 +1650,16 @@ int ec_finalize(ec_handle m) {
   if ((rc = dalloc(m, &m->feat, (size_t)n * HW * C))) return rc;
   if ((rc = dalloc(m, &m->feat_nchw_tmp, (size_t)n * HW * C))) return rc;
   if ((rc = dalloc(m, &m->d_off, (size_t)bs + 1))) return rc;
+  if (getenv("EC_G8_DYN")) m->g8_dyn_mode = atoi(getenv("EC_G8_DYN"));
+  if (m->g8_dyn_mode != 0) {
+    if ((rc = dalloc(m, &m->g8_sched, 16))) return rc;
+    EC_HIP(hipMemset(m->g8_sched, 0, 16 * sizeof(int)));
+  }
   EC_HIP(hipHostMalloc((void**)&m->h_off, ((size_t)bs + 1) * sizeof(int32_t), hipHostMallocDefault));
   const size_t Mk = (size_t)bs * K, Mi = (size_t)bs * HW, KK = (size_t)K * K;
   const int Fs = m->cfg.skel_ffn_dim, Fd = m->cfg.ffn_dim;
 #define WS(ptr, count) if ((rc = dalloc(m, &m->ptr, (size_t)(count)))) return rc
+  WS(tap_n, (size_t)S * Mk); WS(tap_i, (size_t)S * Mk * HW); WS(tap_w, (size_t)S * Mk * HW);
   WS(pooled, Mk * C); WS(sk, Mk * d); WS(valid, Mk); WS(kmask, Mk); WS(kmask_fixed, Mk);
   WS(binary, bs * KK); WS(adj_r1, bs * KK); WS(adj1, bs * KK); WS(P, bs * KK); WS(kn, Mk * d); WS(kp_ref, Mk * d);
   WS(attn_adj, 5 * bs * KK);
@@ -1565,6 +1679,8 @@ int ec_finalize(ec_handle m) {
     const char* ov = getenv("EC_OVERLAP");
     m->overlap = !(ov && atoi(ov) == 0);
     m->timeline = getenv("EC_TIMELINE") != nullptr;
+    m->timeline_defer = m->timeline && atoi(getenv("EC_TIMELINE")) == 2;
+    m->pipe_full = !(getenv("EC_PIPE_FULL") && atoi(getenv("EC_PIPE_FULL")) == 0);
     // the decoder stream of the pipelined entry point (ec_forward_pipelined)
     // (round 3, measured: helper / decoder streams created with a non-default priority - least OR most urgent - wreck the pipelined
     //  step: 6.4 -> 9.6 / 11.2 ms, QKV 0.38 -> 0.34 / 0.22 of peak; profiles/r03_lane_priority_probe.txt.  Default priority only.)
@@ -1572,6 +1688,10 @@ int ec_finalize(ec_handle m) {
     EC_HIP(hipEventCreateWithFlags(&m->ev_dq_start, hipEventDisableTiming));
     EC_HIP(hipEventCreateWithFlags(&m->ev_dq_done, hipEventDisableTiming));
     EC_HIP(hipEventCreateWithFlags(&m->ev_feat_read, hipEventDisableTiming));
+    EC_HIP(hipEventCreateWithFlags(&m->ev_feat_read_p, hipEventDisableTiming));
+    EC_HIP(hipEventCreateWithFlags(&m->ev_feat_read_q, hipEventDisableTiming));
+    EC_HIP(hipEventCreateWithFlags(&m->ev_inputs, hipEventDisableTiming));
+    EC_HIP(hipEventCreateWithFlags(&m->ev_call, hipEventDisableTiming));
     if (m->overlap) {
       // (a high stream priority for the support lane, the longer one, measured nothing - the lanes hold one kernel in flight each)
       EC_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
@@ -1639,7 +1759,10 @@ static int forward_impl(ec_handle m, const float* img_q, const float* const* img
   hipStream_t st = (hipStream_t)stream;
   struct Scope { ec_model* m; ~Scope() { m->dq_active = false; } } scope{m};
   m->dq_active = pipelined;
-  RUN(upload_edges(m, edges, off, bs, st));
+  const bool full = pipelined && m->pipe_full && m->overlap && m->dq;
+  // (FULL mode: the edge lists are only read by the adjacency build on the support lane's stream; uploading them there keeps the
+  //  copy engine's hand-overs - ~50 us between two kernels - out of the caller's stream)
+  RUN(upload_edges(m, edges, off, bs, full ? m->side : st));
   const size_t per = (size_t)bs * m->HW * m->C;
   // EdgeCape.extract_features (EdgeCape.py:186-191): the same backbone on the query and on every support image
   std::vector<const float*> srcs(1 + S), fsp(S);
@@ -1648,9 +1771,13 @@ static int forward_impl(ec_handle m, const float* img_q, const float* const* img
     srcs[1 + s] = img_s[s];
     fsp[s] = m->feat + (1 + s) * per;
   }
+  if (full) RUN(run_head_pre(m, target_s, mask_s, bs, S, st, out));
+  if (m->timeline_defer) RUN(tl_mark(m, "BB", st));
   RUN(run_backbone(m, srcs.data(), 1 + S, bs, m->feat, st));   // (beside the previous pipelined call's decoder, if one is pending)
   m->taps["feature_q"] = {m->feat, (long)per};
-  RUN(wait_pending_decoder(m, st));                            // ... which owns the head workspace until it is done
+  if (m->timeline_defer) RUN(tl_mark(m, "BBend", st));
+  // ... which owns the head workspace until it is done (FULL mode: the next head waits for it on its own streams, run_head)
+  if (!full) RUN(wait_pending_decoder(m, st));
   return run_head(m, m->feat, fsp.data(), target_s, mask_s, bs, S, st, out);
 }
 
@@ -1668,6 +1795,7 @@ int ec_forward_pipelined(ec_handle m, const float* img_q, const float* const* im
 int ec_pipeline_flush(ec_handle m, void* stream) {
   EC_REQUIRE(m && m->finalized, EC_ERR_STATE, "model not finalized");
   if (m->dq && m->dq_pending) EC_HIP(hipStreamWaitEvent((hipStream_t)stream, m->ev_dq_done, 0));   // (dq_pending stays: see header)
+  if (m->timeline_defer) return tl_dump(m, true);
   return EC_OK;
 }
 
@@ -1814,6 +1942,8 @@ int ec_msra_targets(const float* joints_dev, const float* visible_dev, int n, in
 int ec_profile(ec_handle m, int enable, int max_launches) {
   EC_REQUIRE(m, EC_ERR_ARG, "null handle");
   m->prof_on = enable != 0;
+  m->prof_mode = enable;
+  m->prof_pass = 0;
   m->prof_used = 0;
   while (enable && m->prof_ev.size() < (size_t)2 * max_launches) {
     hipEvent_t e;

@@ -69,6 +69,10 @@ int msra_targets(const float* joints, const float* visible, float* target, float
 // head.py:175-184 — bilinear(g->hm) + normalised-heatmap pooling expressed as weights over the g*g cells
 int pool_gather(const float* target, const float* mask_s, float inv_shots, const float* F, float* pooled, float beta, int bs, int K,
                 int hm, int g, int C, hipStream_t st);
+int pool_taps(const float* target, const float* mask_s, float inv_shots, int* tap_n, int* tap_i, float* tap_w, int bs, int K, int hm, int g,
+              hipStream_t st);
+int pool_apply(const int* tap_n, const int* tap_i, const float* tap_w, const float* F, float* pooled, float beta, int bs, int K, int hm, int g,
+               int C, hipStream_t st);
 // skeleton.py:171-205 — edges -> binary adjacency, validity vectors, soft-normalised adjacency
 int adj_build(const int32_t* edges, const int32_t* offsets, const float* mask_s, float* valid, uint8_t* kmask,
               uint8_t* kmask_fixed, float* binary, float* adj_r1, int bs, int K, hipStream_t st);

@@ -202,8 +202,15 @@ __device__ inline void bilinear_src(int dst, float scale, int in_size, int& i0, 
 // 64x64 heatmap = ~4x4 of the 18x18 token grid), so ~16-30 of the 324 cells are non-zero and the dense [K,HW]@[HW,C]
 // contraction (and its launch) disappears; a dense heatmap is still exact, just slower (every cell is visited).
 // Both resize passes run over (cell-row, column) pairs with per-coordinate tap tables, summing in ascending source order.
+// MODE 0: the fused kernel.  MODE 1 / 2 (round 3, ec_forward_pipelined): the same kernel cut in two at the compacted tap list - MODE 1
+// reads the caller's heatmap and mask and writes the list (tap_n[bk] = number of non-zero cells, -1 for a padded slot; tap_i / tap_w
+// [bk][g*g]: cell index and weight, in the fused kernel's order), MODE 2 gathers the feature rows with it.  Identical arithmetic in
+// identical order: the two halves together are bit-equal to the fused kernel.  The first half needs no backbone output, so a pipelined
+// call runs it BESIDE its backbone and the caller's inputs are consumed long before the caller's stream reaches the end of the call.
+template <int MODE>
 __global__ __launch_bounds__(256) void pool_gather_kernel(const float* target, const float* mask_s, float inv_shots, const float* F,
-                                                          float* pooled, float beta, int K, int hm, int g, int C) {
+                                                          float* pooled, float beta, int K, int hm, int g, int C, int* tap_n, int* tap_i,
+                                                          float* tap_w) {
   extern __shared__ float sm[];
   float* t = sm;                       // hm*hm heatmap
   float* tmp = t + hm * hm;            // g*hm : tmp[cy][x]
@@ -215,11 +222,30 @@ __global__ __launch_bounds__(256) void pool_gather_kernel(const float* target, c
   float* red = (float*)(nzi + g * g);  // 4 + 1 (count)
   const int bk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = bk / K;
-  const float msk = mask_s[bk];
   float* out = pooled + (long)bk * C;
+  if constexpr (MODE == 2) {
+    const int n = tap_n[bk];
+    if (n < 0) {
+      if (beta == 0.f)
+        for (int c = tid; c < C; c += 256) out[c] = 0.f;
+      return;
+    }
+    for (int i = tid; i < n; i += 256) {
+      const int cell = tap_i[(long)bk * g * g + i];
+      nzi[i] = cell;
+      wts[cell] = tap_w[(long)bk * g * g + i];
+    }
+    if (tid == 0) ((int*)red)[4] = n;
+    __syncthreads();
+  } else {
+  const float msk = mask_s[bk];
   if (msk == 0.f) {   // padded keypoint slot: pooled feature is multiplied by mask_s = 0 (head.py:187)
-    if (beta == 0.f)
-      for (int c = tid; c < C; c += 256) out[c] = 0.f;
+    if constexpr (MODE == 1) {
+      if (tid == 0) tap_n[bk] = -1;
+    } else {
+      if (beta == 0.f)
+        for (int c = tid; c < C; c += 256) out[c] = 0.f;
+    }
     return;
   }
   const float* src = target + (long)bk * hm * hm;
@@ -280,6 +306,16 @@ __global__ __launch_bounds__(256) void pool_gather_kernel(const float* target, c
     if (lane == 0) ((int*)red)[4] = n;
   }
   __syncthreads();
+  if constexpr (MODE == 1) {
+    const int n = ((const int*)red)[4];
+    for (int i = tid; i < n; i += 256) {
+      tap_i[(long)bk * g * g + i] = nzi[i];
+      tap_w[(long)bk * g * g + i] = wts[nzi[i]];
+    }
+    if (tid == 0) tap_n[bk] = n;
+    return;
+  }
+  }   // MODE != 2
   const int nnz = ((const int*)red)[4];
   const float* Fb = F + (long)b * g * g * C;
   for (int c = tid; c < C; c += 256) {
@@ -833,7 +869,28 @@ int pool_gather(const float* target, const float* mask_s, float inv_shots, const
                 int hm, int g, int C, hipStream_t st) {
   const size_t lds = (size_t)(hm * hm + g * hm + g * g + hm) * sizeof(float) + (size_t)(2 * hm + g * g) * sizeof(int) + 8 * sizeof(float);
   EC_REQUIRE(lds <= 64 * 1024, -1, "pool_gather: heatmap too large for LDS");
-  hipLaunchKernelGGL(pool_gather_kernel, dim3(bs * K), dim3(256), lds, st, target, mask_s, inv_shots, F, pooled, beta, K, hm, g, C);
+  hipLaunchKernelGGL(pool_gather_kernel<0>, dim3(bs * K), dim3(256), lds, st, target, mask_s, inv_shots, F, pooled, beta, K, hm, g, C,
+                     (int*)nullptr, (int*)nullptr, (float*)nullptr);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+// The two halves of pool_gather (see pool_gather_kernel): tap lists from the heatmaps, then the gather.  tap_n [bs*K], tap_i / tap_w [bs*K, g*g].
+int pool_taps(const float* target, const float* mask_s, float inv_shots, int* tap_n, int* tap_i, float* tap_w, int bs, int K, int hm, int g,
+              hipStream_t st) {
+  const size_t lds = (size_t)(hm * hm + g * hm + g * g + hm) * sizeof(float) + (size_t)(2 * hm + g * g) * sizeof(int) + 8 * sizeof(float);
+  EC_REQUIRE(lds <= 64 * 1024, -1, "pool_taps: heatmap too large for LDS");
+  hipLaunchKernelGGL(pool_gather_kernel<1>, dim3(bs * K), dim3(256), lds, st, target, mask_s, inv_shots, (const float*)nullptr,
+                     (float*)nullptr, 0.f, K, hm, g, 0, tap_n, tap_i, tap_w);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int pool_apply(const int* tap_n, const int* tap_i, const float* tap_w, const float* F, float* pooled, float beta, int bs, int K, int hm, int g,
+               int C, hipStream_t st) {
+  const size_t lds = (size_t)(hm * hm + g * hm + g * g + hm) * sizeof(float) + (size_t)(2 * hm + g * g) * sizeof(int) + 8 * sizeof(float);
+  hipLaunchKernelGGL(pool_gather_kernel<2>, dim3(bs * K), dim3(256), lds, st, (const float*)nullptr, (const float*)nullptr, 0.f, F, pooled, beta,
+                     K, hm, g, C, const_cast<int*>(tap_n), const_cast<int*>(tap_i), const_cast<float*>(tap_w));
   EC_LAUNCH_CHECK();
   return 0;
 }

@@ -144,7 +144,7 @@ class EdgeCape:
                **kwargs):
         """First half of forward_test for a back-to-back loop (apis.single_gpu_test(pipelined=True)): enqueue the device work of one
         batch through ec_forward_pipelined and the device -> host copies of its results on a copy stream that waits for THIS
-        batch's decoder only; returns a ticket for collect().  The batch's decoder then overlaps the next submit()'s backbone."""
+        batch's head only; returns a ticket for collect().  The batch's head then overlaps the next submit()'s backbone."""
         height, width = img_q.shape[-2:]
         if height != width:
             raise ValueError("square inputs only")
@@ -163,8 +163,8 @@ class EdgeCape:
         if getattr(self, "_copy_stream", None) is None:
             self._copy_stream = torch.cuda.Stream()
         cs = self._copy_stream
-        cs.wait_stream(torch.cuda.current_stream())      # phase 1 of this call (proposals, adjacency) ...
-        eng.pipeline_flush(cs)                           # ... and its decoder, not the next call's backbone
+        cs.wait_stream(torch.cuda.current_stream())      # this call's backbone ...
+        eng.pipeline_flush(cs)                           # ... and its head, not the next call's backbone
         with torch.cuda.stream(cs):
             host = [t.to("cpu", non_blocking=True) for t in (o["output_kpts"], o["initial_proposals"], o["adj"][0])]
             done = torch.cuda.Event()

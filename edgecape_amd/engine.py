@@ -210,10 +210,10 @@ class HipEngine:
         return o
 
     def forward_pipelined(self, iq, is_, ts, ms, edges, off, outputs):
-        """ec_forward_pipelined on resident tensors: as forward_resident, but the decoder phase of this call stays in flight on the
-        library's decoder stream and overlaps the next call's backbone.  `outputs` (a pair from _outputs()) must not be shared with the
-        next call if its results are read after that call was enqueued; they are complete after pipeline_flush() on the reading
-        stream (or once the current stream has passed the next call's backbone)."""
+        """ec_forward_pipelined on resident tensors: as forward_resident, but the head of this call stays in flight on the library's own
+        streams and overlaps the next call's backbone.  `outputs` (a pair from _outputs()) must not be shared with the next call if its
+        results are read after that call was enqueued; ALL of them are complete after a pipeline_flush() on the reading stream issued
+        before the next pipelined call (include/edgecape_hip.h)."""
         o, eo = outputs
         _lib.check(self.lib.ec_forward_pipelined(self.h, iq.data_ptr(), self._ptr_array(is_), self._ptr_array(ts), ms.data_ptr(),
                                                  edges.ctypes.data, off.ctypes.data, iq.shape[0], len(is_), _lib.current_stream(),
@@ -221,7 +221,7 @@ class HipEngine:
         return o
 
     def pipeline_flush(self, stream=None):
-        """Make `stream` (default: torch's current stream) wait for the decoder of the most recent pipelined call; no host sync."""
+        """Make `stream` (default: torch's current stream) wait for the head of the most recent pipelined call; no host sync."""
         st = _lib.current_stream() if stream is None else stream.cuda_stream
         _lib.check(self.lib.ec_pipeline_flush(self.h, st))
 

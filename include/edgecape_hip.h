@@ -129,17 +129,22 @@ int ec_forward(ec_handle h, const float* img_q_dev, const float* const* img_s_de
                const int32_t* edge_offsets, int bs, int S, void* stream, const ec_outputs* out);
 
 /* Pipelined forward for back-to-back batches (the reference's evaluation loop, EdgeCape/apis/test.py:31-33, only needs the results
- * in order).  Same arguments and results as ec_forward, different completion rule: the backbone and the first phase of the head run
- * on `stream` as usual, but the head's last phase - the decoder layers and keypoint branches, ~0.55 ms of dependent small kernels on
- * an otherwise idle chip - is enqueued on a stream owned by the library and is NOT joined: it runs beside the NEXT call's backbone.
- *   - the outputs of call i (output_kpts_dev, out_points_dev; the other outputs are written before the call's work on `stream`
- *     ends) are complete once a stream has passed an ec_pipeline_flush(h, that_stream) issued after call i, or once `stream` has passed
- *     the backbone of the next ec_forward / ec_forward_pipelined / ec_head call on this handle (every entry point that touches the head
- *     first waits for a pending decoder);
+ * in order).  Same arguments and results (bit for bit) as ec_forward, different completion rule: only the backbone runs on `stream`;
+ * the WHOLE head of call i - ~1.7 ms of dependent small kernels that cannot fill the chip - is enqueued on streams owned by the
+ * library and is NOT joined: it runs beside the backbone of call i+1 (a head waits for the previous call's head, which owns the head
+ * workspace, on those streams - never on `stream`).  What reads the caller's heatmaps / masks (adjacency build, pooling tap lists)
+ * needs no backbone output and runs beside the call's OWN backbone.
+ *   - ALL outputs of call i are complete once a stream has passed an ec_pipeline_flush(h, that_stream) issued after call i and before
+ *     the next pipelined call, or once `stream` has passed the first kernel of any other entry point of this handle that touches the
+ *     head (ec_forward, ec_head, ec_support_encode, ec_forward_cached wait for a pending head on `stream`);
  *   - the output buffers of call i must stay valid until then, and consecutive calls must not share output buffers if the caller
- *     reads call i's results after enqueuing call i+1; inputs may be released as for ec_forward (when `stream` has passed the call).
- * ec_pipeline_flush enqueues, on ANY stream, a wait for the decoder of the most recent pipelined call (no host synchronisation):
- * a copy stream can so fetch call i's results without waiting for call i+1's backbone.  Measured: cfg2 +5 % pairs/s. */
+ *     reads call i's results after enqueuing call i+1; inputs may be released as for ec_forward (when `stream` has passed the call:
+ *     the library's last read of the images, heatmaps and masks lies before that point).
+ * ec_pipeline_flush enqueues, on ANY stream, a wait for the head of the most recent pipelined call (no host synchronisation):
+ * a copy stream can so fetch call i's results without waiting for call i+1's backbone.
+ * EC_PIPE_FULL=0 keeps the first form of round 3 (only the decoder phase is deferred; the other outputs are then complete when
+ * `stream` has passed the call).  Measured on cfg2: 4770 pairs/s through ec_forward, 5135 with the decoder phase
+ * deferred, 5235 with the whole head deferred (one box, interleaved). */
 int ec_forward_pipelined(ec_handle h, const float* img_q_dev, const float* const* img_s_dev,
                          const float* const* target_s_dev, const float* mask_s_dev, const int32_t* edges,
                          const int32_t* edge_offsets, int bs, int S, void* stream, const ec_outputs* out);
@@ -193,7 +198,11 @@ int ec_debug_read(ec_handle h, const char* name, float* host_out, int64_t max_el
 
 /* Measurement hook for bench.py (§ roofline): when enabled, a HIP event pair brackets every launch of the
  * backbone QKV GEMM (the north-star kernel) on the caller's stream; ec_profile_read synchronises on them and
- * returns the summed kernel time and the number of launches since the last ec_profile(h, 1, n). */
+ * returns the summed kernel time and the number of launches since the last ec_profile(h, 1, n).
+ * enable = 2 (round 3): SAMPLED - one launch per backbone pass is bracketed, the block index rotating with the pass
+ * (pass p times block p % depth), so that every block is covered over `depth` passes.  An event pair costs the stream
+ * two ~6 us barrier packets around the launch (profiles/r03_step_trace.txt: 12 x 12 us = 2 % of a cfg2 step when every
+ * launch is bracketed); the sampled form keeps the timed region honest to what an unprofiled run does. */
 int ec_profile(ec_handle h, int enable, int max_launches);
 int ec_profile_read(ec_handle h, float* total_ms, int* launches);
 

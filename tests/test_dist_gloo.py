@@ -158,7 +158,7 @@ def test_world2_collect_results_edge_cases(case):
 
 
 class _FakeLib:
-    """ec_profile / ec_profile_read of the C ABI (the QKV launch timers bench.py arms): 12 launches of 1 ms per step."""
+    """ec_profile / ec_profile_read of the C ABI (the QKV launch timers bench.py arms, mode 2: one sampled launch of 1 ms per step)."""
 
     def __init__(self):
         self.armed = 0
@@ -237,7 +237,7 @@ def test_world2_bench_main_runs_its_distributed_branches():
     assert res0["n_gpus"] == 2 and res0["steps"] == 3 and res0["warmup"] == 1 and res0["scaling"] == "weak"
     assert res0["config"]["global_batch"] == 8 and res0["config"]["parallelism"].startswith("dp2")
     assert res0["value"] > 0 and abs(res0["value"] - 2 * 4 * 3 / (res0["ms_per_step"] * 3e-3)) / res0["value"] < 0.01   # whole-job aggregate
-    assert res0["roofline"]["launches_timed"] == 3 * 12 and res0["roofline"]["avg_launch_ms"] == 1.0
+    assert res0["roofline"]["launches_timed"] == 3 and res0["roofline"]["avg_launch_ms"] == 1.0     # sampled: one QKV launch per step
     assert "cpu_baseline" not in res0 and "episode_cached" not in res0 and "bf16_mode" not in res0   # rank-0-only legs are N = 1 only
     assert res0["pipelined"] is True and "unpipelined" not in res0
     assert set(res0["pck_vs_synthetic_gt"]) >= {"PCK@0.2"}

@@ -34,7 +34,7 @@ def _check(line, with_cpu):
     assert isinstance(d["pipelined"], bool)
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and 0 < r["frac"] < 1
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["launches_timed"] == 3 * 12
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["launches_timed"] == 3      # sampled: one QKV launch per step
     assert isinstance(d["env"], dict) and all(k.startswith("EC_") for k in d["env"]) and len(d["library_source_hash"]) == 16
     assert "traffic" in r and (r["traffic"] is not None or "traffic_note" in r)      # never a number from another library build
     if with_cpu:

@@ -334,7 +334,8 @@ def test_support_cache_matches_pairwise_forward(shots):
         eng.forward_cached(qry["img_q"], cache, np.full(8, 3, np.int32))     # episode index out of range
 
 
-@pytest.mark.parametrize("switch", ["EC_CHAIN=0", "EC_OVERLAP=0", "EC_OVERLAP=1", "EC_DEC_PRE=0", "EC_KPT_CHAIN=0", "EC_GEMM8_OFF=1"])
+@pytest.mark.parametrize("switch", ["EC_CHAIN=0", "EC_OVERLAP=0", "EC_OVERLAP=1", "EC_DEC_PRE=0", "EC_KPT_CHAIN=0", "EC_GEMM8_OFF=1",
+                                    "EC_ENC_CHAIN=0", "EC_PIPE_FULL=0", "EC_G8_DYN=1", "EC_G8_DYN=0"])
 def test_runtime_switch_matrix(switch):
     """Every A/B switch that keeps an alternative code path alive in the shipped library (README "Runtime switches") through the
     reference-generated golden vectors of the head and the detector + the cfg2 precision gate: a switch is read once per process, so
@@ -345,8 +346,8 @@ def test_runtime_switch_matrix(switch):
     here = os.path.dirname(os.path.abspath(__file__))
     k, v = switch.split("=")
     env = dict(os.environ, **{k: v})
-    sel = "reference_golden or (headline_mode_fp16_mixed_head and cfg2)"
+    sel = "reference_golden or (headline_mode_fp16_mixed_head and cfg2) or forward_pipelined_bit_equal"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_model.py"), os.path.join(here, "test_gpu_precision_modes.py"),
-                        "-q", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+                        os.path.join(here, "test_gpu_next_rows.py"), "-q", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]

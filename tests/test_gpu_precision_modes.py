@@ -145,7 +145,9 @@ def conformance_at_scale(n_batches=8, wseeds=(0, 1), backbone="fp16", head="mixe
         eng = HipEngine(w, arch=c["arch"], image_size=c["H"], max_batch=c["bs"], max_shots=c["S"], backbone_precision=backbone, head_precision=head)
         gots, refs, valids = [], [], []
         for b in range(n_batches):
-            batch = synth.make_pairs(c["bs"], c["S"], c["H"], seed=c["iseed"] + 17 * ws + b, fixed_n_kp=False)
+            # DISJOINT pairs: pair i of synth.make_pairs is seeded by seed + first_index + i, so batch b takes the indices b*bs .. b*bs+bs-1
+            # of the weight seed's own range (the first round-3 record used seed + b and so saw the same 39 pairs eight times over)
+            batch = synth.make_pairs(c["bs"], c["S"], c["H"], seed=c["iseed"] + 100000 * (1 + ws), first_index=b * c["bs"], fixed_n_kp=False)
             mask = batch["target_weight_s"][0].copy()
             for tw in batch["target_weight_s"]:
                 mask = mask * tw
@@ -173,23 +175,25 @@ def conformance_at_scale(n_batches=8, wseeds=(0, 1), backbone="fp16", head="mixe
 
 
 def test_headline_conformance_at_scale():
-    """cfg2, fp16 backbone + mixed head (the bench default), 256 pairs x 2 weight seeds vs the oracle.  Gates = the observed rates
-    with head-room (profiles/r03_conformance_fp16_mixed.json): the share of valid keypoints whose proposal argmax flips and the
+    """cfg2, fp16 backbone + mixed head (the bench default), 256 DISJOINT pairs x 2 weight seeds vs the oracle.  Gates = the observed
+    rates with head-room (profiles/r03_conformance_fp16_mixed.json): the share of valid keypoints whose proposal argmax flips and the
     share outside 1e-3 are MEASURED quantities of this mode; every flip-free sample must be inside the tolerance outright."""
     per_seed, pooled = conformance_at_scale()
     print("conformance", per_seed, pooled)
-    # observed (profiles/r03_conformance_fp16_mixed.json, MI355X, round 3): 0 flips of 20 503 valid keypoints, max |d| 1.63e-4 over ALL
-    # of them, p99 8.7e-5, median 3.0e-6, nothing above 1e-3, PCK@0.2 vs the oracle's answers 1.0 - on both weight seeds
+    # observed (MI355X, round 3, 512 disjoint pairs): 22 argmax flips of 20 293 valid keypoints (1.08e-3; 10 / 12 per weight seed), 491 of
+    # 512 samples flip-free with max |d| 2.8e-4 on them, p99 8.7e-5, median 3.5e-6, 9.9e-4 of the keypoints outside 1e-3 (all in flipped
+    # samples), PCK@0.2 against the oracle's answers 0.9993.  (The first round-3 record - 0 flips - had drawn the same 39 pairs per
+    # weight seed eight times over: overlapping seeds.)  BASELINE.md section 4 gates a reduced-precision mode by its PCK@0.2 delta
+    # (<= 0.1) and reports the flip count; the 1e-3 gate is the parity modes' (fp32, bf16x3).
     assert pooled["pairs"] >= 512
-    assert pooled["max_clean"] < 5e-4, pooled                       # continuous part of the error: 3x head-room on the observed, 2x inside the tolerance
+    assert pooled["max_clean"] < 5e-4, pooled                       # continuous part of the error: 2x inside the tolerance
     assert pooled["p99"] < 2e-4 and pooled["median"] < 1e-5
-    assert pooled["flips"] <= 2, pooled                             # an argmax near-tie may flip on another box / clock: <= 1e-4 of the keypoints
-    assert pooled["frac_gt_1e3"] <= 2e-3, pooled                    # (one flipped sample moves its ~40 valid keypoints: 2 flips = 0.4 %)
-    if pooled["flips"] == 0:
-        assert pooled["max_all"] < 5e-4 and pooled["frac_gt_1e3"] == 0.0 and pooled["pck_vs_oracle"] == 1.0
-    assert pooled["pck_vs_oracle"] >= 0.998
+    assert pooled["flip_frac"] <= 2.5e-3, pooled                    # observed 1.08e-3: an indexing / synchronisation bug flips percents
+    assert pooled["frac_gt_1e3"] <= 2.5e-3, pooled
+    assert pooled["clean_samples"] >= 0.93 * pooled["pairs"], pooled   # observed 491 / 512
+    assert pooled["pck_vs_oracle"] >= 0.998                         # observed 0.9993; north star: PCK@0.2 within +-0.1
     for st in per_seed:
-        assert st["max_clean"] < 5e-4 and st["flips"] <= 2, st
+        assert st["max_clean"] < 5e-4 and st["flip_frac"] <= 4e-3, st
 
 
 def test_bf16_mode_cfg2_bounded():
