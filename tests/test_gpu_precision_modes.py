@@ -14,9 +14,10 @@ Modes (backbone / head):
   fp16   / bf16x3  headline throughput mode: IEEE fp16 operands at the bf16 MFMA rate; continuous error ~1e-4.
   bf16   / bf16x3  the north-star's literal bf16 tiles: continuous error ~1e-3, reported and bounded, not parity-grade.
 CPU emulation of the operand rounding on 256 pairs (oracle/precision_study.py, ViT-S) predicted: bf16 95 flips, fp16 11, bf16x3 0.
-MEASURED on MI355X at cfg2, 256 pairs x 2 weight seeds (round 3, test_headline_conformance_at_scale, record
-profiles/r03_conformance_fp16_mixed.json): fp16 backbone + mixed head 0 flips of 20 503 valid keypoints, max |d| 1.63e-4, nothing
-above 1e-3; bf16x3 / bf16x3 (256 pairs) max |d| 8.2e-6 (profiles/r03_conformance_bf16x3.json).
+MEASURED on MI355X at cfg2, 256 DISJOINT pairs x 2 weight seeds (round 3, test_headline_conformance_at_scale, record
+profiles/r03_conformance_fp16_mixed.json): fp16 backbone + mixed head 22 flips of 20 293 valid keypoints (1.1e-3), max |d| 2.8e-4 on the
+491 flip-free samples, 1e-3 of the keypoints (flipped samples) above 1e-3, PCK@0.2 vs the oracle 0.9993; bf16x3 / bf16x3: 1 flip, max
+1.1e-5 (profiles/r03_conformance_bf16x3.json).  (An earlier record with 0 flips had drawn 39 distinct pairs per weight seed.)
 """
 import functools
 
