@@ -167,6 +167,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": f"backbone QKV GEMM M={Mq} K={Kq} N={Nq} ({args.precision})",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "flops_per_launch": qkv_flops, "avg_launch_ms": round(qkv_ms, 5), "launches_timed": launches_timed,
+                         "measured_in": ("the timed ec_forward_pipelined steps: the sampled launches share the chip with the previous step's head"
+                                         if pipelined else "the timed ec_forward steps: nothing else on the chip"),
                          "launch_sampling": "one QKV launch per step bracketed by HIP events on the launch stream, block index = step % depth",
                          # context, not the judged peak: what a pure register-operand MFMA loop sustains on this chip with random
                          # (not zero) fp16 operands - the power-management ceiling of real data (tools/mfma_power_probe.hip)
@@ -192,7 +194,18 @@ def main():
         eng, outputs, dt_u, qkv_u = timed_run(args.precision, n_u, args.warmup, True, False)
         result["unpipelined"] = {"value": round(bs * n_u / dt_u, 2), "unit": "images/s", "ms_per_step": round(dt_u / n_u * 1e3, 3),
                                  "qkv_launch_ms": round(qkv_u, 5), "qkv_frac": round(qkv_flops / (qkv_u * 1e-3) / 1e12 / peak, 4) if qkv_u > 0 else None,
-                                 "note": "ec_forward: no overlap between steps; the QKV launches are not disturbed by a concurrent decoder"}
+                                 "note": "ec_forward: no overlap between steps; the QKV launches are not disturbed by a concurrent head"}
+        if qkv_u > 0:
+            # The roofline of a KERNEL: its launches with the chip to themselves (a second timed region of the same process, HIP events on
+            # the launch stream as above; rocprofv3's kernel trace serialises kernels and agrees with THIS duration).  The figure sampled
+            # inside the pipelined steps - launch duration including the time shared with the previous step's head - stays beside it.
+            r = result["roofline"]
+            r["in_pipelined_steps"] = {"achieved": r["achieved"], "frac": r["frac"], "avg_launch_ms": r["avg_launch_ms"],
+                                       "launches_timed": r["launches_timed"], "note": r["measured_in"]}
+            ach_u = qkv_flops / (qkv_u * 1e-3) / 1e12
+            r.update({"achieved": round(ach_u, 2), "frac": round(ach_u / peak, 4), "avg_launch_ms": round(qkv_u, 5),
+                      "launches_timed": timed_run.launches,
+                      "measured_in": f"{n_u} timed ec_forward steps of this process (nothing else on the chip), one sampled launch per step"})
     if world == 1 and not args.no_alt and args.precision != "bf16":
         # the same step with bf16 operands (north_star's wording): same kernels and rate, 8x coarser rounding - measured beside the
         # headline so both precisions come from one process on one box; it does NOT meet the 1e-3 gate (test_bf16_mode_cfg2_bounded)
