@@ -166,19 +166,20 @@ def test_eval_loop_real_model_vs_oracle(tmp_path):
         assert np.abs(a["preds"][0, m, :2] - b["preds"][0, m, :2]).max() < 0.3 if m.any() else True
 
 
-@pytest.mark.parametrize("S", [1, 5])
-def test_forward_pipelined_bit_equal(S):
-    """ec_forward_pipelined (decoder phase of call i beside the backbone of call i+1) against ec_forward on the same batches: every
+@pytest.mark.parametrize("arch,H,bs,S,nb", [("dinov2_vits14", 224, 4, 1, 5), ("dinov2_vits14", 224, 4, 5, 5), ("dinov2_vitb14", 256, 32, 1, 3),
+                                               ("dinov2_vits14", 224, 32, 1, 3), ("dinov2_vitl14", 384, 8, 1, 3), ("dinov2_vitb14", 256, 16, 5, 3)])
+def test_forward_pipelined_bit_equal(arch, H, bs, S, nb):
+    """ec_forward_pipelined (the head of call i beside the backbone of call i+1) against ec_forward on the same batches: every
     output of every batch bit-equal, with alternating output sets, results fetched through a copy stream behind ec_pipeline_flush,
-    and with plain ec_forward / ec_head calls mixed into the sequence (every entry point waits for a pending decoder)."""
+    and with plain ec_forward calls mixed into the sequence (every other entry point waits for a pending head).  The cfg2-sized case
+    also runs the backbone's QKV / fc1 GEMMs on their DYNAMIC tile schedule in the pipelined calls (static in ec_forward)."""
     from edgecape_amd.engine import HipEngine
-    arch, H, bs = "dinov2_vits14", 224, 4
     sd = synth.make_weights(arch, seed=3)
     eng = HipEngine(sd, arch=arch, image_size=H, max_batch=bs, max_shots=S, backbone_precision="fp16", head_precision="mixed")
     dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
     batches = []
-    for i in range(5):
-        b = synth.make_pairs(bs, S, H, seed=900 + i, fixed_n_kp=False)
+    for i in range(nb):
+        b = synth.make_pairs(bs, S, H, seed=900 + 100 * i, fixed_n_kp=False)
         mask = b["target_weight_s"][0].copy()
         for tw in b["target_weight_s"]:
             mask = mask * tw

@@ -44,14 +44,14 @@ def main():
     args = ap.parse_args()
     args.out = os.path.abspath(args.out)          # rocprofv3 runs from /tmp
     os.makedirs(args.out, exist_ok=True)
-    bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-episode", "--no-alt", "--steps", "2", "--warmup", "1",
+    bench_cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-episode", "--no-alt", "--steps", "2", "--warmup", "1",
              "--precision", args.precision, "--batch", str(args.batch), "--shots", str(args.shots), "--image-size", str(args.image_size),
              "--arch", args.arch]
     env = dict(os.environ, TMPDIR="/tmp")
     merged = {}
     for tag, counters in PASSES:
         d = os.path.join(args.out, "pmc_" + tag)
-        cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "-d", d, "-o", "r", "--"] + bench
+        cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "-d", d, "-o", "r", "--"] + bench_cmd
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
         if r.returncode != 0:
             sys.exit(f"rocprofv3 pass {tag} failed:\n{r.stderr[-2000:]}")
@@ -63,8 +63,8 @@ def main():
     rows = sorted(merged.items())
     sys.path.insert(0, ROOT)
     import bench
-    name = os.path.basename(bench.pmc_path(args.batch, args.shots, args.image_size, args.arch, args.precision))
-    with open(os.path.join(args.out, name.replace(".json", "_kernels.csv")), "w") as f:
+    json_name = os.path.basename(bench.pmc_path(args.batch, args.shots, args.image_size, args.arch, args.precision))
+    with open(os.path.join(args.out, json_name.replace(".json", "_kernels.csv")), "w") as f:
         f.write("Kernel,Counter,Dispatches,MeanValuePerDispatch,MeanDurationNs\n")
         for (kn, cn), (n, v, dur) in rows:
             f.write(f'"{kn}",{cn},{n},{v:.3f},{dur:.1f}\n')
@@ -86,7 +86,7 @@ def main():
         "kernel": f"{name} (backbone QKV GEMM, M={M} K={K} N={N}, {args.precision})",
         "workload": [args.batch, args.shots, args.image_size, args.arch, args.precision],
         "source_hash": build.source_hash(),
-        "command": "rocprofv3 --pmc <counters> --kernel-trace -- " + " ".join(bench[1:]).replace(ROOT + "/", ""),
+        "command": "rocprofv3 --pmc <counters> --kernel-trace -- " + " ".join(bench_cmd[1:]).replace(ROOT + "/", ""),
         "passes": {t: c for t, c in PASSES},
         "dispatches": merged[(name, "FETCH_SIZE")][0],
         "fetch_size_kb_per_launch": round(fetch_kb, 3), "write_size_kb_per_launch": round(write_kb, 3), "fetch_correction": 2.0,
@@ -100,7 +100,7 @@ def main():
         "mean_duration_us_profiled": round(dur_ns / 1e3, 2),
         "effective_clock_ghz": round(gui / 8.0 / dur_ns, 3) if dur_ns > 0 else None,
     }
-    with open(os.path.join(args.out, name), "w") as f:
+    with open(os.path.join(args.out, json_name), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
 
