@@ -166,6 +166,54 @@ def test_eval_loop_real_model_vs_oracle(tmp_path):
         assert np.abs(a["preds"][0, m, :2] - b["preds"][0, m, :2]).max() < 0.3 if m.any() else True
 
 
+def test_forward_pipelined_stress():
+    """A long random sequence of pipelined / plain calls and flushes on one handle (the head of call i beside the backbone of call
+    i + 1, heads queued behind one another, plain calls and flushes cutting in): every call's outputs bit-equal to ec_forward's."""
+    from edgecape_amd.engine import HipEngine
+    arch, H, bs, S = "dinov2_vits14", 224, 6, 1
+    sd = synth.make_weights(arch, seed=4)
+    eng = HipEngine(sd, arch=arch, image_size=H, max_batch=bs, max_shots=S, backbone_precision="fp16", head_precision="mixed")
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    keys = ("output_kpts", "initial_proposals", "similarity_map", "adj", "attn_adj", "out_points")
+    batches, ref = [], []
+    for i in range(6):
+        b = synth.make_pairs(bs, S, H, seed=7000 + 50 * i, fixed_n_kp=False)
+        e, o = eng._edges([m["sample_skeleton"][0] for m in b["img_metas"]], bs)
+        batches.append(dict(iq=dev(b["img_q"]), is_=[dev(x) for x in b["img_s"]], ts=[dev(x) for x in b["target_s"]],
+                            ms=dev(b["target_weight_s"][0].reshape(bs, -1)), edges=e, off=o))
+        outs = eng._outputs(bs)
+        eng.forward_resident(batches[-1]["iq"], batches[-1]["is_"], batches[-1]["ts"], batches[-1]["ms"], e, o, outs)
+        torch.cuda.synchronize()
+        ref.append({k: outs[0][k].clone() for k in keys})
+    rng = np.random.default_rng(11)
+    copy_stream = torch.cuda.Stream()
+    pending = []                                                   # (batch index, host copies, event)
+    n_pipe = 0
+    for step in range(60):
+        bi = int(rng.integers(0, len(batches)))
+        b = batches[bi]
+        outs = eng._outputs(bs)                                    # fresh output set per call: results may be fetched late
+        if rng.random() < 0.75:
+            eng.forward_pipelined(b["iq"], b["is_"], b["ts"], b["ms"], b["edges"], b["off"], outs)
+            n_pipe += 1
+        else:
+            eng.forward_resident(b["iq"], b["is_"], b["ts"], b["ms"], b["edges"], b["off"], outs)
+        copy_stream.wait_stream(torch.cuda.current_stream())
+        eng.pipeline_flush(copy_stream)                            # (after a plain call: nothing pending, a no-op wait)
+        with torch.cuda.stream(copy_stream):
+            host = {k: outs[0][k].to("cpu", non_blocking=True) for k in keys}
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+        pending.append((bi, host, ev, outs))
+        if rng.random() < 0.2:
+            eng.pipeline_flush()                                   # a flush on the compute stream cuts the overlap now and then
+    torch.cuda.synchronize()
+    assert n_pipe > 30
+    for step, (bi, host, ev, _) in enumerate(pending):
+        for k in keys:
+            assert torch.equal(host[k], ref[bi][k].cpu()), (step, bi, k)
+
+
 @pytest.mark.parametrize("arch,H,bs,S,nb", [("dinov2_vits14", 224, 4, 1, 5), ("dinov2_vits14", 224, 4, 5, 5), ("dinov2_vitb14", 256, 32, 1, 3),
                                                ("dinov2_vits14", 224, 32, 1, 3), ("dinov2_vitl14", 384, 8, 1, 3), ("dinov2_vitb14", 256, 16, 5, 3)])
 def test_forward_pipelined_bit_equal(arch, H, bs, S, nb):
