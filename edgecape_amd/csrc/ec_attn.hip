@@ -16,6 +16,8 @@
 //   fp32 path : v_mfma_f32_32x32x2_f32 (exact fp32 products) — parity mode.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "ec_common.h"
 
 namespace ec {
@@ -470,8 +472,11 @@ __device__ __forceinline__ void split8v(const f32x4 x0, const f32x4 x1, bf16x8& 
   lo = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
 }
 
-template <int HD>
+// KV16: K and V arrive as IEEE fp16 (the image K|V projections of the mixed head's single-pass fp16 layers store them so: half the
+// bytes written by the projection and read here; an fp16 value splits EXACTLY into hi + lo bf16, so the three-MFMA product is exact on it)
+template <int HD, bool KV16 = false>
 __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
+  typedef typename std::conditional<KV16, _Float16, float>::type kv_t;
   constexpr int ROWB = HD * 2;             // bytes per bf16 row of an LDS image
   constexpr int IMG = 64 * ROWB;           // one image: 64 keys
   constexpr int KS16 = HD / 16;            // k16 MFMA steps of S^T
@@ -486,8 +491,8 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
   const int h = blockIdx.y, b = blockIdx.z;
   const int q0 = blockIdx.x * 128 + wave * 32;
   const float* Q = (const float*)p.Q + (long)b * p.sQ + h * HD;
-  const float* K = (const float*)p.K + (long)b * p.sK + h * HD;
-  const float* V = (const float*)p.V + (long)b * p.sV + h * HD;
+  const kv_t* K = (const kv_t*)p.K + (long)b * p.sK + h * HD;
+  const kv_t* V = (const kv_t*)p.V + (long)b * p.sV + h * HD;
   constexpr float LOG2E = 1.44269504088896340736f;
   const float scale = rsqrtf((float)HD) * LOG2E;
 
@@ -523,8 +528,13 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
       const int r = idx / (HD / 4), c4 = idx % (HD / 4);
       int kr = k0 + r;
       kr = kr < p.Lk ? kr : p.Lk - 1;
-      kreg[it] = *(const f32x4*)(K + (long)kr * p.ldk + c4 * 4);
-      vreg[it] = *(const f32x4*)(V + (long)kr * p.ldv + c4 * 4);
+      if constexpr (KV16) {
+        kreg[it] = __builtin_convertvector(*(const f16x4*)(K + (long)kr * p.ldk + c4 * 4), f32x4);
+        vreg[it] = __builtin_convertvector(*(const f16x4*)(V + (long)kr * p.ldv + c4 * 4), f32x4);
+      } else {
+        kreg[it] = *(const f32x4*)(K + (long)kr * p.ldk + c4 * 4);
+        vreg[it] = *(const f32x4*)(V + (long)kr * p.ldv + c4 * 4);
+      }
     }
   };
   auto write_tile = [&]() {
@@ -666,8 +676,11 @@ int attention(const AttnP& p, hipStream_t st) {
   dim3 grid((p.Lq + 127) / 128, p.H, p.B);
   if (!p.bf16 && p.split) {
     EC_REQUIRE(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldv % 4 == 0 && p.ldo % 4 == 0, -1, "attention: strides must be multiples of 4");
-    if (p.hd == 64) hipLaunchKernelGGL(attn_split_kernel<64>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(attn_split_kernel<32>, grid, dim3(256), 0, st, p);
+    if (p.kv16) {
+      EC_REQUIRE(p.hd == 64, -1, "attention: fp16 K / V only for head dim 64 (the token -> image cross attention)");
+      hipLaunchKernelGGL((attn_split_kernel<64, true>), grid, dim3(256), 0, st, p);
+    } else if (p.hd == 64) hipLaunchKernelGGL((attn_split_kernel<64>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_split_kernel<32>), grid, dim3(256), 0, st, p);
     EC_LAUNCH_CHECK();
     return 0;
   }

@@ -328,7 +328,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_nt_kernel(GemmP p) {
           if (p.c_bf16) {
             u32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (unsigned)f2h<F16>(v[2 * e]) | ((unsigned)f2h<F16>(v[2 * e + 1]) << 16);
+            for (int e = 0; e < 4; ++e)   // (16-bit output of the single-pass fp16 mode: IEEE fp16, like its operands)
+              o[e] = (unsigned)f2h<F16 || MODE == GM_SPLIT1>(v[2 * e]) | ((unsigned)f2h<F16 || MODE == GM_SPLIT1>(v[2 * e + 1]) << 16);
             *(u32x4*)(Cb + ((long)m * p.ldc + n) * 2) = o;
           } else {
             f32x4 o0, o1;

@@ -66,7 +66,9 @@ constexpr int G8_AHEAD = 5;               // half-tiles the load stream runs ahe
   } while (0)
 
 // Epilogue kinds (compile-time): the three shapes of the bf16 backbone blocks + a generic one (every GemmP option).
-enum { G8_GENERIC = 0, G8_BIAS_BF16 = 1, G8_SCALE_BF16 = 2, G8_GELU_BF16 = 3 };
+// G8_TAB_*: C = acc + bias[n] + table[m % period][n] (the patch embedding's positional table; the head's image K|V / image-query
+// projections, whose positional half is folded into such a table), fp32 or 16-bit output, through the staged whole-line epilogue.
+enum { G8_GENERIC = 0, G8_BIAS_BF16 = 1, G8_SCALE_BF16 = 2, G8_GELU_BF16 = 3, G8_TAB_H16 = 4, G8_TAB_F32 = 5 };
 
 // GELU for 16-bit outputs: x * Phi(x) with Phi(x) = 1 / (1 + 2^(x * P(x^2))), P an even minimax polynomial fitted to the erf
 // form (nn.GELU default, dinov2 Mlp) on |x| <= 9.  bf16 outputs: degree 2 in x^2, max |err| 2.5e-5 (far below the bf16 rounding
@@ -150,15 +152,56 @@ __device__ __forceinline__ void g8_epilogue_generic(const GemmP& p, f32x4 (&acc)
 // zeroed on the way out: the next tile accumulates into them.
 //   rsC: buffer descriptor of C with num_records = M * ldc bytes (rows past M are dropped by its range check); goff: byte offset in C of
 //   (row m0 + wr*128 + mi*16 + (lane>>3), column n0 + wc*64 + (lane&7)*8); col_ok: this lane's 8 columns are inside N.
+//   trow (G8_TAB_* kinds): this lane's row of the table, at the wave's first column (table + (m % period) * ldt + n0 + wc*64); ncols: how
+//   many of the wave's 64 columns lie inside N (a multiple of 16: a lane's four columns are all inside or all outside).
 template <int KIND, bool F16, int LAB>
 __device__ __forceinline__ void g8_piece(f32x4 (&a)[4], const __amdgpu_buffer_rsrc_t rsC, unsigned goff, unsigned ldc2, bool col_ok, char* stg,
-                                         const char* bias_lds, const char* gam_lds, int lane) {
+                                         const char* bias_lds, const char* gam_lds, int lane, const float* trow = nullptr, int ncols = 64) {
   const int wrow = lane & 15, wq = lane >> 4;                       // writer: fragment row, column quad
   const int rrow = lane >> 3, rch = lane & 7;                       // reader: row within 8, 16-byte chunk
+  if constexpr (KIND == G8_TAB_F32) {
+    // fp32 output: the 2 KiB staging slot takes 16 rows x 32 columns, so a piece leaves in two halves of two stores each (8 rows x
+    // 128 B = whole lines; the generic epilogue's fragment-wise stores are 16 rows x 64 B, half lines at twice the cost per byte)
+    f32x4 t[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {   // all four table loads in flight before the first use
+      const int c0 = (ni >> 1) * 32 + (ni & 1) * 16 + wq * 4;
+      t[ni] = c0 < ncols ? *(const f32x4*)(trow + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int ni = half * 2 + q;
+        const int c0 = half * 32 + q * 16 + wq * 4;
+        const f32x4 v = a[ni] + *(const f32x4*)(bias_lds + c0 * 4) + t[ni];
+        *(f32x4*)(stg + wrow * 128 + (((q * 4 + wq) ^ (wrow & 7)) << 4)) = v;
+        a[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = j * 8 + rrow;
+        const u32x4 o = *(const u32x4*)(stg + row * 128 + ((rch ^ (row & 7)) << 4));
+        // (always issued: the seam's counted waits assume 32 stores per wave and tile; lanes past N / rows past M are dropped by the range check)
+        const bool ok = half * 32 + rch * 4 < ncols;
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsC, ok ? goff + (unsigned)(j * 8) * ldc2 + (unsigned)(half * 128) : 0xFFFFFFF0u, 0, 0);
+      }
+    }
+    return;
+  }
+  f32x4 tb[4];
+  if constexpr (KIND == G8_TAB_H16) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int c0 = (ni >> 1) * 32 + (ni & 1) * 16 + wq * 4;
+      tb[ni] = c0 < ncols ? *(const f32x4*)(trow + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
     const int c0 = (ni >> 1) * 32 + (ni & 1) * 16 + wq * 4;         // first of this lane's 4 columns inside the wave's 64
     f32x4 v = a[ni] + *(const f32x4*)(bias_lds + c0 * 4);
+    if constexpr (KIND == G8_TAB_H16) v += tb[ni];
     if constexpr (KIND == G8_GELU_BF16) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = gelu_fast8<F16>(v[e]);
@@ -250,7 +293,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   constexpr bool FAST = KIND != G8_GENERIC && !(LAB & 32);   // bias from LDS, epilogue pieces through the staging slot
   constexpr bool NODRAIN = FAST && !(LAB & 64);              // the load stream is not drained at the seam
   constexpr int NB = KIND == G8_SCALE_BF16 ? 2 : 1;          // LDS-DMA pieces of one bias (+ LayerScale) slice
-  constexpr int NST = 16;                                    // global stores of one tile's epilogue per wave
+  constexpr int NST = KIND == G8_TAB_F32 ? 32 : 16;          // global stores of one tile's epilogue per wave
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -410,7 +453,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 af[4][2], b0[2][2], b1[2][2];
 
-  const unsigned ldc2 = (unsigned)p.ldc * 2u;
+  const unsigned ldc2 = (unsigned)p.ldc * (KIND == G8_TAB_F32 ? 4u : 2u);   // row pitch of C in bytes
   const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((unsigned)p.M * ldc2), 0x00020000);   // (host: < 2 GiB)
   auto pieces = [&](int mi0, int m0, int n0, int par) {   // pieces mi0, mi0 + 1 of tile (m0, n0)
     if constexpr (FAST) {
@@ -428,11 +471,17 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
         }
       } else {
         const bool col_ok = n0 + wc * 64 + (lane & 7) * 8 < p.N;
+        constexpr unsigned esz = KIND == G8_TAB_F32 ? 4u : 2u;
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
           const int r0 = m0 + wr * 128 + (mi0 + d) * 16;
-          const unsigned goff = (unsigned)(r0 + (lane >> 3)) * ldc2 + (unsigned)(n0 + wc * 64) * 2u + (unsigned)(lane & 7) * 16u;
-          g8_piece<KIND == G8_GENERIC ? G8_BIAS_BF16 : KIND, F16, LAB>(acc[mi0 + d], rsC, goff, ldc2, col_ok, stg, bl, gl, lane);
+          const unsigned goff = (unsigned)(r0 + (lane >> 3)) * ldc2 + (unsigned)(n0 + wc * 64) * esz + (unsigned)(lane & 7) * 16u;
+          if constexpr (KIND == G8_TAB_H16 || KIND == G8_TAB_F32) {
+            const float* trow = p.table + (long)((r0 + (lane & 15)) % p.period) * p.ldt + n0 + wc * 64;
+            g8_piece<KIND, F16, LAB>(acc[mi0 + d], rsC, goff, ldc2, col_ok, stg, bl, gl, lane, trow, min(max(p.N - n0 - wc * 64, 0), 64));
+          } else {
+            g8_piece<KIND == G8_GENERIC ? G8_BIAS_BF16 : KIND, F16, LAB>(acc[mi0 + d], rsC, goff, ldc2, col_ok, stg, bl, gl, lane);
+          }
         }
       }
     }
@@ -591,7 +640,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
 // Per-device launch state: the 160 KiB dynamic-LDS attribute is a per-device function attribute and the CU count differs per
 // device, so a process that drives several GPUs (one engine per device) gets both for every device it touches.
 namespace {
-struct G8Dev { bool attr_done = false; int ncu = 0; };
+struct G8Dev { bool attr_done = false; int ncu = 0; float* zeros = nullptr; };   // zeros: the bias of a table kind called without one
 G8Dev g8_dev[64];
 }  // namespace
 
@@ -609,13 +658,19 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
     if (p.act == ACT_NONE && !p.gamma) kind = G8_BIAS_BF16;
     else if (p.act == ACT_NONE && p.gamma) kind = G8_SCALE_BF16;
     else if (p.act == ACT_GELU && !p.gamma) kind = G8_GELU_BF16;
+  } else if (p.table && !p.resid && !p.gamma && !p.aux && p.act == ACT_NONE && p.period > 0 && p.ldt % 4 == 0 && p.ldc % 4 == 0 &&
+             (long)p.M * p.ldc * (p.c_bf16 ? 2 : 4) < (1l << 31)) {
+    static const bool tab_off = getenv("EC_G8_TAB") && atoi(getenv("EC_G8_TAB")) == 0;   // A/B: the generic epilogue
+    if (!tab_off) kind = p.c_bf16 ? G8_TAB_H16 : G8_TAB_F32;
   }
 #define G8_ROW(F) \
       {gemm8_bf16_kernel<0, 0, F>, gemm8_bf16_kernel<0, 1, F>, gemm8_bf16_kernel<0, 2, F>, gemm8_bf16_kernel<0, 3, F>, gemm8_bf16_kernel<0, 4, F>}, \
       {gemm8_bf16_kernel<1, 0, F>, gemm8_bf16_kernel<1, 1, F>, gemm8_bf16_kernel<1, 0, F>, gemm8_bf16_kernel<1, 0, F>, gemm8_bf16_kernel<1, 0, F>}, \
       {gemm8_bf16_kernel<2, 0, F>, gemm8_bf16_kernel<2, 0, F>, gemm8_bf16_kernel<2, 2, F>, gemm8_bf16_kernel<2, 0, F>, gemm8_bf16_kernel<2, 4, F>}, \
-      {gemm8_bf16_kernel<3, 0, F>, gemm8_bf16_kernel<3, 0, F>, gemm8_bf16_kernel<3, 0, F>, gemm8_bf16_kernel<3, 3, F>, gemm8_bf16_kernel<3, 0, F>}
-  static const kern_t table[2][4][5] = {{G8_ROW(false)}, {G8_ROW(true)}};
+      {gemm8_bf16_kernel<3, 0, F>, gemm8_bf16_kernel<3, 0, F>, gemm8_bf16_kernel<3, 0, F>, gemm8_bf16_kernel<3, 3, F>, gemm8_bf16_kernel<3, 0, F>}, \
+      {gemm8_bf16_kernel<4, 0, F>, gemm8_bf16_kernel<4, 0, F>, gemm8_bf16_kernel<4, 0, F>, gemm8_bf16_kernel<4, 0, F>, gemm8_bf16_kernel<4, 0, F>}, \
+      {gemm8_bf16_kernel<5, 0, F>, gemm8_bf16_kernel<5, 0, F>, gemm8_bf16_kernel<5, 0, F>, gemm8_bf16_kernel<5, 0, F>, gemm8_bf16_kernel<5, 0, F>}
+  static const kern_t table[2][6][5] = {{G8_ROW(false)}, {G8_ROW(true)}};
 #undef G8_ROW
   int dev = 0;
   EC_HIP(hipGetDevice(&dev));
@@ -623,9 +678,11 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
   G8Dev& ds = g8_dev[dev];
   if (!ds.attr_done) {
     for (int f = 0; f < 2; ++f)
-      for (int k = 0; k < 4; ++k)
+      for (int k = 0; k < 6; ++k)
         for (int t = 0; t < 5; ++t)
           EC_HIP(hipFuncSetAttribute((const void*)table[f][k][t], hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));
+    EC_HIP(hipMalloc((void**)&ds.zeros, 16384 * sizeof(float)));
+    EC_HIP(hipMemset(ds.zeros, 0, 16384 * sizeof(float)));
     EC_HIP(hipDeviceGetAttribute(&ds.ncu, hipDeviceAttributeMultiprocessorCount, dev));
     ds.attr_done = true;
   }
@@ -633,6 +690,9 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
   long grid = ds.ncu;
   if (ntiles < grid) grid = ntiles;
   GemmP q = p;
+  if ((kind == G8_TAB_H16 || kind == G8_TAB_F32) && !q.bias) {
+    if (p.N > 16384) kind = G8_GENERIC; else q.bias = ds.zeros;
+  }
   if (ntiles <= grid || grid < 8 || p.K < 256 || (kind != G8_BIAS_BF16 && kind != G8_GELU_BF16)) q.sched = nullptr;   // one tile per workgroup: nothing to deal out (K >= 256: the hand-over spans three K-tiles)
   hipLaunchKernelGGL(table[p.h_f16 ? 1 : 0][kind][p.tag], dim3((unsigned)grid), dim3(512), G8_LDS, st, q);
   EC_LAUNCH_CHECK();

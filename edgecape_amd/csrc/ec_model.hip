@@ -134,6 +134,8 @@ struct ec_model {
   Norm dec_norm;
   Lin rp0, rp1, pg_support, pg_query, pg_dyn0, pg_dyn2;
   Lin dec_kv_all; const float* dec_kv_table = nullptr;   // decoder cross-attention K|V projections of all layers, stacked
+  const float* dec_kv_table_L = nullptr;                 // ... the table padded to L rows (period L): the all-rows form of image_kv_all
+  bf16_t* e_x16 = nullptr;                                // fp16 copy of the encoder output [bs*L, d] (operand of that form)
   std::vector<KptBranch> kpt;
 
   // workspace (device)
@@ -542,6 +544,8 @@ struct LayerIO {
   bool update_mem;
   const float* kv_pre = nullptr;   // if set: K|V of the image tokens were projected beforehand ([nb, HW, ld_kv_pre], K at +0, V at +E)
   long ld_kv_pre = 0;
+  long s_kv_pre = 0;               // batch stride of kv_pre in elements (0: HW * ld_kv_pre)
+  bool kv16 = false;               // ... and stored as IEEE fp16 (kv_pre then points at fp16 data; ld_kv_pre in fp16 elements): kv16_on()
   // cross-stream hand-offs (decoder helper stream): the first overwrite of x (LN1) waits for wait_x (a helper is still reading the
   // previous layer's x), the cross-attention waits for wait_ca[] (query positional half of x / pre-projected K|V)
   hipEvent_t wait_x = nullptr;
@@ -564,9 +568,19 @@ struct LayerIO {
 
 // K|V of the image tokens for a layer's token->image cross attention, one batch entry per sample (mem may be a strided view):
 // kv[nb, HW, 2E], the positional half of K folded into the epilogue table (encoder_decoder.py:604-617).
+// The image K|V of a single-pass fp16 layer (head_precision = EC_MIXED) are STORED as IEEE fp16 (round 3): they come out of a GEMM on
+// fp16-rounded operands, so the extra rounding is of the size of the error they already carry, the projection writes half the bytes
+// (it is bound by its output: the decoder's stacked K|V were 127 MB per step and the most expensive single kernel of the head,
+// 171 us of step time) and the cross attention reads half (attn_split_kernel<64, true>).  EC_KV16=0: fp32 as before.
+static bool kv16_on(const ec_model* m, const Lin& kv) {
+  static const bool off = getenv("EC_KV16") && atoi(getenv("EC_KV16")) == 0;
+  return !off && m->head_mixed && m->head_split && kv.h1 && m->E / m->cfg.nhead == 64;
+}
+
 static int project_image_kv(ec_model* m, const DecLayer& L, const float* mem, long s_mem, int nb, float* kv, hipStream_t st,
                             const bf16_t* mem16 = nullptr) {
   const int d = m->d, E = m->E, HW = m->HW;
+  const int out16 = kv16_on(m, L.ca_kv) ? 1 : 0;     // (kv is then an fp16 buffer)
   if (mem16 && L.ca_kv.wf16 && L.ca_kv.h1 && s_mem == (long)HW * d && (long)nb * HW >= 1024) {
     // single-pass fp16 layer, contiguous image rows and an fp16 copy of them at hand (norm4 wrote it): one [nb * HW, 2E] problem on the
     // backbone's 8-phase 16-bit GEMM (fp32 output + positional table) - the same products and fp32 accumulation as the fp16x1 path of
@@ -574,7 +588,7 @@ static int project_image_kv(ec_model* m, const DecLayer& L, const float* mem, lo
     GemmP q;
     q.A = mem16; q.lda = d; q.ab_bf16 = 1; q.h_f16 = 1;
     q.B = L.ca_kv.wf16; q.ldb = d;
-    q.C = kv; q.ldc = 2 * E;
+    q.C = kv; q.ldc = 2 * E; q.c_bf16 = out16;
     q.table = L.ca_kv_table; q.ldt = 2 * E; q.period = HW;
     q.M = nb * HW; q.N = 2 * E; q.K = d;
     return gemm_nt(q, st);
@@ -582,7 +596,7 @@ static int project_image_kv(ec_model* m, const DecLayer& L, const float* mem, lo
   GemmP p;
   p.A = mem; p.lda = d; p.sA = s_mem;
   p.split = L.ca_kv.ws ? (L.ca_kv.h1 ? 2 : 1) : 0; p.B = L.ca_kv.wsel(p.split); p.ldb = d;
-  p.C = kv; p.ldc = 2 * E; p.sC = (long)HW * 2 * E;
+  p.C = kv; p.ldc = 2 * E; p.sC = (long)HW * 2 * E; p.c_bf16 = out16;
   p.table = L.ca_kv_table; p.ldt = 2 * E; p.period = HW;
   p.M = HW; p.N = 2 * E; p.K = d; p.batch = nb;
   return gemm_nt(p, st);
@@ -726,15 +740,17 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
   {
     const float* kvp = io.kv_pre;
     long ldkv = io.ld_kv_pre;
+    bool k16 = io.kv16;
     if (!kvp) {
       RUN(project_image_kv(m, L, io.mem, io.s_mem, io.nb, kv, st));
-      kvp = kv; ldkv = 2 * E;
+      kvp = kv; ldkv = 2 * E; k16 = kv16_on(m, L.ca_kv);
     }
     if (io.wait_kv) EC_HIP(hipStreamWaitEvent(st, io.wait_kv, 0));
     AttnP a;
     a.Q = qc; a.K = kvp; a.V = kvp + E; a.O = att;
+    if (k16) { a.kv16 = 1; a.V = (const bf16_t*)(const void*)kvp + E; }   // (fp16 K|V: V starts E fp16 elements into the row)
     a.ldq = E; a.ldk = a.ldv = ldkv; a.ldo = E;
-    a.sQ = (long)K * E; a.sK = a.sV = (long)HW * ldkv; a.sO = (long)K * E;
+    a.sQ = (long)K * E; a.sK = a.sV = (io.kv_pre && io.s_kv_pre) ? io.s_kv_pre : (long)HW * ldkv; a.sO = (long)K * E;
     a.B = io.nb; a.H = nh; a.Lq = K; a.Lk = HW; a.hd = E / nh;
     a.split = m->head_split ? 1 : 0;   // head throughput mode: bf16x3 MFMAs
     RUN(attention(a, st));
@@ -879,10 +895,14 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
     RUN(linear(fs[s], C, false, m->image_project, m->s_mem + (long)s * Mi * d, d, false, Mi, ACT_NONE, s2));
   if (m->ev_feat_read) EC_HIP(hipEventRecord(m->ev_feat_read, s2));   // (with the pooling on st: the lane's last read of fs)
   if (nsk > 0) {
-    RUN(project_image_kv(m, m->skel[0], m->s_mem, (long)HW * d, nb, m->s_kv, s2));
+    // single-pass fp16 layers: an fp16 copy of the projected image memory (norm4 writes the later layers') puts the first layer's
+    // K|V and image-query projections on the 8-phase GEMM as well (47 -> 23 us for the K|V)
+    bf16_t* mem16 = (m->s_mem16 && m->skel[0].ca_kv.h1 && m->skel[0].ca_kv.wf16) ? m->s_mem16 : nullptr;
+    if (mem16) RUN(f32_to_bf16(m->s_mem, mem16, (long)S * Mi * d, s2, 1));
+    RUN(project_image_kv(m, m->skel[0], m->s_mem, (long)HW * d, nb, m->s_kv, s2, mem16));
     if (ov2) EC_HIP(hipEventRecord(ev_kv, s2));
     RUN(tl_mark(m, "I.kv0", s2));
-    if (nsk > 1) RUN(image_update_q(m, m->skel[0], m->s_mem, nb, m->s_qimg, s2));
+    if (nsk > 1) RUN(image_update_q(m, m->skel[0], m->s_mem, nb, m->s_qimg, s2, mem16));
   }
 
   // (2) support keypoint pooling + query_proj (head.py:175-188)
@@ -920,7 +940,7 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
     io.adj1 = m->adj_r1; io.valid = ss.valid; io.kmask_fixed = ss.kmask_fixed; io.bias = nullptr;
     io.nb = nb; io.bs = bs;
     io.update_mem = false;                       // done below, on s2
-    io.kv_pre = m->s_kv; io.ld_kv_pre = 2 * m->E;
+    io.kv_pre = m->s_kv; io.ld_kv_pre = 2 * m->E; io.kv16 = kv16_on(m, m->skel[i].ca_kv);
     if (ov2) {
       io.wait_x = i > 0 ? ev_xr : nullptr;
       io.wait_kv = ev_kv;
@@ -1033,13 +1053,32 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
   hipEvent_t const ev_sa = m->ev_aux[5];
   const int nL = (int)m->dec.size();
   const bool deferred = m->dq_active && m->dq != nullptr;
+  // fp16 K|V (kv16_on): the projection runs on the backbone's 8-phase GEMM over ALL bs*L encoder rows - image and keypoint rows alike,
+  // one contiguous [bs*L, d] fp16 operand (a small conversion pass) instead of 32 batch entries of 324 fp32 rows; the keypoint rows'
+  // results (24 % of the rows) are never read.  The 2-barrier kernel streamed 590 MB of fp32 / split-packed operands through the LDS
+  // for this K = 256 problem (2304 tiles of 128 x 128: 171 us of step time, the head's most expensive kernel); 636 tiles of 256 x 256
+  // on 16-bit operands move 163 MB.
+  const bool kv_wide = kv16_on(m, m->dec_kv_all) && m->dec_kv_all.wf16 && m->e_x16 && m->dec_kv_table_L && (long)bs * L >= 1024 &&
+                       L <= 2 * HW;   // (the fp16 [bs*L, ..] result must fit the buffer sized for fp32 [bs*HW, ..])
   auto image_kv_all = [&]() -> int {
     // the decoder never updates the image memory (two_way_attn=False, encoder_decoder.py:638): project K|V of the image
     // tokens for ALL decoder layers in one GEMM (stacked weights [nL*2E, d], stacked positional tables [HW, nL*2E])
+    if (kv_wide) {
+      RUN(f32_to_bf16(m->e_x, m->e_x16, (long)Me * d, ax, 1));
+      GemmP q;
+      q.A = m->e_x16; q.lda = d; q.ab_bf16 = 1; q.h_f16 = 1;
+      q.B = m->dec_kv_all.wf16; q.ldb = d;
+      q.C = m->d_kv; q.ldc = (long)nL * 2 * E; q.c_bf16 = 1;
+      q.table = m->dec_kv_table_L; q.ldt = (long)nL * 2 * E; q.period = L;
+      q.M = Me; q.N = nL * 2 * E; q.K = d;
+      RUN(gemm_nt(q, ax));
+      RUN(mark(ev_kv));
+      return tl_mark(m, "A.kv", ax);
+    }
     GemmP p;
     p.A = mem; p.lda = d; p.sA = s_tok;
     p.split = m->dec_kv_all.ws ? (m->dec_kv_all.h1 ? 2 : 1) : 0; p.B = m->dec_kv_all.wsel(p.split); p.ldb = d;
-    p.C = m->d_kv; p.ldc = (long)nL * 2 * E; p.sC = (long)HW * nL * 2 * E;
+    p.C = m->d_kv; p.ldc = (long)nL * 2 * E; p.sC = (long)HW * nL * 2 * E; p.c_bf16 = kv16_on(m, m->dec_kv_all) ? 1 : 0;
     p.table = m->dec_kv_table; p.ldt = (long)nL * 2 * E; p.period = HW;
     p.M = HW; p.N = nL * 2 * E; p.K = d; p.batch = bs;
     RUN(gemm_nt(p, ax));
@@ -1200,6 +1239,11 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     io.adj1 = ss.adj1; io.valid = ss.valid; io.kmask_fixed = ss.kmask_fixed; io.bias = lbias;
     io.nb = bs; io.bs = bs; io.update_mem = false;
     io.kv_pre = m->d_kv + (long)li * 2 * E; io.ld_kv_pre = (long)nL * 2 * E;
+    if (kv16_on(m, m->dec_kv_all)) {   // fp16 K|V: the layer's slice starts li * 2E fp16 elements into the row
+      io.kv16 = true;
+      io.kv_pre = (const float*)(const void*)((const bf16_t*)(const void*)m->d_kv + (long)li * 2 * E);
+      if (kv_wide) io.s_kv_pre = (long)L * nL * 2 * E;   // (all bs*L rows were projected: sample b's image rows start at row b*L)
+    }
     if (li == 0 && ss.dec_bias) io.wait_sa = wait_adj;
     if (ovd) {
       io.wait_x = li > 0 ? ev_x : nullptr;
@@ -1595,6 +1639,11 @@ int ec_finalize(ec_handle m) {
     }
     if ((rc = make_lin_host(m, W, {}, nL * 2 * E, d, &m->dec_kv_all))) return rc;
     if ((rc = upload(m, tb, &m->dec_kv_table))) return rc;
+    {
+      std::vector<float> tl((size_t)L * nL * 2 * E, 0.f);
+      memcpy(tl.data(), tb.data(), tb.size() * sizeof(float));
+      if ((rc = upload(m, tl, &m->dec_kv_table_L))) return rc;
+    }
     for (auto& l : m->dec) { std::vector<float>().swap(l.h_kv_w); std::vector<float>().swap(l.h_kv_table); }
     for (auto& l : m->skel) { std::vector<float>().swap(l.h_kv_w); std::vector<float>().swap(l.h_kv_table); }
   }
@@ -1668,6 +1717,7 @@ int ec_finalize(ec_handle m) {
   WS(s_kvk, S * Mk * 2 * E); WS(s_attimg, S * Mi * E); WS(s_tmpimg, S * Mi * d);
   if (m->head_mixed) WS(s_mem16, S * Mi * d);
   const size_t Me = (size_t)bs * L;
+  if (m->head_mixed) WS(e_x16, Me * d);
   WS(e_x, Me * d); WS(e_qkv, Me * 3 * d); WS(e_att, Me * d); WS(e_tmp, Me * d); WS(e_h, Me * Fd);
   WS(p_fs, Mk * d); WS(p_fq, Mi * d); WS(p_g1, Mk * 128); WS(p_fs2, Mk * d);
   WS(d_qin, Mk * 2 * d); WS(d_sc, Mk * d); WS(d_rp, Mk * d); WS(d_bias, (size_t)bs * m->cfg.nhead * KK); WS(d_bias_all, (size_t)m->cfg.dec_layers * bs * m->cfg.nhead * KK); WS(d_qkv, Mk * 3 * d);

@@ -125,6 +125,12 @@ __global__ void f32_to_bf16_kernel(const float* src, bf16_t* dst, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = f2h<F16>(src[i]);
 }
+// four elements per thread: 16-byte loads, 8-byte stores (n % 4 == 0, both pointers 16-byte aligned)
+template <bool F16>
+__global__ void f32_to_bf16_x4_kernel(const float* src, bf16_t* dst, long n4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) *(u32x2_t*)(dst + 4 * i) = pack4_h<F16>(*(const f32x4*)(src + 4 * i));
+}
 
 __global__ void transpose_pad_bf16_kernel(const float* src, bf16_t* dst, int L, int E, int Lp) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over E*Lp of batch blockIdx.y
@@ -828,6 +834,12 @@ int mean_over(float* dst, const float* src, long stride, int n, long count, hipS
 }
 
 int f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t st, int f16) {
+  if (n % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0) {
+    if (f16) hipLaunchKernelGGL(f32_to_bf16_x4_kernel<true>, dim3(cdiv(n / 4, 256)), dim3(256), 0, st, src, dst, n / 4);
+    else hipLaunchKernelGGL(f32_to_bf16_x4_kernel<false>, dim3(cdiv(n / 4, 256)), dim3(256), 0, st, src, dst, n / 4);
+    EC_LAUNCH_CHECK();
+    return 0;
+  }
   if (f16) hipLaunchKernelGGL(f32_to_bf16_kernel<true>, dim3(cdiv(n, 256)), dim3(256), 0, st, src, dst, n);
   else hipLaunchKernelGGL(f32_to_bf16_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, st, src, dst, n);
   EC_LAUNCH_CHECK();

@@ -32,6 +32,34 @@ def test_out_of_range_edge_is_an_argument_error(eng):
         e.forward(b["img_q"], b["img_s"], b["target_s"], mask, sk)
 
 
+def test_pipelined_call_error_leaves_the_pipeline_usable(eng):
+    """ec_forward_pipelined with a bad edge list fails before anything is enqueued, with a head still in flight from the call before;
+    the next pipelined call and the flush still deliver both good calls' results, bit-equal to ec_forward."""
+    e, _ = eng
+    b, mask, sk = _batch()
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    iq, is_, ts, ms = dev(b["img_q"]), [dev(x) for x in b["img_s"]], [dev(x) for x in b["target_s"]], dev(mask.reshape(2, -1))
+    edges, off = e._edges(sk, 2)
+    ref = e._outputs(2)
+    e.forward_resident(iq, is_, ts, ms, edges, off, ref)
+    torch.cuda.synchronize()
+    o1, o2, o3 = e._outputs(2), e._outputs(2), e._outputs(2)
+    e.forward_pipelined(iq, is_, ts, ms, edges, off, o1)
+    bad = edges.copy()
+    bad[0, 1] = 100
+    with pytest.raises(_lib.EdgeCapeHipError, match="out of range"):
+        e.forward_pipelined(iq, is_, ts, ms, bad, off, o2)
+    e.pipeline_flush()
+    torch.cuda.synchronize()
+    for k in ("output_kpts", "similarity_map", "adj"):
+        assert torch.equal(o1[0][k], ref[0][k]), k
+    e.forward_pipelined(iq, is_, ts, ms, edges, off, o3)
+    e.pipeline_flush()
+    torch.cuda.synchronize()
+    for k in ("output_kpts", "similarity_map", "adj"):
+        assert torch.equal(o3[0][k], ref[0][k]), k
+
+
 def test_batch_larger_than_configured(eng):
     e, _ = eng
     b, mask, sk = _batch(3)
