@@ -474,7 +474,10 @@ __device__ __forceinline__ void split8v(const f32x4 x0, const f32x4 x1, bf16x8& 
 
 // KV16: K and V arrive as IEEE fp16 (the image K|V projections of the mixed head's single-pass fp16 layers store them so: half the
 // bytes written by the projection and read here; an fp16 value splits EXACTLY into hi + lo bf16, so the three-MFMA product is exact on it)
-template <int HD, bool KV16 = false>
+// ONE: single-pass fp16 instead of bf16x3 (head_precision = EC_MIXED, the attentions of the single-pass fp16 layers): Q (pre-scaled), K, V
+// and the probabilities are rounded to IEEE fp16 (P <= 1: exact running maximum), one v_mfma_f32_32x32x16_f16 per product, only the
+// "hi" LDS images are written and read.  Softmax statistics, masks and the bias stay fp32.
+template <int HD, bool KV16 = false, bool ONE = false>
 __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
   typedef typename std::conditional<KV16, _Float16, float>::type kv_t;
   constexpr int ROWB = HD * 2;             // bytes per bf16 row of an LDS image
@@ -506,7 +509,12 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
     for (int m = 0; m < KS16; ++m) {
       f32x4 x0 = *(const f32x4*)(src + m * 16), x1 = *(const f32x4*)(src + m * 16 + 4);
       x0 *= scale; x1 *= scale;
-      split8v(x0, x1, qh[m], ql[m]);
+      if constexpr (ONE) {
+        const u32x2 a = pack4_h<true>(x0), c = pack4_h<true>(x1);
+        qh[m] = __builtin_bit_cast(bf16x8, u32x4{a[0], a[1], c[0], c[1]});
+      } else {
+        split8v(x0, x1, qh[m], ql[m]);
+      }
     }
   }
   f32x16 ot[DT];
@@ -543,11 +551,16 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
       const int idx = tid + it * 256;
       const int r = idx / (HD / 4), c4 = idx % (HD / 4);
       const int off = r * ROWB + (((c4 >> 1) ^ swz(r)) << 4) + (c4 & 1) * 8;
-      u32x2 a, c;
-      split4(kreg[it], a, c);
-      *(u32x2*)(Khi + off) = a; *(u32x2*)(Klo + off) = c;
-      split4(vreg[it], a, c);
-      *(u32x2*)(Vhi + off) = a; *(u32x2*)(Vlo + off) = c;
+      if constexpr (ONE) {
+        *(u32x2*)(Khi + off) = pack4_h<true>(kreg[it]);
+        *(u32x2*)(Vhi + off) = pack4_h<true>(vreg[it]);
+      } else {
+        u32x2 a, c;
+        split4(kreg[it], a, c);
+        *(u32x2*)(Khi + off) = a; *(u32x2*)(Klo + off) = c;
+        split4(vreg[it], a, c);
+        *(u32x2*)(Vhi + off) = a; *(u32x2*)(Vlo + off) = c;
+      }
     }
   };
 
@@ -567,10 +580,14 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
 #pragma unroll
       for (int m = 0; m < KS16; ++m) {
         const int off = row * ROWB + (((2 * m + hi) ^ swz(row)) << 4);
-        const bf16x8 ah = *(const bf16x8*)(Khi + off), al = *(const bf16x8*)(Klo + off);
-        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[m], s[t], 0, 0, 0);
-        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[m], s[t], 0, 0, 0);
-        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[m], s[t], 0, 0, 0);
+        if constexpr (ONE) {
+          s[t] = mfma32x32x16_h<true>(*(const bf16x8*)(Khi + off), qh[m], s[t]);
+        } else {
+          const bf16x8 ah = *(const bf16x8*)(Khi + off), al = *(const bf16x8*)(Klo + off);
+          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[m], s[t], 0, 0, 0);
+          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[m], s[t], 0, 0, 0);
+          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[m], s[t], 0, 0, 0);
+        }
       }
     }
     // key mask of the tile as 64 bits: lane l looks at key k0 + l once (one coalesced byte load instead of 32 scattered ones
@@ -631,8 +648,14 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
 #pragma unroll
       for (int uu = 0; uu < 2; ++uu) {
         bf16x8 ph, pl;
-        split8v(f32x4{s[t][8 * uu], s[t][8 * uu + 1], s[t][8 * uu + 2], s[t][8 * uu + 3]},
-                f32x4{s[t][8 * uu + 4], s[t][8 * uu + 5], s[t][8 * uu + 6], s[t][8 * uu + 7]}, ph, pl);
+        if constexpr (ONE) {
+          const u32x2 a = pack4_h<true>(f32x4{s[t][8 * uu], s[t][8 * uu + 1], s[t][8 * uu + 2], s[t][8 * uu + 3]});
+          const u32x2 c = pack4_h<true>(f32x4{s[t][8 * uu + 4], s[t][8 * uu + 5], s[t][8 * uu + 6], s[t][8 * uu + 7]});
+          ph = __builtin_bit_cast(bf16x8, u32x4{a[0], a[1], c[0], c[1]});
+        } else {
+          split8v(f32x4{s[t][8 * uu], s[t][8 * uu + 1], s[t][8 * uu + 2], s[t][8 * uu + 3]},
+                  f32x4{s[t][8 * uu + 4], s[t][8 * uu + 5], s[t][8 * uu + 6], s[t][8 * uu + 7]}, ph, pl);
+        }
         const int i16 = lane & 15, G = (lane >> 4) & 1;
         const int krow = 32 * t + 16 * uu + 4 * hi + (i16 >> 2);   // second 4-key block: + 8
 #pragma unroll
@@ -642,14 +665,20 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
           const int o1 = (krow + 8) * ROWB + ((chunk ^ swz(krow + 8)) << 4) + (i16 & 1) * 8;
           const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(Vhi + o0));
           const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(Vhi + o1));
-          const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(Vlo + o0));
-          const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(Vlo + o1));
           bf16x8 vh, vl;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { vh[e] = h0[e]; vh[4 + e] = h1[e]; vl[e] = l0[e]; vl[4 + e] = l1[e]; }
-          ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, ot[d], 0, 0, 0);
-          ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, ot[d], 0, 0, 0);
-          ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, ot[d], 0, 0, 0);
+          for (int e = 0; e < 4; ++e) { vh[e] = h0[e]; vh[4 + e] = h1[e]; }
+          if constexpr (ONE) {
+            ot[d] = mfma32x32x16_h<true>(vh, ph, ot[d]);
+          } else {
+            const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(Vlo + o0));
+            const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(Vlo + o1));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { vl[e] = l0[e]; vl[4 + e] = l1[e]; }
+            ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, ot[d], 0, 0, 0);
+            ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, ot[d], 0, 0, 0);
+            ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, ot[d], 0, 0, 0);
+          }
         }
       }
   }
@@ -678,7 +707,11 @@ int attention(const AttnP& p, hipStream_t st) {
     EC_REQUIRE(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldv % 4 == 0 && p.ldo % 4 == 0, -1, "attention: strides must be multiples of 4");
     if (p.kv16) {
       EC_REQUIRE(p.hd == 64, -1, "attention: fp16 K / V only for head dim 64 (the token -> image cross attention)");
-      hipLaunchKernelGGL((attn_split_kernel<64, true>), grid, dim3(256), 0, st, p);
+      if (p.one) hipLaunchKernelGGL((attn_split_kernel<64, true, true>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((attn_split_kernel<64, true>), grid, dim3(256), 0, st, p);
+    } else if (p.one) {
+      if (p.hd == 64) hipLaunchKernelGGL((attn_split_kernel<64, false, true>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((attn_split_kernel<32, false, true>), grid, dim3(256), 0, st, p);
     } else if (p.hd == 64) hipLaunchKernelGGL((attn_split_kernel<64>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((attn_split_kernel<32>), grid, dim3(256), 0, st, p);
     EC_LAUNCH_CHECK();

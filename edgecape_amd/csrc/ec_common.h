@@ -231,6 +231,7 @@ struct AttnP {
   int bf16 = 0;                                 // Q/K/V/O are 16-bit
   int f16 = 0;                                  // ... in IEEE fp16 instead of bf16
   int split = 0;                                // fp32 data, bf16x3 MFMAs (head throughput mode)
+  int one = 0;                                  // split mode only: ONE fp16 MFMA per product instead of three bf16 ones (mixed head, see ec_attn.hip)
   int kv16 = 0;                                 // split mode only: K and V are IEEE fp16 (ldk / ldv / sK / sV in fp16 elements), Q and O fp32
 };
 int attention(const AttnP& p, hipStream_t st);

@@ -572,6 +572,12 @@ struct LayerIO {
 // fp16-rounded operands, so the extra rounding is of the size of the error they already carry, the projection writes half the bytes
 // (it is bound by its output: the decoder's stacked K|V were 127 MB per step and the most expensive single kernel of the head,
 // 171 us of step time) and the cross attention reads half (attn_split_kernel<64, true>).  EC_KV16=0: fp32 as before.
+// The attentions of the single-pass fp16 layers (head_precision = EC_MIXED: skeleton head, decoder layers) with ONE fp16 MFMA per product
+// instead of three bf16 ones (AttnP::one).  The encoder's self-attention, on the proposal argmax's path, stays bf16x3.  EC_ATTN_ONE=0: off.
+static bool attn_one(const ec_model* m, const DecLayer& L) {
+  static const bool off = getenv("EC_ATTN_ONE") && atoi(getenv("EC_ATTN_ONE")) == 0;
+  return !off && m->head_mixed && m->head_split && L.sa_in.h1;
+}
 static bool kv16_on(const ec_model* m, const Lin& kv) {
   static const bool off = getenv("EC_KV16") && atoi(getenv("EC_KV16")) == 0;
   return !off && m->head_mixed && m->head_split && kv.h1 && m->E / m->cfg.nhead == 64;
@@ -629,6 +635,7 @@ static int image_update(ec_model* m, const DecLayer& L, const float* x, long ldx
   a.sQ = (long)HW * E; a.sK = a.sV = (long)K * 2 * E; a.sO = (long)HW * E;
   a.B = nb; a.H = nh; a.Lq = HW; a.Lk = K; a.hd = E / nh;
   a.split = m->head_split ? 1 : 0;   // head throughput mode: bf16x3 MFMAs
+  a.one = attn_one(m, L) ? 1 : 0;
   RUN(attention(a, st));
   RUN(linear(attimg, E, false, L.i2t_fold, tmpimg, d, false, Mi, ACT_NONE, st, nullptr, mem, d));
   LnP q;
@@ -674,7 +681,7 @@ static bool layer_chains(const ec_model* m, const DecLayer& L) {
 }
 
 // Self attention over the K keypoint tokens of every sample (hd = d/nh = 32; encoder_decoder.py:596-603): qkv [nb*K, 3d] -> att [nb*K, d].
-static int run_self_attention(ec_model* m, const LayerIO& io, const float* qkv, float* att, hipStream_t st) {
+static int run_self_attention(ec_model* m, const LayerIO& io, const float* qkv, float* att, hipStream_t st, bool one = false) {
   const int d = m->d, K = m->K, nh = m->cfg.nhead;
   AttnP a;
   a.Q = qkv; a.K = qkv + d; a.V = qkv + 2 * d; a.O = att;
@@ -684,6 +691,7 @@ static int run_self_attention(ec_model* m, const LayerIO& io, const float* qkv, 
   a.bias = io.bias;
   a.B = io.nb; a.H = nh; a.Lq = K; a.Lk = K; a.hd = d / nh;
   a.split = m->head_split ? 1 : 0;   // head throughput mode: bf16x3 MFMAs
+  a.one = one ? 1 : 0;
   return attention(a, st);
 }
 
@@ -706,7 +714,7 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
   if (!io.sa_done) {
     if (!io.qkv_ready) RUN(linear(io.x, io.ldx, false, L.sa_in, qkv, 3 * d, false, Mk, ACT_NONE, st));
     if (io.wait_sa) EC_HIP(hipStreamWaitEvent(st, io.wait_sa, 0));
-    RUN(run_self_attention(m, io, qkv, att, st));
+    RUN(run_self_attention(m, io, qkv, att, st, attn_one(m, L)));
   }
   if (chain) {
     // x = norm1(x + out_proj(att)); qc = q_proj([x | qpe]) - one launch (encoder_decoder.py:596-611)
@@ -753,6 +761,7 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
     a.sQ = (long)K * E; a.sK = a.sV = (io.kv_pre && io.s_kv_pre) ? io.s_kv_pre : (long)HW * ldkv; a.sO = (long)K * E;
     a.B = io.nb; a.H = nh; a.Lq = K; a.Lk = HW; a.hd = E / nh;
     a.split = m->head_split ? 1 : 0;   // head throughput mode: bf16x3 MFMAs
+    a.one = attn_one(m, L) ? 1 : 0;
     RUN(attention(a, st));
   }
   // ---- GCN feed-forward (encoder_decoder.py:508-524,634-637): y = conv1d(x) -> [.., 2F];
@@ -1122,6 +1131,8 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     a.kmask = ss.kmask; a.mask_start = HW; a.mask_len = K; a.mask_mod = 0;
     a.B = bs; a.H = nh; a.Lq = L; a.Lk = L; a.hd = d / nh;
     a.split = m->head_split ? 1 : 0;   // head throughput mode: bf16x3 MFMAs
+    // (round 3, measured and not adopted: this attention in single-pass fp16 like the skeleton head's and the decoder's - +0.6 % pairs/s,
+    //  23 instead of 22 argmax flips of 20 293 on the conformance set; it sits on the proposal argmax's path and stays bf16x3)
     RUN(attention(a, st));
     // The row-wise rest of the layer (encoder_decoder.py:470-483) as ONE row chain: x1 = norm1(x + out_proj(att)); y = relu(linear1(x1));
     // x = norm2(x1 + linear2(y)) (+ pos -> the next layer's in-proj).  x1 stays in registers (keep) and LDS, y [32, F] in LDS; att is
@@ -1279,7 +1290,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     if (sa_prelaunched) {
       LayerIO nio = io;
       nio.bias = ss.dec_bias + (size_t)(li + 1) * bs * nh * K * K;
-      RUN(run_self_attention(m, nio, m->d_qkv, m->d_att, ax));
+      RUN(run_self_attention(m, nio, m->d_qkv, m->d_att, ax, attn_one(m, m->dec[li + 1])));
       EC_HIP(hipEventRecord(ev_sa, ax));
     }
     if (kpt_chain) {

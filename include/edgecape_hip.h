@@ -57,9 +57,10 @@ enum ec_precision {
                      keeps output_kpts inside the 1e-3 tolerance at bf16 speed (backbone only) */
   EC_MIXED = 4    /* head only: EC_BF16X3 everywhere the proposal generator's argmax depends on (input projections, support pooling,
                      encoder, proposal generator - encoder_decoder.py:91-110 is the path's one discontinuity) and in the small MLPs;
-                     single-pass fp16 MFMAs (fp32 data rounded to fp16 operands, fp32 accumulate) in the Linear layers of the skeleton
-                     head (skeleton.py:58-161) and of the decoder layers (encoder_decoder.py:584-651), which only move the output
-                     continuously: max |d kpt| 1.6e-4 vs 1.55e-4 without (oracle/head_precision_study.py, 32 pairs) */
+                     single-pass fp16 MFMAs (fp32 data rounded to fp16 operands, fp32 accumulate) in the Linear layers AND the
+                     attentions of the skeleton head (skeleton.py:58-161) and of the decoder layers (encoder_decoder.py:584-651),
+                     whose image K|V are also stored as fp16 - all of which only move the output continuously: max |d kpt| on
+                     flip-free samples 2.8e-4 over 512 pairs, the same as with a bf16x3 head (profiles/r03_conformance_*.json) */
 };
 enum ec_dtype { EC_DT_F32 = 0, EC_DT_F16 = 1, EC_DT_BF16 = 2, EC_DT_F64 = 3 };
 enum ec_layout { EC_LAYOUT_TOKENS = 0, EC_LAYOUT_NCHW = 1 };
