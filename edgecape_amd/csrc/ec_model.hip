@@ -122,6 +122,7 @@ struct ec_model {
 
   // backbone
   Lin patch;
+  const bf16_t* patch_w16x3 = nullptr;   // fp16 backbone: [C, 3 Kp] = [W_hi | W_hi | W_lo] of the patch embedding (split precision, see run_backbone)
   const float *cls = nullptr, *pos = nullptr;
   Norm bnorm;
   std::vector<BBlock> blocks;
@@ -458,17 +459,23 @@ static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_
   const int nh = m->cfg.num_heads;
   const int n = n_src * n_each;
   const long M = (long)n * T;
+  // fp16 backbone: the patch embedding in SPLIT precision (round 3).  The image patches and the patch weights rounded to fp16 carry 38 %
+  // of the error variance of the backbone's features (oracle/precision_sites.py) - every later block inherits it through the residual
+  // stream - for 0.5 % of the FLOPs: with [hi | lo | hi] patches against [W_hi | W_hi | W_lo] weights the same 8-phase GEMM, K = 3 Kp,
+  // computes the products to ~2^-22.  EC_PATCH_X3=0: single fp16 operands as before.
+  const bool px3 = m->patch_w16x3 != nullptr;
+  const int Kpe = px3 ? 3 * m->Kp : m->Kp;
   for (int s = 0; s < n_src; ++s)
-    RUN(im2col14(imgs[s], (char*)m->bb_h + (size_t)s * n_each * T * m->Kp * (h16 ? 2 : 4), hfmt, n_each, H, g, m->Kp, st));
+    RUN(im2col14(imgs[s], (char*)m->bb_h + (size_t)s * n_each * T * Kpe * (h16 ? 2 : 4), px3 ? 3 : hfmt, n_each, H, g, m->Kp, st));
   {  // patch embedding: ONE GEMM over all n*T token rows (the zero cls rows produce bias + pos[0], overwritten below);
      // epilogue adds the conv bias and the positional table row m % T
     GemmP p;
-    p.A = m->bb_h; p.lda = m->Kp; p.ab_bf16 = h16; p.h_f16 = m->bbf16;
+    p.A = m->bb_h; p.lda = Kpe; p.ab_bf16 = h16; p.h_f16 = m->bbf16;
     p.split = m->bb_split ? 1 : 0;
-    p.B = h16 ? (const void*)m->patch.w16 : m->patch.wsel(m->bb_split); p.ldb = m->Kp;
+    p.B = px3 ? (const void*)m->patch_w16x3 : h16 ? (const void*)m->patch.w16 : m->patch.wsel(m->bb_split); p.ldb = Kpe;
     p.C = m->bb_x; p.ldc = C;
     p.bias = m->patch.b; p.table = m->pos; p.ldt = C; p.period = T;
-    p.M = (int)M; p.N = C; p.K = m->Kp;
+    p.M = (int)M; p.N = C; p.K = Kpe;
     RUN(gemm_nt(p, st));
   }
   RUN(set_cls_rows(m->bb_x, C, m->cls, m->pos, n, T, C, st));
@@ -1590,6 +1597,21 @@ int ec_finalize(ec_handle m) {
     m->patch.N = C; m->patch.K = m->Kp; m->patch.b = pb->dev;
     if ((rc = upload(m, Wp, &m->patch.w))) return rc;
     if (m->bb16 && (rc = upload16(m, Wp, &m->patch.w16))) return rc;
+    if (m->bbf16 && !(getenv("EC_PATCH_X3") && atoi(getenv("EC_PATCH_X3")) == 0)) {
+      std::vector<bf16_t> w3((size_t)C * 3 * m->Kp);
+      for (int n = 0; n < C; ++n)
+        for (int k = 0; k < m->Kp; ++k) {
+          const float w = Wp[(size_t)n * m->Kp + k];
+          const bf16_t h = f2half_host(w);
+          const bf16_t l = f2half_host(w - half2f_host(h));
+          bf16_t* row = &w3[(size_t)n * 3 * m->Kp];
+          row[k] = h; row[m->Kp + k] = h; row[2 * m->Kp + k] = l;
+        }
+      bf16_t* p3 = nullptr;
+      if ((rc = dalloc(m, &p3, w3.size()))) return rc;
+      EC_HIP(hipMemcpy(p3, w3.data(), w3.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+      m->patch_w16x3 = p3;
+    }
     if (m->bb_split && (rc = upload_split(m, Wp.data(), C, m->Kp, &m->patch.ws))) return rc;
     GET(cls, bp + "cls_token"); GET(pos, "@pos_table");
     m->cls = cls->dev; m->pos = pos->dev;
@@ -1706,7 +1728,7 @@ int ec_finalize(ec_handle m) {
   if ((rc = dmalloc(m, &m->bb_att, MT * C * es))) return rc;
   if (m->bb16 && (rc = dmalloc(m, &m->bb_y, MT * C * 2))) return rc;
   if (m->bb16 && (rc = dmalloc(m, &m->bb_y2, MT * C * 2))) return rc;
-  if ((rc = dmalloc(m, &m->bb_h, std::max(MT * 4 * C, MT * m->Kp) * es))) return rc;
+  if ((rc = dmalloc(m, &m->bb_h, std::max(MT * 4 * C, MT * 3 * m->Kp) * es))) return rc;
   if ((rc = dalloc(m, &m->feat, (size_t)n * HW * C))) return rc;
   if ((rc = dalloc(m, &m->feat_nchw_tmp, (size_t)n * HW * C))) return rc;
   if ((rc = dalloc(m, &m->d_off, (size_t)bs + 1))) return rc;

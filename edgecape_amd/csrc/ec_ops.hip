@@ -142,24 +142,55 @@ __global__ void transpose_pad_bf16_kernel(const float* src, bf16_t* dst, int L, 
 
 // im2col for Conv2d(3, C, k=14, s=14) (DINOv2 PatchEmbed): patches[(n*g+py)*g+px][c*196+ky*14+kx],
 // row length Kp >= 588 (zero padded) so the GEMM K is a multiple of 128 bytes.
-template <int OUT>   // 0 fp32, 1 bf16, 2 fp16
-__global__ void im2col14_kernel(const float* img, void* out, int H, int g, int Kp) {
+template <int OUT>   // 0 fp32, 1 bf16, 2 fp16, 3 fp16 split [hi | lo | hi]
+__global__ __launch_bounds__(256) void im2col14_kernel(const float* img, void* out, int H, int g, int Kp) {
   // output rows are TOKEN rows: image n owns rows n*(g*g+1) .. ; row 0 of each image (the cls token) is zero-filled so the
-  // patch embedding is ONE GEMM over M = n_img * T contiguous rows (its cls rows are overwritten by set_cls_rows)
+  // patch embedding is ONE GEMM over M = n_img * T contiguous rows (its cls rows are overwritten by set_cls_rows).
+  // One workgroup per row: the 588 pixels of the patch go through LDS and leave as 16-byte stores (Kp % 8 == 0, Kp <= 1024).
+  __shared__ __attribute__((aligned(16))) float px[1024];
   const int T = g * g + 1;
   const int n = blockIdx.x / T, tok = blockIdx.x % T;
   const long orow = blockIdx.x;
   const int pp = tok - 1;
-  const int py = pp / g, px = pp % g;
+  const int py = pp / g, pxx = pp % g;
   const float* src = img + (long)n * 3 * H * H;
   for (int k = threadIdx.x; k < Kp; k += blockDim.x) {
     float v = 0.f;
     if (tok > 0 && k < 588) {
       const int c = k / 196, r = k % 196, ky = r / 14, kx = r % 14;
-      v = src[((long)c * H + (py * 14 + ky)) * H + px * 14 + kx];
+      v = src[((long)c * H + (py * 14 + ky)) * H + pxx * 14 + kx];
     }
-    if (OUT != 0) ((bf16_t*)out)[orow * Kp + k] = f2h<OUT == 2>(v);
-    else ((float*)out)[orow * Kp + k] = v;
+    px[k] = v;
+  }
+  __syncthreads();
+  if constexpr (OUT == 0) {
+    for (int i = threadIdx.x; i < Kp / 4; i += blockDim.x) *(f32x4*)((float*)out + orow * Kp + i * 4) = *(const f32x4*)(px + i * 4);
+  } else if constexpr (OUT == 3) {
+    // split-precision patch embedding (fp16 backbone): the row is [hi | lo | hi], hi = fp16(v), lo = fp16(v - hi); against the weight
+    // rows [W_hi | W_hi | W_lo] one K = 3 Kp GEMM adds hi*W_hi + lo*W_hi + hi*W_lo - the product to ~2^-22
+    const int c8n = Kp / 8;
+    for (int i = threadIdx.x; i < 3 * c8n; i += blockDim.x) {
+      const int plane = i / c8n, c8 = i - plane * c8n;
+      const f32x4 a = *(const f32x4*)(px + c8 * 8), b = *(const f32x4*)(px + c8 * 8 + 4);
+      u32x2_t h0 = pack4_h<true>(a), h1 = pack4_h<true>(b);
+      if (plane == 1) {
+        f32x4 ra, rb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ra[e] = a[e] - h2f<true>((bf16_t)((e & 1) ? (h0[e >> 1] >> 16) : (h0[e >> 1] & 0xffffu)));
+          rb[e] = b[e] - h2f<true>((bf16_t)((e & 1) ? (h1[e >> 1] >> 16) : (h1[e >> 1] & 0xffffu)));
+        }
+        h0 = pack4_h<true>(ra); h1 = pack4_h<true>(rb);
+      }
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+      *(u32x4_*)((bf16_t*)out + orow * 3 * Kp + plane * Kp + c8 * 8) = u32x4_{h0[0], h0[1], h1[0], h1[1]};
+    }
+  } else {
+    for (int i = threadIdx.x; i < Kp / 8; i += blockDim.x) {
+      const u32x2_t h0 = pack4_h<OUT == 2>(*(const f32x4*)(px + i * 8)), h1 = pack4_h<OUT == 2>(*(const f32x4*)(px + i * 8 + 4));
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+      *(u32x4_*)((bf16_t*)out + orow * Kp + i * 8) = u32x4_{h0[0], h0[1], h1[0], h1[1]};
+    }
   }
 }
 __global__ void set_cls_kernel(float* x, long ldx, const float* cls, const float* pos0, int T, int C) {
@@ -853,7 +884,9 @@ int transpose_pad_bf16(const float* src, bf16_t* dst, int B, int L, int E, int L
 }
 
 int im2col14(const float* img, void* patches, int out_bf16, int n_img, int H, int g, int Kp, hipStream_t st) {
-  if (out_bf16 == 2) hipLaunchKernelGGL(im2col14_kernel<2>, dim3(n_img * (g * g + 1)), dim3(256), 0, st, img, patches, H, g, Kp);
+  EC_REQUIRE(Kp % 8 == 0 && Kp <= 1024, -1, "im2col14: padded row length must be a multiple of 8, at most 1024");
+  if (out_bf16 == 3) hipLaunchKernelGGL(im2col14_kernel<3>, dim3(n_img * (g * g + 1)), dim3(256), 0, st, img, patches, H, g, Kp);
+  else if (out_bf16 == 2) hipLaunchKernelGGL(im2col14_kernel<2>, dim3(n_img * (g * g + 1)), dim3(256), 0, st, img, patches, H, g, Kp);
   else if (out_bf16) hipLaunchKernelGGL(im2col14_kernel<1>, dim3(n_img * (g * g + 1)), dim3(256), 0, st, img, patches, H, g, Kp);
   else hipLaunchKernelGGL(im2col14_kernel<0>, dim3(n_img * (g * g + 1)), dim3(256), 0, st, img, patches, H, g, Kp);
   EC_LAUNCH_CHECK();
