@@ -91,12 +91,12 @@ def main():
         mask = mask * tw
     ms = dev(mask.reshape(bs, -1))
 
-    def timed_run(precision, steps, warmup, profile, pipelined=True):
+    def timed_run(precision, steps, warmup, profile, pipelined=True, head_precision=None):
         """`warmup` + `steps` passes of the hot path in `precision`; returns (engine, outputs, seconds (max over ranks), mean QKV launch ms).
         pipelined: ec_forward_pipelined with two alternating output sets - step i's decoder phase runs beside step i+1's backbone -
         and an ec_pipeline_flush inside the timed region, so that all the work of the K steps is charged to them."""
         eng = HipEngine(sd, arch=arch, image_size=H, max_batch=bs, max_shots=S, backbone_precision=precision,
-                        head_precision=args.head_precision)
+                        head_precision=head_precision or args.head_precision)
         edges, off = eng._edges([m["sample_skeleton"][0] for m in batch["img_metas"]], bs)
         sets = [eng._outputs(bs), eng._outputs(bs)]
         count = [0]
@@ -167,12 +167,10 @@ def main():
             "roofline": {"bound": "mfma", "kernel": f"backbone QKV GEMM M={Mq} K={Kq} N={Nq} ({args.precision})",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "flops_per_launch": qkv_flops, "avg_launch_ms": round(qkv_ms, 5), "launches_timed": launches_timed,
-                         "measured_in": ("the timed ec_forward_pipelined steps: the sampled launches share the chip with the previous step's head"
-                                         if pipelined else "the timed ec_forward steps: nothing else on the chip"),
+                         # achieved / frac / avg_launch_ms belong to the timed region that produced `value` (this run's K steps)
+                         "measured_in": ("the timed region of `value`: the K ec_forward_pipelined steps - the sampled launches share the chip with "
+                                         "the previous step's head" if pipelined else "the timed region of `value`: the K ec_forward steps - nothing else on the chip"),
                          "launch_sampling": "one QKV launch per step bracketed by HIP events on the launch stream, block index = step % depth",
-                         # context, not the judged peak: what a pure register-operand MFMA loop sustains on this chip with random
-                         # (not zero) fp16 operands - the power-management ceiling of real data (tools/mfma_power_probe.hip)
-                         "mfma_sustained_random_operands_tflops": [1710, 1951], "mfma_probe_source": "profiles/r03_mfma_power_probe.txt",
                          **pmc_traffic(args, bs, S, H, arch, build.source_hash())},
             "pck_vs_synthetic_gt": {k: round(v, 4) for k, v in pck.items()},
             # every switch that changes what the library runs (README "Runtime switches"): none set = the shipped defaults
@@ -195,17 +193,34 @@ def main():
         result["unpipelined"] = {"value": round(bs * n_u / dt_u, 2), "unit": "images/s", "ms_per_step": round(dt_u / n_u * 1e3, 3),
                                  "qkv_launch_ms": round(qkv_u, 5), "qkv_frac": round(qkv_flops / (qkv_u * 1e-3) / 1e12 / peak, 4) if qkv_u > 0 else None,
                                  "note": "ec_forward: no overlap between steps; the QKV launches are not disturbed by a concurrent head"}
+        # the reference's contract (forward_test returns complete results): the same steps through ec_forward
+        result["value_reference_contract"] = result["unpipelined"]["value"]
         if qkv_u > 0:
-            # The roofline of a KERNEL: its launches with the chip to themselves (a second timed region of the same process, HIP events on
-            # the launch stream as above; rocprofv3's kernel trace serialises kernels and agrees with THIS duration).  The figure sampled
-            # inside the pipelined steps - launch duration including the time shared with the previous step's head - stays beside it.
-            r = result["roofline"]
-            r["in_pipelined_steps"] = {"achieved": r["achieved"], "frac": r["frac"], "avg_launch_ms": r["avg_launch_ms"],
-                                       "launches_timed": r["launches_timed"], "note": r["measured_in"]}
+            # The same kernel with the chip to itself (a second timed region of the same process through ec_forward, HIP events on the launch
+            # stream as above; rocprofv3's kernel trace serialises kernels and agrees with THIS duration): a property of the KERNEL, kept
+            # beside - not instead of - the figure of the timed region that produced `value`.
             ach_u = qkv_flops / (qkv_u * 1e-3) / 1e12
-            r.update({"achieved": round(ach_u, 2), "frac": round(ach_u / peak, 4), "avg_launch_ms": round(qkv_u, 5),
-                      "launches_timed": timed_run.launches,
-                      "measured_in": f"{n_u} timed ec_forward steps of this process (nothing else on the chip), one sampled launch per step"})
+            result["roofline"]["kernel_isolated"] = {
+                "achieved": round(ach_u, 2), "frac": round(ach_u / peak, 4), "avg_launch_ms": round(qkv_u, 5), "launches_timed": timed_run.launches,
+                "measured_in": f"{n_u} timed ec_forward steps of this process (nothing else on the chip), one sampled launch per step"}
+    if world == 1 and not args.no_alt and (args.precision, args.head_precision) != ("bf16x3", "bf16x3"):
+        # the tolerance-conforming fast mode (every MFMA operand split hi + lo bf16, three MFMAs per product: fp32-class, meets the 1e-3
+        # coordinate tolerance on every keypoint by construction - tests/test_gpu_precision_modes.py::test_parity_mode_bf16x3), same
+        # process, same box, same API as the headline
+        del eng, outputs
+        torch.cuda.empty_cache()
+        n_c = max(5, args.steps // 2)
+        eng, outputs, dt_c, qkv_c = timed_run("bf16x3", n_c, args.warmup, True, pipelined, head_precision="bf16x3")
+        ach_c = qkv_flops / (qkv_c * 1e-3) / 1e12 if qkv_c > 0 else 0.0
+        conf_c = conformance_record(args, bs, S, H, arch, "bf16x3", "bf16x3")
+        result["conforming_mode"] = {
+            "precision": "bf16x3 backbone / bf16x3 head", "value": round(bs * n_c / dt_c, 2), "unit": "images/s", "ms_per_step": round(dt_c / n_c * 1e3, 3),
+            "pipelined": pipelined,
+            "roofline": {"bound": "mfma", "achieved": round(ach_c, 2), "peak": round(PEAK_TFLOPS["bf16x3"], 1), "unit": "TFLOP/s",
+                         "frac": round(ach_c / PEAK_TFLOPS["bf16x3"], 4), "avg_launch_ms": round(qkv_c, 5), "launches_timed": timed_run.launches,
+                         "peak_note": "2500 / 3: three bf16 MFMAs per product"},
+            "argmax_flips": conf_c["argmax_flips"] if conf_c else None, "conformance_at_scale": conf_c,
+            "note": "meets the 1e-3 coordinate tolerance on every keypoint; the headline precision meets it on all but the measured flip rate"}
     if world == 1 and not args.no_alt and args.precision != "bf16":
         # the same step with bf16 operands (north_star's wording): same kernels and rate, 8x coarser rounding - measured beside the
         # headline so both precisions come from one process on one box; it does NOT meet the 1e-3 gate (test_bf16_mode_cfg2_bounded)
@@ -222,19 +237,31 @@ def main():
     return result
 
 
-def conformance_record(args, bs, S, H, arch):
-    """The MEASURED conformance of this precision mode at scale (tools/conformance.py on the GPU box: 256 pairs x 2 weight seeds
-    against the CPU oracle; committed under profiles/): argmax flips and the share of keypoints outside 1e-3 are rates of the
-    mode, not of the 32-pair `parity_sample` of one run.  Only reported for the configuration it was measured on (cfg2)."""
-    path = os.path.join(ROOT, "profiles", f"r03_conformance_{args.precision}_{args.head_precision}.json")
-    if (bs, S, H, arch) != (32, 1, 256, "dinov2_vitb14") or not os.path.exists(path):
+CONF_CFG = {(32, 1, 224, "dinov2_vits14"): "cfg1_", (32, 1, 256, "dinov2_vitb14"): "", (16, 5, 256, "dinov2_vitb14"): "cfg4_", (8, 1, 384, "dinov2_vitl14"): "cfg5_"}
+
+
+def conformance_record(args, bs, S, H, arch, precision=None, head_precision=None):
+    """The MEASURED conformance of a precision mode at scale (tools/conformance.py on the GPU box: >= 128 disjoint pairs x 2 weight seeds
+    against the CPU oracle; committed under profiles/): argmax flips and the share of keypoints outside 1e-3 are rates of the mode,
+    not of the 32-pair `parity_sample` of one run.  The newest record (r04 before r03) of the benched configuration, if any."""
+    import glob
+    precision, head_precision = precision or args.precision, head_precision or args.head_precision
+    if (bs, S, H, arch) not in CONF_CFG:
         return None
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_conformance_{CONF_CFG[(bs, S, H, arch)]}{precision}_{head_precision}.json")))
+    if not found:
+        return None
+    path = found[-1]
     d = json.load(open(path))
     p = d["pooled"]
-    return {"pairs": p["pairs"], "weight_seeds": [s_["weight_seed"] for s_ in d["per_weight_seed"]], "valid_keypoints": p["n_valid"],
-            "argmax_flips": p["flips"], "flip_rate": p["flip_frac"], "max_abs_kpt_err": p["max_all"], "p99_abs_kpt_err": p["p99"],
-            "frac_gt_1e-3": p["frac_gt_1e3"], "pck@0.2_hip_vs_oracle_pred": p["pck_vs_oracle"], "tolerance": 1e-3,
-            "source": os.path.relpath(path, ROOT)}
+    rec = {"pairs": p["pairs"], "weight_seeds": [s_["weight_seed"] for s_ in d["per_weight_seed"]], "valid_keypoints": p["n_valid"],
+           "argmax_flips": p["flips"], "flip_rate": p["flip_frac"], "max_abs_kpt_err": p["max_all"], "max_abs_kpt_err_flip_free": p["max_clean"],
+           "p99_abs_kpt_err": p["p99"], "frac_gt_1e-3": p["frac_gt_1e3"], "pck@0.2_hip_vs_oracle_pred": p["pck_vs_oracle"], "tolerance": 1e-3,
+           "source": os.path.relpath(path, ROOT)}
+    g = p.get("near_tie_guard")
+    if g:
+        rec["near_tie_guard_2x_max_map_err"] = g["guards"]["2x_max"]
+    return rec
 
 
 def pmc_path(bs, S, H, arch, precision):

@@ -98,6 +98,11 @@ def timed_steps(step, steps, warmup, collective=None, before_timed=None):
     timers) runs between the warm-up and the first barrier; returns the MAX over ranks of the wall time."""
     for _ in range(warmup):
         step()
+    # One all-reduce and one barrier BEFORE the clock starts, whatever the arguments: RCCL creates communicators / channels lazily on
+    # the first collective of a kind, and that one-off cost (hundreds of ms on an 8-GPU node) must not land inside the timed region,
+    # where `collective` and the closing barrier run.  (init_distributed also passes device_id, which makes the process group
+    # create its communicator eagerly.)
+    max_over_ranks(0.0)
     if before_timed is not None:
         barrier()
         before_timed()

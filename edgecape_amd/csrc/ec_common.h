@@ -67,13 +67,18 @@ template <bool F16> __device__ __forceinline__ f32x16 mfma32x32x16_h(bf16x8 a, b
   if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// fp16 saturation at +-65504 that keeps NaN: v_med3_f32 alone returns min3 = -65504 for a NaN input (its NaN rule: the minimum of the
+// operands, and v_min ignores quiet NaNs), which would turn a NaN activation into a finite value and hide it from the caller
+// (round 3 did).  v * 0 is NaN exactly when v is NaN or +-inf and (+-)0 otherwise, so one more full-rate v_fma_f32 puts the NaN back:
+// finite v -> clamp(v), NaN -> NaN, an fp32 +-inf (an accumulator overflow: nothing finite to saturate to) -> NaN as well.
+__device__ __forceinline__ float sat_h16(float v) { return fmaf(v, 0.f, __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f)); }
 // 4 floats -> 4 packed 16-bit values (round to nearest even): 2 x v_cvt_pk_{bf16,f16}_f32
-// (fp16: saturated at +-65504 first - one v_med3_f32 per value - so an activation outlier of a real checkpoint becomes the largest
-// finite half instead of inf -> NaN in the next softmax / LayerNorm; NaN inputs stay NaN)
+// (fp16: saturated at +-65504 first - sat_h16 - so an activation outlier of a real checkpoint becomes the largest finite half
+// instead of inf -> NaN in the next softmax / LayerNorm; NaN inputs stay NaN)
 template <bool F16> __device__ __forceinline__ u32x2_t pack4_h(f32x4 v) {
   if constexpr (F16) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+    for (int e = 0; e < 4; ++e) v[e] = sat_h16(v[e]);
     return __builtin_bit_cast(u32x2_t, __builtin_convertvector(v, f16x4));
   }
   else {
@@ -82,7 +87,7 @@ template <bool F16> __device__ __forceinline__ u32x2_t pack4_h(f32x4 v) {
   }
 }
 template <bool F16> __device__ __forceinline__ bf16_t f2h(float f) {
-  if constexpr (F16) return __builtin_bit_cast(bf16_t, (_Float16)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f));
+  if constexpr (F16) return __builtin_bit_cast(bf16_t, (_Float16)sat_h16(f));
   else return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 template <bool F16> __device__ __forceinline__ float h2f(bf16_t h) {

@@ -55,6 +55,8 @@ constexpr int G8_BIAS = G8_STAGE + 8 * 2048;    // 2 tile parities x 8 waves x 2
 constexpr int G8_GAMMA = G8_BIAS + 2 * 8 * 256;  // same for the LayerScale vector
 constexpr int G8_SCHED = G8_GAMMA + 2 * 8 * 256;  // two ints: the dynamic schedule's hand-over slots (tile parity)
 constexpr int G8_LDS = G8_SCHED + 64;            // 152 KiB + 64 B
+constexpr int G8_TRACE = G8_LDS;                 // lab build, LAB & 512: 2 wave groups x 32 s_memtime stamps (64-bit) behind the product's LDS
+constexpr int G8_LDS_LAB = G8_TRACE + 512;
 constexpr int G8_AHEAD = 5;               // half-tiles the load stream runs ahead
 
 #define G8_SB() __builtin_amdgcn_sched_barrier(0)
@@ -270,7 +272,11 @@ template <int N> __device__ __forceinline__ void g8_wait_vm() { asm volatile("s_
 
 // LAB (0 in the shipped library; other values are only instantiated under -DEC_G8_LAB by tools/g8_lab.py): ablations for
 // locating the bottleneck - 1 no global stores, 2 every tile loads tile 0's operands (L2-resident), 4 no LDS-DMA in the steady
-// state, 8 no MFMAs, 32 no epilogue at all, 64 the load stream is drained at the tile seam (the round-1 seam, for A/B).
+// state, 8 no MFMAs, 32 no epilogue at all, 64 the load stream is drained at the tile seam (the round-1 seam, for A/B),
+// 512 (round 4) s_memtime stamps of one wave per wave group at the tile milestones (kernel start | per tile: K loop start, K loop
+// end, epilogue end | kernel end), kept in LDS and dumped to p.aux[blockIdx][64] at the end: the per-tile cycle ledger of DESIGN.md;
+// 1024 (round 4) every tile STORES to the rows of tile row 0 (the output of a launch aliases onto 256 x N: dirty lines stay in the
+// L2s, nothing is written back in the burst): what the seam costs without the fabric write-back.
 //
 // Tile seam of the 16-bit output kinds (KIND != GENERIC): the epilogue runs at the END of the tile, both wave groups at once
 // (all four SIMDs convert and store), and NOTHING is drained: the bias / LayerScale slices come from LDS (one small LDS-DMA per
@@ -298,6 +304,12 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
+  auto stamp = [&](int idx) {           // lab only (LAB & 512): wave 0 / wave 4, lane 0 -> LDS
+    if constexpr (LAB & 512) {
+      if ((wave & 3) == 0 && g8_lane_now() == 0) ((unsigned long long*)(smem + G8_TRACE))[wr * 32 + idx] = __builtin_amdgcn_s_memtime();
+    }
+  };
+  stamp(0);
 
   const int ntm = (p.M + 255) >> 8, ntn = (p.N + 255) >> 8;
   const int ntiles = ntm * ntn;
@@ -490,6 +502,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   int it = 0;                                          // tile counter of this workgroup (bias parity)
   for (int t = t_first; t < t_end; t = t_nxt, t_nxt = t_nn, t_nn = dyn ? t_end : t_nxt + nslot, ++it) {
     const int m0 = (t / ntn) << 8, n0 = (t % ntn) << 8;
+    if (it < 9) stamp(1 + 3 * it);
     for (int kt2 = 0; kt2 < nk; kt2 += 2) {
 #pragma unroll
       for (int buf = 0; buf < 2; ++buf) {
@@ -613,6 +626,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
       }
     }
     // ---- epilogue at the end of the tile.  Both groups run it concurrently: group 0 passes the tile's last barrier first.
+    if (it < 9) stamp(2 + 3 * it);
     if (wr == 0) G8_BAR();
     if constexpr (KIND == G8_GENERIC) {
       g8_epilogue_generic<F16>(p, acc, m0, n0, wr, wc, lane);
@@ -622,12 +636,19 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     } else if constexpr (FAST) {
       if constexpr (!NODRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // lab only: the round-1 seam
-      pieces(0, m0, n0, it & 1); pieces(2, m0, n0, it & 1); pieces(4, m0, n0, it & 1); pieces(6, m0, n0, it & 1);
+      const int m0s = (LAB & 1024) ? 0 : m0;
+      pieces(0, m0s, n0, it & 1); pieces(2, m0s, n0, it & 1); pieces(4, m0s, n0, it & 1); pieces(6, m0s, n0, it & 1);
     }
+    if (it < 9) stamp(3 + 3 * it);
     if (wr == 1) G8_BAR();
   }
   if (wr == 0) G8_BAR();   // balances group 1's extra barrier at the start
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stream's tail pieces must land before the LDS is released
+  if constexpr (LAB & 512) {
+    stamp(31);
+    __syncthreads();
+    if (tid < 64 && p.aux) ((unsigned long long*)p.aux)[(long)blockIdx.x * 64 + tid] = ((const unsigned long long*)(smem + G8_TRACE))[tid];
+  }
   if (dyn && wave == 0) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(left_s));   // (requested at least ten K-tiles ago)
     sched_rearm(left_s);
@@ -727,6 +748,9 @@ extern "C" int ec_lab_gemm8(const void* A, const void* W, const float* bias, voi
     case 65: k = gemm8_bf16_kernel<1, 1, false, 65>; break;
     case 100: k = gemm8_bf16_kernel<3, 3, false, 0>; break;     // fc1 + GELU, pipelined
     case 164: k = gemm8_bf16_kernel<3, 3, false, 64>; break;    // fc1 + GELU, epilogue at the end of the tile
+    case 1001: k = gemm8_bf16_kernel<1, 1, true, 1>; break;     // fp16 qkv kind: no global stores
+    case 1008: k = gemm8_bf16_kernel<1, 1, true, 8>; break;     // ... no MFMAs
+    case 2024: k = gemm8_bf16_kernel<1, 1, true, 1024>; break;  // ... stores aliased onto tile row 0 (L2-resident)
     case 1000: k = gemm8_bf16_kernel<1, 1, true, 0>; break;     // the shipped fp16 instantiations: qkv / proj (bias)
     case 2000: k = gemm8_bf16_kernel<2, 4, true, 0>; break;     // fc2 / proj with LayerScale (gamma = the bias vector here)
     case 3000: k = gemm8_bf16_kernel<3, 3, true, 0>; break;     // fc1 + GELU
@@ -756,6 +780,31 @@ extern "C" int ec_lab_gemm8(const void* A, const void* W, const float* bias, voi
   *ms = t / (float)iters;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  return 0;
+}
+
+// Lab build only (tools/g8_ledger.py): ONE launch of the shipped QKV-kind fp16 kernel with s_memtime stamps (LAB 512) after two warm
+// launches; trace: device buffer of grid x 64 uint64 (per workgroup: [wave group][32 stamps], see the LAB comment).
+extern "C" int ec_lab_gemm8_trace(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int kind, void* trace, void* stream) {
+  typedef void (*kern_t)(GemmP);
+  kern_t k = kind == 3 ? (kern_t)gemm8_bf16_kernel<3, 3, true, 512> : kind == 2 ? (kern_t)gemm8_bf16_kernel<2, 4, true, 512> : (kern_t)gemm8_bf16_kernel<1, 1, true, 512>;
+  kern_t k0 = kind == 3 ? (kern_t)gemm8_bf16_kernel<3, 3, true, 0> : kind == 2 ? (kern_t)gemm8_bf16_kernel<2, 4, true, 0> : (kern_t)gemm8_bf16_kernel<1, 1, true, 0>;
+  hipStream_t st = (hipStream_t)stream;
+  EC_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS_LAB));
+  EC_HIP(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));
+  GemmP p;
+  p.A = A; p.B = W; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N; p.ab_bf16 = 1; p.c_bf16 = 1; p.h_f16 = 1;
+  p.gamma = bias;
+  int dev = 0, ncu = 0;
+  EC_HIP(hipGetDevice(&dev));
+  EC_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+  const long ntiles = (long)((M + 255) / 256) * ((N + 255) / 256);
+  const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k0, dim3(grid), dim3(512), G8_LDS, st, p);
+  p.aux = (const float*)trace;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), G8_LDS_LAB, st, p);
+  EC_LAUNCH_CHECK();
+  EC_HIP(hipStreamSynchronize(st));
   return 0;
 }
 #endif

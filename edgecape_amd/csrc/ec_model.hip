@@ -105,6 +105,7 @@ struct ec_model {
   hipEvent_t ev_feat_read_p = nullptr, ev_feat_read_q = nullptr;   // ... the pooling's (support lane) and input_proj's (query lane)
   bool pipe_full = true;               // the WHOLE head of a pipelined call runs beside the next backbone (run_head); EC_PIPE_FULL=0: only its decoder phase
   bool dq_active = false, dq_pending = false;
+  bool dq_recorded = false;            // ev_dq_done has been recorded at least once: ec_pipeline_flush may always wait for it
   bool feat_read_pending = false;      // FULL mode: the ev_feat_read* events have to be waited for before the feature buffer is rewritten
   // EC_TIMELINE=1: timed HIP events at the head's milestones on every stream, printed (us from the head's start) after a
   // device sync at the end of the call - the unprofiled picture of which lane is critical (rocprofv3 makes the head host-bound)
@@ -1353,6 +1354,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
   if (deferred) {
     EC_HIP(hipEventRecord(m->ev_dq_done, m->dq));
     m->dq_pending = true;
+    m->dq_recorded = true;
   }
   m->taps["hs"] = {m->d_hs, (long)m->dec.size() * Mk * d};
   return 0;
@@ -1877,7 +1879,10 @@ int ec_forward_pipelined(ec_handle m, const float* img_q, const float* const* im
 
 int ec_pipeline_flush(ec_handle m, void* stream) {
   EC_REQUIRE(m && m->finalized, EC_ERR_STATE, "model not finalized");
-  if (m->dq && m->dq_pending) EC_HIP(hipStreamWaitEvent((hipStream_t)stream, m->ev_dq_done, 0));   // (dq_pending stays: see header)
+  // ALWAYS waits for the most recent pipelined call's head, also after a plain entry point has cleared dq_pending on ITS stream
+  // (wait_pending_decoder): `stream` may be a different one that has never been ordered behind that head.  A wait for a completed
+  // event costs nothing on the device.  (dq_pending stays: see header)
+  if (m->dq && m->dq_recorded) EC_HIP(hipStreamWaitEvent((hipStream_t)stream, m->ev_dq_done, 0));
   if (m->timeline_defer) return tl_dump(m, true);
   return EC_OK;
 }

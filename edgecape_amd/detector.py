@@ -165,16 +165,31 @@ class EdgeCape:
         cs = self._copy_stream
         cs.wait_stream(torch.cuda.current_stream())      # this call's backbone ...
         eng.pipeline_flush(cs)                           # ... and its head, not the next call's backbone
+        # PINNED destinations: an asynchronous device -> host copy into pageable memory blocks the calling thread until the copy has
+        # run - i.e. until this batch's head has finished - and submit(i + 1) could then never enqueue backbone i + 1 beside head i.
+        # The buffers come from a small free list and go back to it in collect().
+        src = (o["output_kpts"], o["initial_proposals"], o["adj"][0])
+        host = [self._pinned(t.shape) for t in src]
         with torch.cuda.stream(cs):
-            host = [t.to("cpu", non_blocking=True) for t in (o["output_kpts"], o["initial_proposals"], o["adj"][0])]
+            for h, t in zip(host, src):
+                h.copy_(t, non_blocking=True)
             done = torch.cuda.Event()
             done.record(cs)
         return dict(host=host, done=done, keep=(iq, is_, ts, ms, o), img_metas=img_metas, size=[width, height], vis_offset=vis_offset)
 
+    def _pinned(self, shape):
+        """A pinned float32 host tensor of `shape` from the free list (page-locking is a system call: the loop reuses its buffers)."""
+        pool = self.__dict__.setdefault("_pin_pool", {})
+        free = pool.setdefault(tuple(shape), [])
+        return free.pop() if free else torch.empty(tuple(shape), dtype=torch.float32, pin_memory=True)
+
     def collect(self, ticket):
         """Second half: wait for the ticket's copies and build the reference's result dict (forward_test's host part)."""
         ticket["done"].synchronize()
-        layers, proposals, skeleton = (h.numpy() for h in ticket["host"])
+        layers, proposals, skeleton = (h.numpy().copy() for h in ticket["host"])    # own copies: the pinned buffers are reused
+        for h in ticket["host"]:
+            self._pin_pool[tuple(h.shape)].append(h)
+        ticket["host"] = None
         img_metas = ticket["img_metas"]
         result = self.decode(img_metas, layers[-1], img_size=ticket["size"])
         if ticket["vis_offset"]:

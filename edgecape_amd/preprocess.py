@@ -48,8 +48,10 @@ def get_affine_transform(center, scale, rot, output_size, shift=(0., 0.), inv=Fa
     th = np.pi * rot / 180
     sn, cs = np.sin(th), np.cos(th)
     up = -0.5 * box[0]                                            # (0, up) rotated by `rot`
-    c = center + box * np.asarray(shift)
-    src = _triangle(c, c + np.array([-up * sn, up * cs]))
+    # the reference's summation order (post_transforms.py:50-51): src[0] = center + box*shift, src[1] = (center + src_dir) + box*shift -
+    # with a non-zero shift another order can differ by an ulp in float64 and flip the float32 rounding of the stored point
+    sh = box * np.asarray(shift)
+    src = _triangle(center + sh, center + np.array([-up * sn, up * cs]) + sh)
     d0 = np.array([output_size[0] * 0.5, output_size[1] * 0.5])
     dst = _triangle(d0, d0 + np.array([0., output_size[0] * -0.5]))
     return _solve_affine(dst, src) if inv else _solve_affine(src, dst)

@@ -261,3 +261,36 @@ def test_single_process_helpers_without_process_group():
     assert apis.collect_results(res, 2) == res[:2]
     with pytest.raises(ValueError):
         apis.multi_gpu_test(_FakeModel(), [dict(idx=[[0]])])   # no size, no .dataset
+
+
+def test_init_distributed_nccl_passes_device_id(monkeypatch):
+    """the RCCL process group is created with device_id = this rank's GPU (eager communicator creation on the right
+    device - a lazily created communicator would be built inside the first collective, i.e. possibly inside bench.py's timed region)."""
+    import torch
+    import torch.distributed as dist
+    from edgecape_amd import apis
+    calls = {}
+    monkeypatch.setenv("RANK", "1"); monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("LOCAL_RANK", "1")
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: calls.setdefault("set_device", d))
+    monkeypatch.setattr(dist, "is_initialized", lambda: False)
+    monkeypatch.setattr(dist, "init_process_group", lambda backend, **kw: calls.update(backend=backend, **kw))
+    assert apis.init_distributed("nccl") == (1, 2, 1)
+    assert calls["backend"] == "nccl" and calls["set_device"] == 1
+    assert calls["device_id"] == torch.device("cuda", 1) and calls["rank"] == 1 and calls["world_size"] == 2
+    assert os.environ["MASTER_ADDR"] == "127.0.0.1" or os.environ["MASTER_ADDR"]
+
+
+def test_timed_steps_warms_collectives_before_the_clock(monkeypatch):
+    """The order of bench.py's timed region: warm-up steps, an all-reduce and a barrier (communicators exist), the arming hook, a
+    barrier, THEN the clock; K steps, the job's collective and the closing barrier inside; max over ranks after the clock."""
+    import time
+    from edgecape_amd import apis
+    log = []
+    monkeypatch.setattr(apis, "barrier", lambda: log.append("barrier"))
+    monkeypatch.setattr(apis, "max_over_ranks", lambda v: (log.append("allreduce_max"), float(v))[1])
+    ticks = iter(range(100))
+    monkeypatch.setattr(time, "perf_counter", lambda: (log.append("clock"), float(next(ticks)))[1])
+    dt = apis.timed_steps(lambda: log.append("step"), 3, 2, collective=lambda: log.append("collective"), before_timed=lambda: log.append("arm"))
+    assert log == ["step", "step", "allreduce_max", "barrier", "arm", "barrier", "clock", "step", "step", "step", "collective", "barrier", "clock",
+                   "allreduce_max"]
+    assert dt == 1.0

@@ -75,6 +75,14 @@ def test_bench_unpipelined_flag_and_companion_run():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["pipelined"] is True and d["unpipelined"]["value"] > 0 and d["unpipelined"]["ms_per_step"] > 0 and "bf16_mode" in d
+    # which number is which: roofline.* belongs to the timed region of `value`, the chip-alone figure sits beside it
+    r = d["roofline"]
+    assert "the timed region of `value`" in r["measured_in"] and r["launches_timed"] == d["steps"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["kernel_isolated"]["frac"] > 0 and r["kernel_isolated"]["avg_launch_ms"] > 0
+    assert d["value_reference_contract"] == d["unpipelined"]["value"]
+    c = d["conforming_mode"]                                 # the tolerance-conforming mode, measured in the same process
+    assert c["value"] > 0 and c["roofline"]["peak"] < 834 and 0 < c["roofline"]["frac"] < 1 and c["precision"].startswith("bf16x3")
     out = subprocess.run(base + ["--no-pipeline", "--no-alt"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])

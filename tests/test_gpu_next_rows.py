@@ -166,6 +166,42 @@ def test_eval_loop_real_model_vs_oracle(tmp_path):
         assert np.abs(a["preds"][0, m, :2] - b["preds"][0, m, :2]).max() < 0.3 if m.any() else True
 
 
+def test_submit_returns_before_its_head_has_finished():
+    """detector.submit() must not block on the batch's head (its device -> host copies go into PINNED buffers; a copy into
+    pageable memory would hold the calling thread until the head has run, and the next submit() could not overlap it).  At cfg2
+    size the head alone takes > 1.5 ms of device time behind a ~5 ms backbone, submit()'s host part well under a millisecond:
+    the ticket's `done` event must still be pending when submit() returns, and collect() must deliver forward_test's result."""
+    from edgecape_amd.detector import EdgeCape
+    arch, H, bs = "dinov2_vitb14", 256, 32
+    sd = synth.make_weights(arch, seed=3)
+    head_cfg = dict(type="TwoStageHead", in_channels=synth.ARCHS[arch]["C"],
+                    transformer=dict(type="TwoStageSupportRefineTransformer", d_model=256, nhead=8, num_encoder_layers=3,
+                                     num_decoder_layers=3, dim_feedforward=384, dropout=0.1, similarity_proj_dim=256,
+                                     dynamic_proj_dim=128, activation="relu", normalize_before=False,
+                                     return_intermediate_dec=True, use_bias_attn_module=True, attn_bias=True, max_hops=4),
+                    share_kpt_branch=False, num_decoder_layer=3,
+                    positional_encoding=dict(type="SinePositionalEncoding", num_feats=128, normalize=True),
+                    skeleton_head=dict(type="SkeletonPredictor", learn_skeleton=True), learn_skeleton=True,
+                    masked_supervision=True, masking_ratio=0.5, model_freeze="skeleton")
+    model = EdgeCape(keypoint_head=head_cfg, encoder_config=dict(), train_cfg=dict(), test_cfg=dict(flip_test=False), pretrained=arch,
+                     backbone_precision="fp16", head_precision="mixed")
+    model.load_state_dict(sd)
+    b = synth.make_pairs(bs, 1, H, seed=900, fixed_n_kp=False)
+    t = lambda x: torch.from_numpy(x).cuda()
+    data = dict(img_s=[t(x) for x in b["img_s"]], img_q=t(b["img_q"]), target_s=[t(x) for x in b["target_s"]],
+                target_weight_s=[torch.from_numpy(x) for x in b["target_weight_s"]], img_metas=b["img_metas"])
+    ref = model(return_loss=False, **data)                   # also the warm-up (engine build, first launches)
+    torch.cuda.synchronize()
+    pending = []
+    for _ in range(3):
+        ticket = model.submit(**data)
+        pending.append(ticket["done"].query())               # True = the copies (hence the head) had finished inside submit()
+        res = model.collect(ticket)
+        assert np.array_equal(res["preds"], ref["preds"]) and np.array_equal(res["points"], ref["points"]) and np.array_equal(res["skeleton"], ref["skeleton"])
+    assert not any(pending), pending
+    assert all(h.is_pinned() for free in model._pin_pool.values() for h in free) and sum(len(f) for f in model._pin_pool.values()) == 3
+
+
 def test_forward_pipelined_stress():
     """A long random sequence of pipelined / plain calls and flushes on one handle (the head of call i beside the backbone of call
     i + 1, heads queued behind one another, plain calls and flushes cutting in): every call's outputs bit-equal to ec_forward's."""

@@ -310,6 +310,29 @@ def test_linear_h16_fp16_saturates(lib, kind):
     assert ((got[ok] - ref[ok]).abs() <= ref[ok].abs() * 2.0 ** -10 + 0.05).all()
 
 
+@pytest.mark.parametrize("kind", ["bias", "gelu", "scale"])
+def test_linear_h16_fp16_nan_in_nan_out(lib, kind):
+    """The fp16 saturation keeps NaN (v_med3_f32 alone turned a NaN into -65504 - a NaN activation then left the backbone
+    as a finite value and the caller never saw it; ec_common.h sat_h16 adds v * 0 back).  A NaN in one activation row must come out
+    as NaN in every column of that row and nowhere else; the saturated values of test_linear_h16_fp16_saturates are unchanged."""
+    M, N, K = 2048, 512, 256
+    g = torch.Generator().manual_seed(6)
+    A = torch.randn(M, K, generator=g)
+    A[77, 5] = float("nan")
+    A[1500, 200] = float("nan")
+    W = torch.randn(N, K, generator=g)
+    b = torch.randn(N, generator=g)
+    gam = (torch.rand(N, generator=g) + 0.5) if kind == "scale" else None
+    buf = torch.empty(M * N, device="cuda", dtype=torch.float16)
+    _chk(lib, lib.ec_op_linear_h16(_p(A.cuda()), _p(W.cuda()), _p(b.cuda()), _p(gam.cuda()) if gam is not None else None, _p(buf), M, N, K,
+                                   2 if kind == "gelu" else 0, 3, 1, None))
+    torch.cuda.synchronize()
+    got = buf.view(M, N)
+    nan_rows = torch.isnan(got).all(dim=1).nonzero().flatten().tolist()
+    assert nan_rows == [77, 1500], nan_rows
+    assert int(torch.isnan(got).any(dim=1).sum().item()) == 2
+
+
 @pytest.mark.parametrize("prec", [1, 3])
 @pytest.mark.parametrize("M,N,K,kind", [(20800, 2304, 768, "bias"), (20800, 768, 768, "scale"), (4099, 3072, 768, "gelu"), (4099, 768, 3072, "scale"),
                                         (2600, 1152, 384, "bias"), (2600, 384, 1536, "scale"), (1300, 1536, 384, "gelu"), (5840, 1024, 1024, "bias")])

@@ -13,11 +13,16 @@ Modes (backbone / head):
   bf16x3 / bf16x3  "parity mode": every MFMA operand split hi+lo bf16 - fp32-class; must meet 1e-3 outright, no flips.
   fp16   / bf16x3  headline throughput mode: IEEE fp16 operands at the bf16 MFMA rate; continuous error ~1e-4.
   bf16   / bf16x3  the north-star's literal bf16 tiles: continuous error ~1e-3, reported and bounded, not parity-grade.
-CPU emulation of the operand rounding on 256 pairs (oracle/precision_study.py, ViT-S) predicted: bf16 95 flips, fp16 11, bf16x3 0.
-MEASURED on MI355X at cfg2, 256 DISJOINT pairs x 2 weight seeds (round 3, test_headline_conformance_at_scale, record
-profiles/r03_conformance_fp16_mixed.json): fp16 backbone + mixed head 13 flips of 20 293 valid keypoints (6.4e-4), max |d| 1.65e-4 on the
-flip-free samples, 5e-4 of the keypoints (flipped samples) above 1e-3, PCK@0.2 vs the oracle 0.9997; bf16x3 / bf16x3: 1 flip, max
-1.1e-5 (profiles/r03_conformance_bf16x3.json).  (An earlier record with 0 flips had drawn 39 distinct pairs per weight seed.)
+MEASURED on MI355X, 256 DISJOINT pairs x 2 weight seeds per configuration against the oracle (tools/conformance.py, records under
+profiles/; the at-scale gates below are these observations + <= 50 %):
+  fp16 / mixed   cfg1 (ViT-S/14 @ 224, the reference's shipped config)  13 flips of 19 288 valid keypoints (6.7e-4), 6.2e-4 outside 1e-3,
+                      max |d| 1.87e-4 on the 499 flip-free samples, PCK@0.2 vs the oracle's answers 0.9994  (r04_conformance_cfg1_fp16_mixed)
+                 cfg2 13 of 20 293 (6.4e-4), 5.2e-4, 1.65e-4 on 500 samples, 0.9997                          (r04_conformance_fp16_mixed)
+                 cfg4  9 of  9 841 (9.1e-4), 1.5e-4 on 248 samples, 0.9995  (256 pairs)                  (r03_conformance_cfg4_fp16_mixed)
+                 cfg5  7 of  4 753 (1.5e-3), 1.6e-4 on 121 samples, 0.9992  (128 pairs)                  (r03_conformance_cfg5_fp16_mixed)
+  bf16x3 / bf16x3  cfg1 0 flips, max 9.1e-6 over all 512 pairs; cfg2 1 flip (a 4.9e-5 near-tie), 1.1e-5 on the other 511.
+A device-side near-tie guard is NOT viable (near_tie_guard in the records): the similarity map (scale ~ 60) is up to 2.8e-2 off in
+fp16, and 55-62 % of the samples hold a valid keypoint whose top-2 gap is below twice that (2.4-2.9 % of the keypoints).
 """
 import functools
 
@@ -30,6 +35,8 @@ from edgecape_amd import synth
 pytestmark = pytest.mark.gpu
 
 CFG = {
+    # the reference's own shipped configuration (configs/test/1shot_split1.py:37,74; EdgeCape.py:33): ViT-S/14 @ 224, at the bench's batch
+    "cfg1": dict(arch="dinov2_vits14", H=224, bs=32, S=1, wseed=0, iseed=4000),
     "cfg2": dict(arch="dinov2_vitb14", H=256, bs=32, S=1, wseed=0, iseed=1000),    # BASELINE configs[1]
     "cfg4": dict(arch="dinov2_vitb14", H=256, bs=16, S=5, wseed=0, iseed=2000),    # configs[3]
     "cfg5": dict(arch="dinov2_vitl14", H=384, bs=8, S=1, wseed=0, iseed=3000),     # configs[4]
@@ -86,7 +93,37 @@ def stats(got, ref, valid, H):
                 pck_vs_oracle=pck_vs_oracle, adj_err=float(np.abs(got["adj"] - ref["adj"]).max()))
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg4", "cfg5"])
+def gap_analysis(got_sim, ref_sim, valid, flip=None):
+    """What a device-side near-tie guard would see: per valid keypoint the top-2 gap of the HIP similarity map
+    and the map's error against the oracle.  A guard that re-runs (through the conforming precision) every SAMPLE with a valid
+    keypoint whose gap is below `thr` is safe when thr >= 2 x the map error (the oracle's argmax cell is then the HIP one); reported
+    for thr = 2 x {p99, p99.9, max} of the per-keypoint maximum map error: the share of keypoints / samples it would re-run and
+    how many of the observed flips it would have caught."""
+    bs, K = valid.shape
+    g = got_sim.reshape(bs, K, -1).astype(np.float64)
+    r = ref_sim.reshape(bs, K, -1).astype(np.float64)
+    top2 = np.partition(g, -2, axis=-1)[:, :, -2:]
+    gap = (top2[:, :, 1] - top2[:, :, 0])                       # [bs,K] >= 0
+    err = np.abs(g - r).max(-1)                                 # per keypoint: max over the map
+    if flip is None:
+        flip = (g.argmax(-1) != r.argmax(-1)) & valid
+    gv, ev = gap[valid], err[valid]
+    edges = [0.0, 1e-3, 2e-3, 5e-3, 1e-2, 2e-2, 5e-2, 1e-1, 2e-1, 5e-1, 1.0, 2.0, 5.0, 1e9]
+    hist = np.histogram(gv, bins=edges)[0]
+    out = dict(n_valid=int(valid.sum()), samples=int(bs), map_scale=float(np.abs(r[valid]).max()),
+               map_err=dict(median=float(np.median(ev)), p99=float(np.quantile(ev, 0.99)), p999=float(np.quantile(ev, 0.999)), max=float(ev.max())),
+               gap_hist=dict(edges=edges[:-1] + ["inf"], counts=[int(x) for x in hist]),
+               gap_of_flipped=[float(x) for x in np.sort(gap[flip])], guards={})
+    for tag, e in (("2x_p99", out["map_err"]["p99"]), ("2x_p999", out["map_err"]["p999"]), ("2x_max", out["map_err"]["max"])):
+        thr = 2.0 * e
+        near = (gap < thr) & valid
+        out["guards"][tag] = dict(thr=float(thr), kpt_frac=float(near.sum() / max(valid.sum(), 1)), sample_frac=float(near.any(1).mean()),
+                                  flips_caught=int((near & flip).sum()), flips=int(flip.sum()),
+                                  flipped_samples_caught=int((near.any(1) & flip.any(1)).sum()), flipped_samples=int(flip.any(1).sum()))
+    return out
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg4", "cfg5"])
 def test_parity_mode_bf16x3(name):
     """bf16x3 backbone + bf16x3 head: the tolerance-conforming fast mode.  Full batch of the BASELINE config vs the oracle."""
     s = _run(name, "bf16x3", "bf16x3")
@@ -97,38 +134,39 @@ def test_parity_mode_bf16x3(name):
     assert s["pck_vs_oracle"] == 1.0
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg4", "cfg5"])
-def test_headline_mode_fp16(name):
-    """fp16 backbone + bf16x3 head (bench.py's headline precision).  Continuous error an order of magnitude inside the gate;
-    argmax near-ties may flip (emulation: 0.15 % of the valid keypoints with random weights)."""
-    s = _run(name, "fp16", "bf16x3")
-    print(name, "fp16/bf16x3", s)
-    # observed on all three configs: 0 flips, max |d| 1.4-1.6e-4 (round 2 and 3); at scale: test_headline_conformance_at_scale
-    assert s["max_clean"] < 5e-4, s                       # every sample without an argmax flip: 2x inside the north-star tolerance
-    assert s["p99"] < 2e-4 and s["median"] < 2e-5
-    assert s["flips"] <= 1, s                             # one near-tie may flip on another box; it moves ONE sample
+def _headline_gates(s, name):
+    """One full batch of a configuration in the bench's default backbone precision.  Observed on every configuration (rounds 2-4):
+    0 flips on these batches, max |d| 1.4-1.9e-4, p99 <= 8e-5, median <= 6e-6; gates = that + <= 50 %.  A near-tie may flip on another
+    box (a flip moves ONE sample by up to a grid cell): at most one, and then only that sample may leave the tolerance."""
+    assert s["max_clean"] < 2.8e-4, s                     # every sample without an argmax flip: 3.5x inside the north-star tolerance
+    assert s["p99"] < 1.2e-4 and s["median"] < 9e-6, s
+    assert s["flips"] <= 1, s
     assert s["clean_samples"] >= CFG[name]["bs"] - 1
     if s["flips"] == 0:
-        assert s["max_all"] < 5e-4 and s["frac_gt_1e3"] == 0.0
+        assert s["max_all"] < 2.8e-4 and s["frac_gt_1e3"] == 0.0
     assert s["pck_vs_oracle"] >= 0.99                     # north star: PCK@0.2 within +-0.1 (here against the oracle's own answers)
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg4", "cfg5"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg4", "cfg5"])
+def test_headline_mode_fp16(name):
+    """fp16 backbone + bf16x3 head.  Continuous error most of an order of magnitude inside the tolerance; argmax near-ties may flip
+    (measured rate at scale: 6-15e-4 of the valid keypoints, module docstring)."""
+    s = _run(name, "fp16", "bf16x3")
+    print(name, "fp16/bf16x3", s)
+    _headline_gates(s, name)
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg4", "cfg5"])
 def test_headline_mode_fp16_mixed_head(name):
-    """fp16 backbone + MIXED head (bench.py's headline precision, round 2): bf16x3 wherever the proposal generator's argmax depends on
-    it, single-pass fp16 MFMAs in the Linear layers of the skeleton head and the decoder layers (EC_MIXED).  Same gates as the
+    """fp16 backbone + MIXED head (bench.py's default precision): bf16x3 wherever the proposal generator's argmax depends on it,
+    single-pass fp16 MFMAs in the Linear layers and attentions of the skeleton head and the decoder layers (EC_MIXED).  Same gates as the
     fp16 / bf16x3 mode - the head's share of the error is below the backbone's (oracle/head_precision_study.py) - plus: no more argmax
-    flips than that mode, and the refined adjacency (the skeleton head's product) still at 1e-3."""
+    flips than that mode, and the refined adjacency (the skeleton head's product) at 1e-4."""
     s = _run(name, "fp16", "mixed")
     s0 = _run(name, "fp16", "bf16x3")
     print(name, "fp16/mixed", s, "\n     fp16/bf16x3", s0)
-    assert s["max_clean"] < 5e-4, s
-    assert s["p99"] < 2e-4 and s["median"] < 2e-5
-    assert s["flips"] <= s0["flips"] and s["flips"] <= 1  # the encoder / proposal path is bit-identical to the bf16x3 head's
-    assert s["clean_samples"] >= CFG[name]["bs"] - 1
-    if s["flips"] == 0:
-        assert s["max_all"] < 5e-4 and s["frac_gt_1e3"] == 0.0
-    assert s["pck_vs_oracle"] >= 0.99
+    _headline_gates(s, name)
+    assert s["flips"] <= s0["flips"]                      # the encoder / proposal path is bit-identical to the bf16x3 head's
     assert s["adj_err"] < 1e-4
 
 
@@ -172,30 +210,38 @@ def conformance_at_scale(n_batches=8, wseeds=(0, 1), backbone="fp16", head="mixe
                    dict(output_kpts=cat(pooled_ref, "output_kpts", 1), similarity_map=cat(pooled_ref, "similarity_map", 0), adj=cat(pooled_ref, "adj", 0)),
                    np.concatenate(pooled_valid, 0), c["H"])
     pooled["pairs"] = int(sum(v.shape[0] for v in pooled_valid))
+    pooled["near_tie_guard"] = gap_analysis(cat(pooled_got, "similarity_map", 0), cat(pooled_ref, "similarity_map", 0), np.concatenate(pooled_valid, 0))
     return per_seed, pooled
 
 
-def test_headline_conformance_at_scale():
-    """cfg2, fp16 backbone + mixed head (the bench default), 256 DISJOINT pairs x 2 weight seeds vs the oracle.  Gates = the observed
-    rates with head-room (profiles/r03_conformance_fp16_mixed.json): the share of valid keypoints whose proposal argmax flips and the
-    share outside 1e-3 are MEASURED quantities of this mode; every flip-free sample must be inside the tolerance outright."""
-    per_seed, pooled = conformance_at_scale()
-    print("conformance", per_seed, pooled)
-    # observed (MI355X, round 3, 512 disjoint pairs, split-precision patch embedding): 13 argmax flips of 20 293 valid keypoints (6.4e-4;
-    # 9 / 4 per weight seed), max |d| 1.65e-4 on the flip-free samples, p99 7.0e-5, median 3.3e-6, 5.2e-4 of the keypoints outside 1e-3
-    # (all in flipped samples), PCK@0.2 against the oracle's answers 0.9997 (with single fp16 operands in the patch embedding: 22 flips,
-    # 2.8e-4, 8.7e-5, 9.9e-4, 0.9993).  (The first round-3 record - 0 flips - had drawn the same 39 pairs per
-    # weight seed eight times over: overlapping seeds.)  BASELINE.md section 4 gates a reduced-precision mode by its PCK@0.2 delta
-    # (<= 0.1) and reports the flip count; the 1e-3 gate is the parity modes' (fp32, bf16x3).
-    assert pooled["pairs"] >= 512
-    assert pooled["max_clean"] < 5e-4, pooled                       # continuous part of the error: 2x inside the tolerance
-    assert pooled["p99"] < 2e-4 and pooled["median"] < 1e-5
-    assert pooled["flip_frac"] <= 2.5e-3, pooled                    # observed 1.08e-3: an indexing / synchronisation bug flips percents
-    assert pooled["frac_gt_1e3"] <= 2.5e-3, pooled
-    assert pooled["clean_samples"] >= 0.93 * pooled["pairs"], pooled   # observed 491 / 512
-    assert pooled["pck_vs_oracle"] >= 0.998                         # observed 0.9993; north star: PCK@0.2 within +-0.1
+# Observed at scale (256 disjoint pairs x 2 weight seeds, fp16 / mixed; profiles/r04_conformance_*): the gates are these + <= 50 %.
+AT_SCALE = {
+    "cfg1": dict(flips=13, n_valid=19288, frac_gt_1e3=6.2e-4, max_clean=1.87e-4, p99=7.0e-5, median=5.1e-6, flipped_samples=13, pck=0.9994, seed_flips=8),
+    "cfg2": dict(flips=13, n_valid=20293, frac_gt_1e3=5.2e-4, max_clean=1.65e-4, p99=7.0e-5, median=3.3e-6, flipped_samples=12, pck=0.9997, seed_flips=9),
+}
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2"])
+def test_headline_conformance_at_scale(name):
+    """fp16 backbone + mixed head (the bench default) on 256 DISJOINT pairs x 2 weight seeds vs the oracle, for the reference's own
+    shipped configuration (cfg1: ViT-S/14 @ 224, configs/test/1shot_split1.py:37,74) and the benched one (cfg2).  The share of valid
+    keypoints whose proposal argmax flips and the share outside 1e-3 are MEASURED rates of this mode; every flip-free sample must be
+    inside the tolerance outright.  BASELINE.md section 4 gates a reduced-precision mode by its PCK@0.2 delta (<= 0.1) and reports
+    the flip count; the 1e-3 coordinate gate on EVERY keypoint is the parity modes' (fp32, bf16x3: test_parity_mode_bf16x3)."""
+    per_seed, pooled = conformance_at_scale(name=name)
+    print("conformance", name, per_seed, {k: v for k, v in pooled.items() if k != "near_tie_guard"})
+    o = AT_SCALE[name]
+    assert pooled["pairs"] >= 512 and abs(pooled["n_valid"] - o["n_valid"]) <= 0.01 * o["n_valid"]      # the same pairs as the record
+    assert pooled["flips"] <= 1.5 * o["flips"], pooled                     # a regression that doubles the flip rate fails
+    assert pooled["frac_gt_1e3"] <= 1.5 * o["frac_gt_1e3"], pooled
+    assert pooled["max_clean"] < 1.5 * o["max_clean"], pooled              # continuous part of the error: > 3.5x inside the tolerance
+    assert pooled["p99"] < 1.5 * o["p99"] and pooled["median"] < 1.5 * o["median"], pooled
+    assert pooled["pairs"] - pooled["clean_samples"] <= 1.5 * o["flipped_samples"], pooled
+    assert pooled["pck_vs_oracle"] >= o["pck"] - 5e-4, pooled              # north star: PCK@0.2 within +-0.1
     for st in per_seed:
-        assert st["max_clean"] < 5e-4 and st["flip_frac"] <= 4e-3, st
+        assert st["max_clean"] < 1.5 * o["max_clean"] and st["flips"] <= 1.5 * o["seed_flips"], st
+    g = pooled["near_tie_guard"]["guards"]["2x_max"]                       # the guard decision's evidence stays measurable
+    assert g["flips_caught"] == g["flips"] and g["sample_frac"] > 0.25, g
 
 
 def test_bf16_mode_cfg2_bounded():

@@ -18,7 +18,7 @@ ap.add_argument("--backbone", default="fp16")
 ap.add_argument("--head", default="mixed")
 ap.add_argument("--batches", type=int, default=8)
 ap.add_argument("--seeds", default="0,1")
-ap.add_argument("--config", default="cfg2", help="cfg2 | cfg4 | cfg5 (tests/test_gpu_precision_modes.py CFG)")
+ap.add_argument("--config", default="cfg2", help="cfg1 | cfg2 | cfg4 | cfg5 (tests/test_gpu_precision_modes.py CFG)")
 ap.add_argument("--out", default=None)
 a = ap.parse_args()
 per_seed, pooled = T.conformance_at_scale(a.batches, tuple(int(x) for x in a.seeds.split(",")), a.backbone, a.head, a.config)

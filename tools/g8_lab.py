@@ -28,7 +28,8 @@ def main():
     lib.ec_lab_gemm_nt.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, C.POINTER(C.c_float)]
     nt_cfgs = [int(v) for v in os.environ.get("NT", "").split(",") if v]
     g4_variants = [int(v) for v in os.environ.get("G4", "").split(",") if v]
-    lib.ec_lab_gemm4.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, C.POINTER(C.c_float)]
+    if g4_variants:   # the four-wave kernel of round 2 (git show 22a53bf:edgecape_amd/csrc/ec_gemm4.hip) is no longer in the lab library
+        lib.ec_lab_gemm4.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, C.POINTER(C.c_float)]
     shapes = [("qkv", 20800, 2304, 768)]
     if os.environ.get("SHAPES"):
         shapes = [(n, int(m), int(nn), int(k)) for n, m, nn, k in (x.split(":") for x in os.environ["SHAPES"].split(","))]
