@@ -86,6 +86,18 @@ template <bool F16> __device__ __forceinline__ u32x2_t pack4_h(f32x4 v) {
     return __builtin_bit_cast(u32x2_t, __builtin_convertvector(v, bf16v4_));
   }
 }
+// The same for kernels that have switched the wave's MODE.FP16_OVFL bit on (fp16_ovfl_mode() at kernel entry): with that bit the
+// hardware clamps an overflowing fp16 conversion result to +-65504 itself, keeps true infinities and NaN (probed on gfx950:
+// tools/fp16_ovfl_probe.hip, profiles/r04_fp16_ovfl_probe.txt) - the saturation costs no instruction at all.  Used by the 8-phase
+// GEMM, whose epilogues are VALU-bound (v_med3 + v_fma per value measured +1.5 % on the QKV launch, profiles/r04_sat_ab.txt).
+__device__ __forceinline__ void fp16_ovfl_mode() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }   // hwreg(HW_REG_MODE, 23, 1) = 1
+template <bool F16> __device__ __forceinline__ u32x2_t pack4_h_ovfl(f32x4 v) {
+  if constexpr (F16) return __builtin_bit_cast(u32x2_t, __builtin_convertvector(v, f16x4));
+  else {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16v4_;
+    return __builtin_bit_cast(u32x2_t, __builtin_convertvector(v, bf16v4_));
+  }
+}
 template <bool F16> __device__ __forceinline__ bf16_t f2h(float f) {
   if constexpr (F16) return __builtin_bit_cast(bf16_t, (_Float16)sat_h16(f));
   else return __builtin_bit_cast(bf16_t, (__bf16)f);

@@ -72,31 +72,32 @@ constexpr int G8_AHEAD = 5;               // half-tiles the load stream runs ahe
 // projections, whose positional half is folded into such a table), fp32 or 16-bit output, through the staged whole-line epilogue.
 enum { G8_GENERIC = 0, G8_BIAS_BF16 = 1, G8_SCALE_BF16 = 2, G8_GELU_BF16 = 3, G8_TAB_H16 = 4, G8_TAB_F32 = 5 };
 
-// GELU for 16-bit outputs: x * Phi(x) with Phi(x) = 1 / (1 + 2^(x * P(x^2))), P an even minimax polynomial fitted to the erf
-// form (nn.GELU default, dinov2 Mlp) on |x| <= 9.  bf16 outputs: degree 2 in x^2, max |err| 2.5e-5 (far below the bf16 rounding
-// of the result), 6 plain VALU ops + exp2 + rcp per element (the epilogue of fc1 is VALU-bound: 128 GELUs per lane per tile).
-// fp16 outputs carry three more significand bits: degree 4, max |err| 3.0e-6 (two more FMAs).
-// The degree-4 polynomial needs no clamp: its leading coefficient is negative, P(s) < -100 for every s > 81 (x * P -> -/+ inf,
-// 2^ -> 0 / inf, rcp -> 1 / 0: the exact limits); the degree-2 one grows positive past s = 105 and keeps the clamp.
-// Measured and not adopted for fp16 outputs (round 3, tools/g8_ab.py, interleaved medians on the fc1 shape): the degree-2 polynomial
-// -1.4 % of the launch, the polynomial of two elements in packed fp16 (v_pk_*_f16 + v_fma_mix_f32, |d Phi| up to 2e-4) -2.7 %: the
-// epilogue's exp2 / rcp (quarter rate, 16 of its ~34 cycles per element) stay either way.
+// GELU for 16-bit outputs (erf form: nn.GELU default, dinov2 Mlp) with ONE transcendental (round 4):
+//     gelu(x) = x Phi(x) = max(x, 0) - |x| Phi(-|x|),      Phi(-a) = 2^L(a),  L(a) = log2 Phi(-a)  smooth and concave on a >= 0
+// (for x > 0 by Phi(x) = 1 - Phi(-x)).  L is replaced by a polynomial in a = |x|, a weighted minimax fit (weight a Phi(-a) ln 2, the
+// sensitivity of the result to L; tools/gelu_fit.py: Lawson iteration on [0, 6]) whose leading coefficient is negative, so the
+// polynomial runs to -inf beyond the fitted range, 2^ -> 0 and the result goes to its exact limits x / -0 without a clamp.
+//   fp16 outputs: degree 5, max |err| 6.4e-7 in fp32 arithmetic on |x| <= 12 (the round-2/3 form 1 / (1 + 2^(x P(x^2))) had 3.0e-6);
+//   bf16 outputs: degree 3, max |err| 5.5e-5 (far below the bf16 rounding of the result).
+// Cost per element: 5 (3) v_fma + v_exp + v_max + v_fma = 7 (5) full-rate and ONE quarter-rate instruction; the old form was 8 (6)
+// full-rate and TWO quarter-rate ones (v_exp + v_rcp = 16 of its ~34 cycles; measured and rejected in round 3: a degree-2 polynomial,
+// packed-fp16 polynomials - both kept the two transcendentals).  |x| and -|x| are source modifiers, NaN goes through the last fma.
 template <bool F16>
 __device__ __forceinline__ float gelu_fast8(float x) {
+  const float a = fabsf(x);
   float q;
   if constexpr (F16) {
-    const float s = x * x;
-    q = fmaf(-3.229071e-06f, s, 8.82395e-05f);
-    q = fmaf(q, s, 3.6026796e-04f);
-    q = fmaf(q, s, -1.0522668e-01f);
-    q = fmaf(q, s, -2.3020453e+00f);
+    q = fmaf(-4.732939302e-04f, a, 7.084460654e-03f);
+    q = fmaf(q, a, -5.182716738e-02f);
+    q = fmaf(q, a, -4.599926465e-01f);
+    q = fmaf(q, a, -1.150787770e+00f);
+    q = fmaf(q, a, -1.000037632e+00f);
   } else {
-    const float s = fminf(x * x, 81.f);
-    q = fmaf(1.01453915e-03f, s, -1.06777424e-01f);
-    q = fmaf(q, s, -2.30111947e+00f);
+    q = fmaf(-2.487393087e-02f, a, -4.988535682e-01f);
+    q = fmaf(q, a, -1.129219622e+00f);
+    q = fmaf(q, a, -1.003536762e+00f);
   }
-  const float e = __builtin_amdgcn_exp2f(x * q);
-  return x * __builtin_amdgcn_rcpf(1.f + e);
+  return fmaf(-a, __builtin_amdgcn_exp2f(q), fmaxf(x, 0.f));
 }
 
 // acc[mi][ni] (f32x4) of lane l: row m = m0 + wr*128 + mi*16 + (l&15),
@@ -138,7 +139,7 @@ __device__ __forceinline__ void g8_epilogue_generic(const GemmP& p, f32x4 (&acc)
       v *= gam4[ni];
       if (p.resid) v += *(const f32x4*)(p.resid + (long)m * p.ldr + n);
       if (p.c_bf16) {
-        *(u32x2*)((char*)p.C + ((long)m * p.ldc + n) * 2) = pack4_h<F16>(v);
+        *(u32x2*)((char*)p.C + ((long)m * p.ldc + n) * 2) = pack4_h_ovfl<F16>(v);
       } else {
         *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = v;
       }
@@ -210,7 +211,7 @@ __device__ __forceinline__ void g8_piece(f32x4 (&a)[4], const __amdgpu_buffer_rs
     }
     if constexpr (KIND == G8_SCALE_BF16) v *= *(const f32x4*)(gam_lds + c0 * 4);
     const int chunk = (ni >> 1) * 4 + (ni & 1) * 2 + (wq >> 1);
-    *(u32x2*)(stg + wrow * 128 + ((chunk ^ (wrow & 7)) << 4) + (wq & 1) * 8) = pack4_h<F16>(v);   // 2 x v_cvt_pk (RNE)
+    *(u32x2*)(stg + wrow * 128 + ((chunk ^ (wrow & 7)) << 4) + (wq & 1) * 8) = pack4_h_ovfl<F16>(v);   // 2 x v_cvt_pk (RNE)
     a[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
@@ -245,7 +246,7 @@ __device__ __forceinline__ void g8_piece_reg(f32x4 (&a)[4], const __amdgpu_buffe
       for (int e = 0; e < 4; ++e) v[e] = gelu_fast8<F16>(v[e]);
     }
     if constexpr (KIND == G8_SCALE_BF16) v *= *(const f32x4*)(gam_lds + c0 * 4);
-    pk[ni] = pack4_h<F16>(v);
+    pk[ni] = pack4_h_ovfl<F16>(v);
     a[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
@@ -275,7 +276,8 @@ template <int N> __device__ __forceinline__ void g8_wait_vm() { asm volatile("s_
 // state, 8 no MFMAs, 32 no epilogue at all, 64 the load stream is drained at the tile seam (the round-1 seam, for A/B),
 // 512 (round 4) s_memtime stamps of one wave per wave group at the tile milestones (kernel start | per tile: K loop start, K loop
 // end, epilogue end | kernel end), kept in LDS and dumped to p.aux[blockIdx][64] at the end: the per-tile cycle ledger of DESIGN.md;
-// 1024 (round 4) every tile STORES to the rows of tile row 0 (the output of a launch aliases onto 256 x N: dirty lines stay in the
+// 2048 (round 4) no LDS fragment reads after the first K-tile pair of a workgroup (the MFMAs reuse the registers: what the ds_read
+// traffic of the partner group costs the MFMA blocks); 1024 (round 4) every tile STORES to the rows of tile row 0 (the output of a launch aliases onto 256 x N: dirty lines stay in the
 // L2s, nothing is written back in the burst): what the seam costs without the fabric write-back.
 //
 // Tile seam of the 16-bit output kinds (KIND != GENERIC): the epilogue runs at the END of the tile, both wave groups at once
@@ -296,6 +298,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   // 128-byte lines per store: the bias / LayerScale kinds are bound by the stores themselves, QKV 64.6 vs 66.4 us); LAB & 128 flips it.
   constexpr bool REGEPI = (KIND == G8_GELU_BF16) != ((LAB & 128) != 0);
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (F16) fp16_ovfl_mode();   // fp16 outputs saturate at +-65504 in the conversion itself (pack4_h_ovfl; ec_common.h)
   constexpr bool FAST = KIND != G8_GENERIC && !(LAB & 32);   // bias from LDS, epilogue pieces through the staging slot
   constexpr bool NODRAIN = FAST && !(LAB & 64);              // the load stream is not drained at the seam
   constexpr int NB = KIND == G8_SCALE_BF16 ? 2 : 1;          // LDS-DMA pieces of one bias (+ LayerScale) slice
@@ -309,6 +312,10 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
       if ((wave & 3) == 0 && g8_lane_now() == 0) ((unsigned long long*)(smem + G8_TRACE))[wr * 32 + idx] = __builtin_amdgcn_s_memtime();
     }
   };
+  if constexpr (LAB & 512) {
+    if (tid < 64) ((unsigned long long*)(smem + G8_TRACE))[tid] = 0ull;
+    __syncthreads();
+  }
   stamp(0);
 
   const int ntm = (p.M + 255) >> 8, ntn = (p.N + 255) >> 8;
@@ -510,7 +517,9 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
         const char* bb = b_base + buf * G8_KT;
         const bool head = buf == 0 && kt2 == 0;                        // first K-tile of the tile
         const bool seam = NODRAIN && head && it > 0;                   // ... with the previous tile's stores in the VM queue
+        const bool rd = !(LAB & 2048) || (it == 0 && kt2 == 0);        // lab: fragment reads only in the workgroup's first K-tile pair
         // ---------------- phase 0: quadrant (m-half 0, n-half 0)
+        if (rd) {
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -519,6 +528,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
         for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
           for (int kh = 0; kh < 2; ++kh) af[fi][kh] = *(const bf16x8*)(ab + fi * 2048 + kh * KH);
+        }
         issue(rsB, vo1, ldb8, 1);
         if constexpr (NODRAIN) {
           if (seam) g8_wait_vm<6 + NST>(); else g8_wait_vm<6>();
@@ -545,10 +555,12 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
         __builtin_amdgcn_s_setprio(0);
         G8_BAR();
         // ---------------- phase 1: quadrant (0, 1)
+        if (rd) {
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
           for (int kh = 0; kh < 2; ++kh) b1[f][kh] = *(const bf16x8*)(bb + G8_HALF + f * 2048 + kh * KH);
+        }
         issue(rsB, vo2, ldb8, 2);
         if constexpr (NODRAIN) {
           if (seam) g8_wait_vm<6 + NST>(); else g8_wait_vm<6>();
@@ -567,10 +579,12 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
         __builtin_amdgcn_s_setprio(0);
         G8_BAR();
         // ---------------- phase 2: quadrant (1, 1)
+        if (rd) {
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
           for (int kh = 0; kh < 2; ++kh) af[fi][kh] = *(const bf16x8*)(ab + 3 * G8_HALF + fi * 2048 + kh * KH);
+        }
         issue(rsA, vo3, lda8, 3);
         if constexpr (FAST) {
           if (head) {                                                              // third phase of a tile
@@ -751,6 +765,9 @@ extern "C" int ec_lab_gemm8(const void* A, const void* W, const float* bias, voi
     case 1001: k = gemm8_bf16_kernel<1, 1, true, 1>; break;     // fp16 qkv kind: no global stores
     case 1008: k = gemm8_bf16_kernel<1, 1, true, 8>; break;     // ... no MFMAs
     case 2024: k = gemm8_bf16_kernel<1, 1, true, 1024>; break;  // ... stores aliased onto tile row 0 (L2-resident)
+    case 1004: k = gemm8_bf16_kernel<1, 1, true, 4>; break;     // ... no LDS-DMA in the steady state
+    case 3048: k = gemm8_bf16_kernel<1, 1, true, 2048>; break;  // ... no fragment reads in the steady state
+    case 3052: k = gemm8_bf16_kernel<1, 1, true, 2052>; break;  // ... neither
     case 1000: k = gemm8_bf16_kernel<1, 1, true, 0>; break;     // the shipped fp16 instantiations: qkv / proj (bias)
     case 2000: k = gemm8_bf16_kernel<2, 4, true, 0>; break;     // fc2 / proj with LayerScale (gamma = the bias vector here)
     case 3000: k = gemm8_bf16_kernel<3, 3, true, 0>; break;     // fc1 + GELU

@@ -181,7 +181,7 @@ def test_submit_returns_before_its_head_has_finished():
                                      return_intermediate_dec=True, use_bias_attn_module=True, attn_bias=True, max_hops=4),
                     share_kpt_branch=False, num_decoder_layer=3,
                     positional_encoding=dict(type="SinePositionalEncoding", num_feats=128, normalize=True),
-                    skeleton_head=dict(type="SkeletonPredictor", learn_skeleton=True), learn_skeleton=True,
+                    skeleton_head=dict(type="SkeletonPredictor", learn_skeleton=True, dim_feedforward=synth.ARCHS[arch]["C"]), learn_skeleton=True,
                     masked_supervision=True, masking_ratio=0.5, model_freeze="skeleton")
     model = EdgeCape(keypoint_head=head_cfg, encoder_config=dict(), train_cfg=dict(), test_cfg=dict(flip_test=False), pretrained=arch,
                      backbone_precision="fp16", head_precision="mixed")
