@@ -51,6 +51,13 @@ struct ChainP {
   // v_mfma_f32_16x16x32_f16 per product.  Half the weight bytes - which is what bounds the kernel - and a third of the MFMAs.
   int h1 = 0;
   ChainStage st[CH_MAX_STAGES];
+  // Row compaction (round 4): the chain is row-wise, and all MASKED keypoint tokens of a sample are identical rows in the reference
+  // (head.py:187 multiplies the pooled support features by mask_s; adjacency rows / columns and key masks of masked tokens are
+  // zeroed, skeleton.py:186-189), 62 % of the token rows on average.  With a plan (ec_ops.hip rowplan): slab row i of the launch
+  // is token row rowmap[i], i < *n_active - every valid token plus ONE representative masked token per sample; workgroups past
+  // *n_active leave at once.  The masked rows that were not computed are filled in by bcast_rows (ec_ops.h) right behind the launch.
+  const int* rowmap = nullptr;
+  const int* n_active = nullptr;
   int trace_stage = -1;        // TRACE: stage whose K loop / epilogue is stamped finely into trace[64..127]
   unsigned* trace = nullptr;   // EC_CHAIN_TRACE=1 (debug instantiation): s_memtime stamps of one mid-grid workgroup's wave 0
 };

@@ -85,6 +85,18 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
   const int lrow = lane & 15, lq = lane >> 4;
   const bool h1 = p.h1 != 0;
   float* const red = (float*)smem;
+  // Row compaction (ChainP::rowmap): slab row r is token row grow(r); rows at or past n_rows are computed on a duplicate of the last
+  // row and never stored (as the edge rows of the last slab always were).  The map of the slab's 32 rows sits in LDS behind the
+  // LayerNorm / keypoint-tail scratch (first read behind a stage's opening barrier); this lane's own two rows also in registers
+  // (the first stage's residual is requested before any barrier).
+  const int n_rows = p.n_active ? min(*p.n_active, p.rows) : p.rows;
+  if (row0 >= n_rows) return;                       // whole workgroup, before any barrier
+  int* const rowm = (int*)(smem + 3072);            // [32] (CH_RED = 4096: LayerNorm partials 0..2047, keypoint tail ..2303)
+  auto map_row = [&](int i) { const int c = min(i, n_rows - 1); return p.rowmap ? p.rowmap[c] : c; };
+  if (tid < CH_BM) rowm[tid] = map_row(row0 + tid);
+  int grow_l[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) grow_l[mi] = map_row(row0 + mi * 16 + lrow);
 
   f32x4 keep[2][2];
 #pragma unroll
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
         const f32x4 bias = pbias[j];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
-          const int gr = min(row0 + mi * 16 + lrow, p.rows - 1);
+          const int gr = grow_l[mi];
           f32x4 v = acc[mi][j] + bias;
           if (S.table) v += *(const f32x4*)(S.table + (long)(gr % S.period) * S.ldt + n);
           if (S.act == ACT_RELU) {
@@ -295,13 +307,13 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
           const int r = tid >> 1, c = tid & 1;
           const float* q = red + c * 256 + r * 8;
           const float dl = (((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]))) + S.kp_b[c];
-          const int gr = min(row0 + r, p.rows - 1);
+          const int gr = rowm[r];
           float x = S.kp_prev[(long)gr * 2 + c];   // inverse_sigmoid, eps 1e-3 (head.py:27-31)
           x = fminf(fmaxf(x, 0.f), 1.f);
           const float z = dl + logf(fmaxf(x, 1e-3f) / fmaxf(1.f - x, 1e-3f));
           const float bn = 1.f / (1.f + expf(-z));
           coord[r * 2 + c] = bn;
-          if (row0 + r < p.rows && part == 0) S.kp_next[(long)(row0 + r) * 2 + c] = bn;
+          if (row0 + r < n_rows && part == 0) S.kp_next[(long)gr * 2 + c] = bn;
         }
         __syncthreads();
         if (kp_sine) {   // sine embedding of b_next -> the operand buffer of the next stage (positional_encoding.py; sincos_kernel)
@@ -331,8 +343,8 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
         for (int mi = 0; mi < 2; ++mi) {
           const int r = mi * 16 + lrow;
           if (S.post_table)   // (encoder: src = norm2(..) + pos is what the next layer's q, k AND v read, encoder_decoder.py:461-470)
-            acc[mi][j] += *(const f32x4*)(S.post_table + (long)(min(row0 + r, p.rows - 1) % S.post_period) * S.ldpt + n);
-          if (store_out && row0 + r < p.rows) *(f32x4*)(S.out + (long)(row0 + r) * S.ldo + n) = acc[mi][j];
+            acc[mi][j] += *(const f32x4*)(S.post_table + (long)(grow_l[mi] % S.post_period) * S.ldpt + n);
+          if (store_out && row0 + r < n_rows) *(f32x4*)(S.out + (long)grow_l[mi] * S.ldo + n) = acc[mi][j];
           if (S.s_off >= 0 && !kp_sine) {
             char* dst = smem + S.s_off + r * ((long)S.N * 4 + 16) + (n >> 5) * 128 + (n & 31) * 2;
             if (h1) {
@@ -375,7 +387,7 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)   // (LayerNorm stages, N = 256: every wave has its two fragments)
-          presid[mi][j] = *(const f32x4*)(S.resid + (long)min(row0 + mi * 16 + lrow, p.rows - 1) * S.ldr + (wave * 2 + j) * 16 + lq * 4);
+          presid[mi][j] = *(const f32x4*)(S.resid + (long)grow_l[mi] * S.ldr + (wave * 2 + j) * 16 + lq * 4);
     }
     __syncthreads();   // every wave is done with the previous stage's operand buffers (this stage may re-stage one of them)
     stamp();   // barrier passed
@@ -391,7 +403,7 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
         for (int u = 0; u < 4; ++u) {
           const int idx = min(base + u * 512, total - 1);
           r[u] = idx / q4; c[u] = (idx - r[u] * q4) << 2;
-          const int gr = min(row0 + r[u], p.rows - 1);   // rows past the edge: duplicated, computed, never stored
+          const int gr = rowm[r[u]];   // rows past the edge: duplicated, computed, never stored
           v[u] = *(const f32x4*)(S.g_in + (long)gr * S.ld_in + c[u]);
         }
 #pragma unroll

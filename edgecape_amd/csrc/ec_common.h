@@ -90,7 +90,10 @@ template <bool F16> __device__ __forceinline__ u32x2_t pack4_h(f32x4 v) {
 // hardware clamps an overflowing fp16 conversion result to +-65504 itself, keeps true infinities and NaN (probed on gfx950:
 // tools/fp16_ovfl_probe.hip, profiles/r04_fp16_ovfl_probe.txt) - the saturation costs no instruction at all.  Used by the 8-phase
 // GEMM, whose epilogues are VALU-bound (v_med3 + v_fma per value measured +1.5 % on the QKV launch, profiles/r04_sat_ab.txt).
-__device__ __forceinline__ void fp16_ovfl_mode() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }   // hwreg(HW_REG_MODE, 23, 1) = 1
+// The bit is switched on for the conversion passes ONLY (the GEMM: around a tile's epilogue): with it set for the whole kernel a NaN
+// activation no longer came out as NaN (tests/test_gpu_ops.py::test_linear_h16_fp16_nan_in_nan_out) - the mode is not confined to
+// conversions.
+template <int ON> __device__ __forceinline__ void fp16_ovfl_mode() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), ON); }   // hwreg(HW_REG_MODE, 23, 1) = ON
 template <bool F16> __device__ __forceinline__ u32x2_t pack4_h_ovfl(f32x4 v) {
   if constexpr (F16) return __builtin_bit_cast(u32x2_t, __builtin_convertvector(v, f16x4));
   else {

@@ -157,9 +157,14 @@ __device__ __forceinline__ void g8_epilogue_generic(const GemmP& p, f32x4 (&acc)
 //   (row m0 + wr*128 + mi*16 + (lane>>3), column n0 + wc*64 + (lane&7)*8); col_ok: this lane's 8 columns are inside N.
 //   trow (G8_TAB_* kinds): this lane's row of the table, at the wave's first column (table + (m % period) * ldt + n0 + wc*64); ncols: how
 //   many of the wave's 64 columns lie inside N (a multiple of 16: a lane's four columns are all inside or all outside).
+//   Bias kinds (G8_BIAS_BF16 / G8_SCALE_BF16 / G8_GELU_BF16, round 4): the accumulators START from the bias - they are initialised with the
+//   tile's bias slice instead of zero (the MFMA chain adds the products on top), so a piece neither adds the bias nor zeroes its
+//   registers: it re-loads them with the NEXT tile's slice `bias_next` (staged a whole tile ahead) by four ds_read_b128 - per value one
+//   packed add and one move fewer on the VALU, which is what bounds the epilogue.
 template <int KIND, bool F16, int LAB>
 __device__ __forceinline__ void g8_piece(f32x4 (&a)[4], const __amdgpu_buffer_rsrc_t rsC, unsigned goff, unsigned ldc2, bool col_ok, char* stg,
-                                         const char* bias_lds, const char* gam_lds, int lane, const float* trow = nullptr, int ncols = 64) {
+                                         const char* bias_lds, const char* gam_lds, int lane, const float* trow = nullptr, int ncols = 64,
+                                         const char* bias_next = nullptr) {
   const int wrow = lane & 15, wq = lane >> 4;                       // writer: fragment row, column quad
   const int rrow = lane >> 3, rch = lane & 7;                       // reader: row within 8, 16-byte chunk
   if constexpr (KIND == G8_TAB_F32) {
@@ -203,8 +208,8 @@ __device__ __forceinline__ void g8_piece(f32x4 (&a)[4], const __amdgpu_buffer_rs
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
     const int c0 = (ni >> 1) * 32 + (ni & 1) * 16 + wq * 4;         // first of this lane's 4 columns inside the wave's 64
-    f32x4 v = a[ni] + *(const f32x4*)(bias_lds + c0 * 4);
-    if constexpr (KIND == G8_TAB_H16) v += tb[ni];
+    f32x4 v = a[ni];
+    if constexpr (KIND == G8_TAB_H16) v += *(const f32x4*)(bias_lds + c0 * 4) + tb[ni];
     if constexpr (KIND == G8_GELU_BF16) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = gelu_fast8<F16>(v[e]);
@@ -212,7 +217,8 @@ __device__ __forceinline__ void g8_piece(f32x4 (&a)[4], const __amdgpu_buffer_rs
     if constexpr (KIND == G8_SCALE_BF16) v *= *(const f32x4*)(gam_lds + c0 * 4);
     const int chunk = (ni >> 1) * 4 + (ni & 1) * 2 + (wq >> 1);
     *(u32x2*)(stg + wrow * 128 + ((chunk ^ (wrow & 7)) << 4) + (wq & 1) * 8) = pack4_h_ovfl<F16>(v);   // 2 x v_cvt_pk (RNE)
-    a[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (KIND == G8_TAB_H16) a[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    else a[ni] = *(const f32x4*)(bias_next + c0 * 4);
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -234,20 +240,20 @@ __device__ __forceinline__ void g8_piece(f32x4 (&a)[4], const __amdgpu_buffer_rs
 //   column n0 + wc*64 + (lane >> 4 & 1) * 16 + (lane >> 5) * 8); col_ok0 / col_ok1: the lane's 8 columns of pair 0 / 1 are inside N.
 template <int KIND, bool F16, int LAB>
 __device__ __forceinline__ void g8_piece_reg(f32x4 (&a)[4], const __amdgpu_buffer_rsrc_t rsC, unsigned goff, bool col_ok0, bool col_ok1,
-                                             const char* bias_lds, const char* gam_lds, int lane) {
+                                             const char* bias_next, const char* gam_lds, int lane) {
   const int wq = lane >> 4;
   u32x2 pk[4];
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
     const int c0 = (ni >> 1) * 32 + (ni & 1) * 16 + wq * 4;
-    f32x4 v = a[ni] + *(const f32x4*)(bias_lds + c0 * 4);
+    f32x4 v = a[ni];                                      // (the accumulators started from the bias: see g8_piece)
     if constexpr (KIND == G8_GELU_BF16) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = gelu_fast8<F16>(v[e]);
     }
     if constexpr (KIND == G8_SCALE_BF16) v *= *(const f32x4*)(gam_lds + c0 * 4);
     pk[ni] = pack4_h_ovfl<F16>(v);
-    a[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    a[ni] = *(const f32x4*)(bias_next + c0 * 4);
   }
 #pragma unroll
   for (int pr = 0; pr < 2; ++pr) {
@@ -298,7 +304,6 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   // 128-byte lines per store: the bias / LayerScale kinds are bound by the stores themselves, QKV 64.6 vs 66.4 us); LAB & 128 flips it.
   constexpr bool REGEPI = (KIND == G8_GELU_BF16) != ((LAB & 128) != 0);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if constexpr (F16) fp16_ovfl_mode();   // fp16 outputs saturate at +-65504 in the conversion itself (pack4_h_ovfl; ec_common.h)
   constexpr bool FAST = KIND != G8_GENERIC && !(LAB & 32);   // bias from LDS, epilogue pieces through the staging slot
   constexpr bool NODRAIN = FAST && !(LAB & 64);              // the load stream is not drained at the seam
   constexpr int NB = KIND == G8_SCALE_BF16 ? 2 : 1;          // LDS-DMA pieces of one bias (+ LayerScale) slice
@@ -465,11 +470,17 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   const char* b_base = smem + rd_off + wc * 4096 + G8_HALF;      // row-groups 2*wc.. of the B halves (B-h0 is slot 1)
   char* const stg = smem + G8_STAGE + wave * 2048;
 
+  // Bias kinds: the accumulators start from the first tile's bias slice (parity 0: landed behind the prologue's vmcnt(0), staged by
+  // this wave itself), every later tile's from the slice its predecessor's epilogue loads (g8_piece)
+  constexpr bool BIASACC = FAST && (KIND == G8_BIAS_BF16 || KIND == G8_SCALE_BF16 || KIND == G8_GELU_BF16);
   f32x4 acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (BIASACC) acc[i][j] = *(const f32x4*)(smem + G8_BIAS + wave * 256 + ((j >> 1) * 32 + (j & 1) * 16 + (lane >> 4) * 4) * 4);
+      else acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   bf16x8 af[4][2], b0[2][2], b1[2][2];
 
   const unsigned ldc2 = (unsigned)p.ldc * (KIND == G8_TAB_F32 ? 4u : 2u);   // row pitch of C in bytes
@@ -478,6 +489,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
     if constexpr (FAST) {
       const int lane = g8_lane_now();                      // (shadows the kernel's: see g8_lane_now)
       const char* bl = smem + G8_BIAS + (par * 8 + wave) * 256;
+      const char* bn = smem + G8_BIAS + ((par ^ 1) * 8 + wave) * 256;     // the next tile's slice (staged a tile ahead)
       const char* gl = smem + G8_GAMMA + (par * 8 + wave) * 256;
       if constexpr (REGEPI) {
         const int cq = ((lane >> 4) & 1) * 16 + (lane >> 5) * 8;          // first of the lane's 8 columns inside a 32-column pair
@@ -486,7 +498,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
         for (int d = 0; d < 2; ++d) {
           const int r0 = m0 + wr * 128 + (mi0 + d) * 16 + (lane & 15);
           const unsigned goff = (unsigned)r0 * ldc2 + (unsigned)(n0 + wc * 64 + cq) * 2u;
-          g8_piece_reg<KIND == G8_GENERIC ? G8_BIAS_BF16 : KIND, F16, LAB>(acc[mi0 + d], rsC, goff, ok0, ok1, bl, gl, lane);
+          g8_piece_reg<KIND == G8_GENERIC ? G8_BIAS_BF16 : KIND, F16, LAB>(acc[mi0 + d], rsC, goff, ok0, ok1, bn, gl, lane);
         }
       } else {
         const bool col_ok = n0 + wc * 64 + (lane & 7) * 8 < p.N;
@@ -499,7 +511,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
             const float* trow = p.table + (long)((r0 + (lane & 15)) % p.period) * p.ldt + n0 + wc * 64;
             g8_piece<KIND, F16, LAB>(acc[mi0 + d], rsC, goff, ldc2, col_ok, stg, bl, gl, lane, trow, min(max(p.N - n0 - wc * 64, 0), 64));
           } else {
-            g8_piece<KIND == G8_GENERIC ? G8_BIAS_BF16 : KIND, F16, LAB>(acc[mi0 + d], rsC, goff, ldc2, col_ok, stg, bl, gl, lane);
+            g8_piece<KIND == G8_GENERIC ? G8_BIAS_BF16 : KIND, F16, LAB>(acc[mi0 + d], rsC, goff, ldc2, col_ok, stg, bl, gl, lane, nullptr, 64, bn);
           }
         }
       }
@@ -642,6 +654,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
     // ---- epilogue at the end of the tile.  Both groups run it concurrently: group 0 passes the tile's last barrier first.
     if (it < 9) stamp(2 + 3 * it);
     if (wr == 0) G8_BAR();
+    if constexpr (F16) fp16_ovfl_mode<1>();   // fp16 outputs saturate at +-65504 in the conversion itself (pack4_h_ovfl; ec_common.h)
     if constexpr (KIND == G8_GENERIC) {
       g8_epilogue_generic<F16>(p, acc, m0, n0, wr, wc, lane);
 #pragma unroll
@@ -653,6 +666,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
       const int m0s = (LAB & 1024) ? 0 : m0;
       pieces(0, m0s, n0, it & 1); pieces(2, m0s, n0, it & 1); pieces(4, m0s, n0, it & 1); pieces(6, m0s, n0, it & 1);
     }
+    if constexpr (F16) fp16_ovfl_mode<0>();
     if (it < 9) stamp(3 + 3 * it);
     if (wr == 1) G8_BAR();
   }

@@ -85,6 +85,16 @@ struct ec_model {
   bool head_mixed = false;   // ... except the Linear layers of the skeleton head and the decoder layers: single-pass fp16 (GM_SPLIT1)
   bool cur_h1 = false;       // build time: the Lin being made belongs to that set
   bool head_chain = false;   // ... and the row-wise stretches of every head layer as row-chain launches (ec_chain.hip); EC_CHAIN=0: off
+  // Row compaction of the token-row chains (round 4; ec_ops.h rowplan): the chains compute the valid keypoint tokens and one
+  // representative masked token per sample, bcast_rows fills in the other masked rows.  EC_COMPACT=0: every row is computed as before.
+  struct RowPlan { int* plan = nullptr; int* rowmap = nullptr; int* csrc = nullptr; int* cdst = nullptr; int max_pairs = 0; };
+  RowPlan plan_dec, plan_skel;   // bs samples (decoder, keypoint branches) / S * bs samples (skeleton head)
+  // Measured (profiles/r04_compact_ab.txt, cfg2, interleaved): +1.5 % pairs/s through ec_forward_pipelined (5384 / 5385 / 5398 -> 5481 /
+  // 5464 / 5466: a deferred head costs the backbone beside it CU time), -0.7 % through ec_forward (4927 -> 4883 / 4901: there the head's
+  // LATENCY counts, a chain workgroup takes as long as before and every chain now drags a copy launch behind it).  So: pipelined
+  // calls only (compact_mode 1, default); EC_COMPACT=2: every call, EC_COMPACT=0: never.  Results are bit-identical either way.
+  int compact_mode = 0;
+  bool compact = false;          // ... for the call being enqueued
   // the support half of the head (pooling + SkeletonPredictor) has no query input: it runs on a side stream, concurrently
   // with input_proj / encoder / proposal generator on the caller's stream (both are small-grid, latency-bound kernels)
   hipStream_t side = nullptr;
@@ -572,6 +582,7 @@ struct LayerIO {
   float* x_alt = nullptr; long ldx_alt = 0;
   float** x_final = nullptr; long* ldx_final = nullptr;
   const float* qpe = nullptr; long ld_qpe = 0;   // main decoder: positional half of the cross-attention query (default: x + d)
+  const ec_model::RowPlan* plan = nullptr;       // row compaction of the layer's chains (nb * K token rows)
 };
 
 // K|V of the image tokens for a layer's token->image cross attention, one batch entry per sample (mem may be a strided view):
@@ -656,6 +667,9 @@ static int image_update(ec_model* m, const DecLayer& L, const float* x, long ldx
 struct ChainBuild {
   ChainP p;
   int top = CH_LDS0;
+  const ec_model::RowPlan* plan = nullptr;   // token-row chains: compute the plan's rows only, then fill in the copies (ec_ops.h rowplan)
+  ChainBuild() {}
+  explicit ChainBuild(const ec_model::RowPlan* pl) : plan(pl && pl->plan ? pl : nullptr) {}
   int buf(int k) { const int o = top; top += chain_layout_bytes(k); return o; }
   ChainStage& add() { return p.st[p.n_stages++]; }
   int run(int rows, hipStream_t st, bool may_split = false) {
@@ -663,7 +677,28 @@ struct ChainBuild {
     p.h1 = p.st[0].h1;   // one arithmetic per chain (run_chain checks that every stage was packed for it)
     // two workgroups per slab while that still fits one round of the chip and there is a stage to deal out
     p.split = (may_split && p.n_stages > 1 && ((rows + CH_BM - 1) / CH_BM) * 2 <= 256) ? 2 : 1;
-    return run_chain(p, st);
+    if (!plan) return run_chain(p, st);
+    p.rowmap = plan->rowmap; p.n_active = plan->plan;
+    RUN(run_chain(p, st));
+    // every global output of the chain: the masked rows that were not computed equal their sample's representative row
+    BcastP t;
+    auto flush = [&]() -> int {
+      const int rc = bcast_rows(t, plan->plan, plan->csrc, plan->cdst, std::min(plan->max_pairs, rows), st);
+      t = BcastP();
+      return rc;
+    };
+    for (int i = 0; i < p.n_stages; ++i) {
+      const ChainStage& S = p.st[i];
+      if (S.out) {
+        t.ptr[t.n] = S.out; t.ld[t.n] = S.ldo; t.ncols[t.n] = S.N; ++t.n;
+        if (t.n == 4) RUN(flush());
+      }
+      if (S.kp_next) {
+        t.ptr[t.n] = S.kp_next; t.ld[t.n] = 2; t.ncols[t.n] = 2; ++t.n;
+        if (t.n == 4) RUN(flush());
+      }
+    }
+    return flush();
   }
 };
 static void chain_lin(ChainStage& S, const Lin& W) { S.W = W.wc; S.bias = W.b; S.N = W.N; S.K = W.K; S.k1 = W.K; S.h1 = W.h1 ? 1 : 0; }
@@ -732,7 +767,7 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
     if (io.sa_done) EC_HIP(hipStreamWaitEvent(st, io.sa_done, 0));
     for (hipEvent_t e : io.wait_ca)
       if (e) EC_HIP(hipStreamWaitEvent(st, e, 0));
-    ChainBuild cb;
+    ChainBuild cb(io.plan);
     const int bx = chain_resid_ln(cb, att, d, L.sa_out, L.n1, xc, lxc, xo, lxo, true);
     ChainStage& Q = cb.add();
     chain_lin(Q, L.ca_q);
@@ -775,7 +810,7 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
   // ---- GCN feed-forward (encoder_decoder.py:508-524,634-637): y = conv1d(x) -> [.., 2F];
   //      z = relu(valid * y[:, :F] + adj1 @ y[:, F:]);  x = LN3(x + ffn2(z))
   if (chain) {
-    ChainBuild cb;   // x = norm2(x + choker(out_proj(att))); y = ffn1(x)
+    ChainBuild cb(io.plan);   // x = norm2(x + choker(out_proj(att))); y = ffn1(x)
     const int bx = chain_resid_ln(cb, att, E, L.ca_fold, L.n2, xc, lxc, xo, lxo, true);
     ChainStage& Y = cb.add();
     chain_lin(Y, L.ffn1);
@@ -798,7 +833,7 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
     RUN(bgemm_small(p, st));
   }
   if (chain) {
-    ChainBuild cb;   // x = norm3(x + ffn2(z)) (-> next layer's self-attention in-proj) (-> image->token K|V)
+    ChainBuild cb(io.plan);   // x = norm3(x + ffn2(z)) (-> next layer's self-attention in-proj) (-> image->token K|V)
     const bool more = (io.next_sa_in && chain_ok(*io.next_sa_in)) || (io.kvk_in_chain && chain_ok(L.i2t_kv));
     const int bx = chain_resid_ln(cb, z, F, L.ffn2, L.n3, xc, lxc, xo, lxo, more);
     if (io.next_sa_in && chain_ok(*io.next_sa_in)) {
@@ -828,13 +863,13 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
 }
 
 static int kpt_mlp(ec_model* m, const KptBranch& kb, const float* x, long ldx, int rows, const float* prev, float* out,
-                   hipStream_t st, float* t1 = nullptr, float* t2 = nullptr) {
+                   hipStream_t st, float* t1 = nullptr, float* t2 = nullptr, const ec_model::RowPlan* plan = nullptr) {
   const int d = m->d;
   static const bool kpt_chain_off = getenv("EC_KPT_CHAIN") && atoi(getenv("EC_KPT_CHAIN")) == 0;
   if (!kpt_chain_off && m->head_chain && chain_ok(kb.l0) && chain_ok(kb.l2) && chain_ok(kb.l4) && d == 256 && kb.l0.K == d &&
       kb.l0.N == d && kb.l2.K == d && kb.l2.N == d && kb.l4.K == d && kb.l4.N == d && kb.l0.h1 == kb.l2.h1 && kb.l0.h1 == kb.l4.h1) {
     // the three GELU Linear layers and the keypoint tail (kpt_out) as ONE row chain (see the decoder's helper lane)
-    ChainBuild cb;
+    ChainBuild cb(plan);
     const int b0 = cb.buf(d), b1 = cb.buf(d);
     ChainStage& S1 = cb.add();
     chain_lin(S1, kb.l0);
@@ -876,6 +911,15 @@ struct SupportState {
 // part (FULL mode of a pipelined call, see run_head): 0 everything; 1 only what reads the caller's heatmaps / masks (adjacency build,
 // pooling tap lists: no backbone output needed - enqueued BEFORE the call's backbone); 2 everything else (the pooling as a gather
 // over the tap lists).
+// Row-compaction plans of a batch (ec_ops.h rowplan) from its keypoint mask [bs, K] (non-zero = valid): the decoder's over bs samples,
+// the skeleton head's over S * bs (shot-major token rows; one shot: the same plan).
+static int build_row_plans(ec_model* m, const float* mask, int bs, int S, hipStream_t st, bool dec = true, bool skel = true) {
+  if (!m->compact) return 0;
+  if (dec || S == 1) RUN(rowplan(mask, bs, bs, m->K, m->plan_dec.plan, m->plan_dec.rowmap, m->plan_dec.csrc, m->plan_dec.cdst, st));
+  if (skel && S > 1) RUN(rowplan(mask, bs, S * bs, m->K, m->plan_skel.plan, m->plan_skel.rowmap, m->plan_skel.csrc, m->plan_skel.cdst, st));
+  return 0;
+}
+
 static int run_head_support(ec_model* m, const float* const* fs, const float* const* target_s, const float* mask_s, int bs, int S,
                             hipStream_t st, const SupportState& ss, hipEvent_t ev_sk = nullptr, int part = 0) {
   const int C = m->C, d = m->d, K = m->K, HW = m->HW, g = m->g;
@@ -893,6 +937,7 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
   const int nsk = (int)m->skel.size();
   if (part == 1) {
     RUN(adj_build(m->d_edges, m->d_off, mask_s, ss.valid, ss.kmask, ss.kmask_fixed, m->binary, m->adj_r1, bs, K, st));
+    RUN(build_row_plans(m, mask_s, bs, S, st));
     for (int s = 0; s < S; ++s)
       RUN(pool_taps(target_s[s], mask_s, 1.f / (float)S, m->tap_n + (long)s * Mk, m->tap_i + (long)s * Mk * HW, m->tap_w + (long)s * Mk * HW,
                     bs, K, m->cfg.heatmap_size, g, st));
@@ -905,6 +950,7 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
       // adjacency from the skeleton edges + key masks (skeleton.py:58-75): needs only the edges and the keypoint mask, so with the helper
       // lane it runs there FIRST, beside the pooling chain, instead of between query_proj and the first layer on the critical lane
       RUN(adj_build(m->d_edges, m->d_off, mask_s, ss.valid, ss.kmask, ss.kmask_fixed, m->binary, m->adj_r1, bs, K, s2));
+      RUN(build_row_plans(m, mask_s, bs, S, s2));
       EC_HIP(hipEventRecord(ev_adjb, s2));
     }
   }
@@ -938,7 +984,10 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
   RUN(tl_mark(m, "S.pooled", st));
   if (part == 2) {}   // (adjacency build: part 1, earlier on this stream)
   else if (ov2) EC_HIP(hipStreamWaitEvent(st, ev_adjb, 0));
-  else RUN(adj_build(m->d_edges, m->d_off, mask_s, ss.valid, ss.kmask, ss.kmask_fixed, m->binary, m->adj_r1, bs, K, st));
+  else {
+    RUN(adj_build(m->d_edges, m->d_off, mask_s, ss.valid, ss.kmask, ss.kmask_fixed, m->binary, m->adj_r1, bs, K, st));
+    RUN(build_row_plans(m, mask_s, bs, S, st));
+  }
   if (ev_sk) EC_HIP(hipEventRecord(ev_sk, st));   // support tokens + key masks are ready: the encoder may start
 
   // (3) skeleton head (skeleton.py:58-161).  Two lanes: the token path of every layer (self-attention, token->image cross
@@ -956,6 +1005,7 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
     io.x_final = &sx; io.ldx_final = &sx_ld;
     io.adj1 = m->adj_r1; io.valid = ss.valid; io.kmask_fixed = ss.kmask_fixed; io.bias = nullptr;
     io.nb = nb; io.bs = bs;
+    io.plan = m->compact ? &m->plan_skel : nullptr;
     io.update_mem = false;                       // done below, on s2
     io.kv_pre = m->s_kv; io.ld_kv_pre = 2 * m->E; io.kv16 = kv16_on(m, m->skel[i].ca_kv);
     if (ov2) {
@@ -1244,6 +1294,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
   // Now the helper chain runs on st right behind the layer, and what has slack moves to ax instead: layer l+1's self-attention
   // (its q|k|v were produced by layer l's last chain), dec_norm -> hs[l] and the output keypoint branch.
   bool sa_prelaunched = false;                // this layer's self-attention already runs on ax (ev_sa)
+  const ec_model::RowPlan* dplan = m->compact ? &m->plan_dec : nullptr;   // row compaction of the decoder's token-row chains
   for (int li = 0; li < nL; ++li) {
     const DecLayer& Ld = m->dec[li];
     float* bi = pts + (long)li * Mk * 2;
@@ -1257,6 +1308,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     io.qpe = m->d_qin + d; io.ld_qpe = 2 * d;
     io.adj1 = ss.adj1; io.valid = ss.valid; io.kmask_fixed = ss.kmask_fixed; io.bias = lbias;
     io.nb = bs; io.bs = bs; io.update_mem = false;
+    io.plan = dplan;
     io.kv_pre = m->d_kv + (long)li * 2 * E; io.ld_kv_pre = (long)nL * 2 * E;
     if (kv16_on(m, m->dec_kv_all)) {   // fp16 K|V: the layer's slice starts li * 2E fp16 elements into the row
       io.kv16 = true;
@@ -1302,7 +1354,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
       EC_HIP(hipEventRecord(ev_sa, ax));
     }
     if (kpt_chain) {
-      ChainBuild cb;
+      ChainBuild cb(dplan);
       const int b0 = cb.buf(d), b1 = cb.buf(d);
       ChainStage& S1 = cb.add();
       chain_lin(S1, kb.l0);
@@ -1327,7 +1379,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     } else if (!kpt_chain_off && li + 1 == nL) {
       // last layer: b_L = update(b_{L-1}, kpt_branch(x)) on the helper lane, dec_norm + kpt_branch(hs) beside it (one row chain each)
       RUN(ln(dx, dx_ld, hs, d, false, m->dec_norm, Mk, d, 1e-5f, last_split ? st : ax));
-      RUN(kpt_mlp(m, kb, dx, dx_ld, Mk, bi, bnext, ax));
+      RUN(kpt_mlp(m, kb, dx, dx_ld, Mk, bi, bnext, ax, nullptr, nullptr, dplan));
       RUN(mark(ev_x));
     } else {
       RUN(ln(dx, dx_ld, hs, d, false, m->dec_norm, Mk, d, 1e-5f, last_split ? st : ax));
@@ -1342,8 +1394,8 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
       }
     }
     // (7) head output of this level (head.py:216-220): kpt_branch[l](hs[l]) on top of out_points[l] = b_l
-    if (last_split) RUN(kpt_mlp(m, kb, hs, d, Mk, bi, out->output_kpts_dev + (long)li * Mk * 2, st, m->d_k3, m->d_k4));
-    else RUN(kpt_mlp(m, kb, hs, d, Mk, bi, out->output_kpts_dev + (long)li * Mk * 2, ax));
+    if (last_split) RUN(kpt_mlp(m, kb, hs, d, Mk, bi, out->output_kpts_dev + (long)li * Mk * 2, st, m->d_k3, m->d_k4, dplan));
+    else RUN(kpt_mlp(m, kb, hs, d, Mk, bi, out->output_kpts_dev + (long)li * Mk * 2, ax, nullptr, nullptr, dplan));
   }
   RUN(tl_mark(m, "A.end", ax));
   if (ovd) {
@@ -1759,6 +1811,17 @@ int ec_finalize(ec_handle m) {
   WS(d_att, Mk * E); WS(d_tmp, Mk * d); WS(d_qc, Mk * E); WS(d_kv, Mi * 2 * E * m->cfg.dec_layers); WS(d_y, Mk * 2 * Fd); WS(d_z, Mk * Fd);
   WS(d_hs, (size_t)m->cfg.dec_layers * Mk * d); WS(d_pts, (size_t)(m->cfg.dec_layers + 1) * Mk * 2); WS(d_k1, Mk * d); WS(d_k2, Mk * d); WS(d_k3, Mk * d); WS(d_k4, Mk * d);
 #undef WS
+  m->compact_mode = (m->head_chain && K <= 128) ? (getenv("EC_COMPACT") ? atoi(getenv("EC_COMPACT")) : 1) : 0;
+  if (m->compact_mode) {
+    for (int which = 0; which < 2; ++which) {
+      ec_model::RowPlan& pl = which ? m->plan_skel : m->plan_dec;
+      const size_t rows = (which ? (size_t)S : 1) * Mk;
+      if (which && S == 1) { pl = m->plan_dec; break; }   // one shot: the skeleton head's token rows are the decoder's
+      if ((rc = dalloc(m, &pl.plan, 4)) || (rc = dalloc(m, &pl.rowmap, rows)) || (rc = dalloc(m, &pl.csrc, rows)) || (rc = dalloc(m, &pl.cdst, rows))) return rc;
+      pl.max_pairs = (int)rows;
+      EC_HIP(hipMemset(pl.plan, 0, 4 * sizeof(int)));
+    }
+  }
   EC_REQUIRE(m->pg_dyn0.N <= 128, EC_ERR_ARG, "dynamic_proj_dim must be <= 128");
   {
     const char* ov = getenv("EC_OVERLAP");
@@ -1819,6 +1882,8 @@ int ec_head(ec_handle m, const float* fq, const float* const* fs, int layout, co
   RUN(check_head_args(m, bs, S, out));
   EC_REQUIRE(fq && fs && target_s && mask_s, EC_ERR_ARG, "null input");
   hipStream_t st = (hipStream_t)stream;
+  struct CScope { ec_model* m; ~CScope() { m->compact = false; } } cscope{m};
+  m->compact = m->compact_mode == 2;
   RUN(wait_pending_decoder(m, st));
   RUN(upload_edges(m, edges, off, bs, st));
   const size_t per = (size_t)bs * m->HW * m->C;
@@ -1842,8 +1907,9 @@ static int forward_impl(ec_handle m, const float* img_q, const float* const* img
   RUN(check_head_args(m, bs, S, out));
   EC_REQUIRE(img_q && img_s && target_s && mask_s, EC_ERR_ARG, "null input");
   hipStream_t st = (hipStream_t)stream;
-  struct Scope { ec_model* m; ~Scope() { m->dq_active = false; } } scope{m};
+  struct Scope { ec_model* m; ~Scope() { m->dq_active = false; m->compact = false; } } scope{m};
   m->dq_active = pipelined;
+  m->compact = m->compact_mode == 2 || (m->compact_mode == 1 && pipelined);   // row compaction of the token chains: see ec_model::compact_mode
   const bool full = pipelined && m->pipe_full && m->overlap && m->dq;
   // (FULL mode: the edge lists are only read by the adjacency build on the support lane's stream; uploading them there keeps the
   //  copy engine's hand-overs - ~50 us between two kernels - out of the caller's stream)
@@ -1928,6 +1994,8 @@ int ec_support_encode(ec_handle m, ec_support_t c, const float* const* img_s, co
   EC_REQUIRE(img_s && target_s && mask_s, EC_ERR_ARG, "null input");
   EC_REQUIRE(n_episodes > 0 && n_episodes <= c->cap && S > 0 && S <= m->cfg.max_shots, EC_ERR_ARG, "n_episodes / S exceed the configured maxima");
   hipStream_t st = (hipStream_t)stream;
+  struct CScope { ec_model* m; ~CScope() { m->compact = false; } } cscope{m};
+  m->compact = m->compact_mode == 2;
   RUN(wait_pending_decoder(m, st));
   RUN(upload_edges(m, edges, off, n_episodes, st));
   const size_t per = (size_t)n_episodes * m->HW * m->C;
@@ -1948,6 +2016,8 @@ int ec_forward_cached(ec_handle m, ec_support_t c, const float* img_q, const int
   for (int b = 0; b < bs; ++b)
     EC_REQUIRE(episode_of_query[b] >= 0 && episode_of_query[b] < c->n, EC_ERR_ARG, "episode index out of range");
   hipStream_t st = (hipStream_t)stream;
+  struct CScope { ec_model* m; ~CScope() { m->compact = false; } } cscope{m};
+  m->compact = m->compact_mode == 2;
   RUN(wait_pending_decoder(m, st));
   EC_HIP(hipMemcpyAsync(c->d_idx, episode_of_query, (size_t)bs * 4, hipMemcpyHostToDevice, st));
   RUN(run_backbone(m, &img_q, 1, bs, m->feat, st));
@@ -1961,6 +2031,7 @@ int ec_forward_cached(ec_handle m, ec_support_t c, const float* img_q, const int
   RUN(gather_rows(ws.adj1, c->ss.adj1, c->d_idx, KK, bs, 1, 0, 0, st));
   RUN(gather_rows(ws.adj_out, c->ss.adj_out, c->d_idx, 2 * KK, bs, 1, 0, 0, st));
   RUN(gather_rows(ws.attn_adj, c->ss.attn_adj, c->d_idx, KK, bs, m->cfg.max_hops + 1, (long)c->n * KK, (long)bs * KK, st));
+  RUN(build_row_plans(m, ws.valid, bs, 1, st, true, false));   // the queries' masks: valid[b] = 1 / 0 gathered from their episodes
   return join_on_error(m, run_head_query(m, m->feat, bs, st, out, ws));
 }
 

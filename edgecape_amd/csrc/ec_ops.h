@@ -76,6 +76,18 @@ int pool_apply(const int* tap_n, const int* tap_i, const float* tap_w, const flo
 // skeleton.py:171-205 — edges -> binary adjacency, validity vectors, soft-normalised adjacency
 int adj_build(const int32_t* edges, const int32_t* offsets, const float* mask_s, float* valid, uint8_t* kmask,
               uint8_t* kmask_fixed, float* binary, float* adj_r1, int bs, int K, hipStream_t st);
+// Row compaction plan of the token-row chains (ec_chain.h ChainP::rowmap; round 4).  All masked keypoint tokens of a sample are
+// identical rows throughout the head (head.py:187: pooled features * mask_s; skeleton.py:186-189 and encoder_decoder.py key masks: the
+// adjacency rows / columns and attention keys of masked tokens are zeroed), so a row-wise kernel only has to compute the valid tokens
+// and ONE masked token per sample.  For `ns` samples of K tokens, sample i using the mask row i % bs of mask_s [bs, K]:
+//   plan[0] = n_active, plan[1] = n_copy, rowmap [ns*K]: token rows to compute (sample-major, valid tokens in order, then the
+//   representative = the first masked token), copy_src / copy_dst [ns*K]: for every other masked token dst the row src it equals.
+// A sample WITHOUT a valid token keeps token 0 as a row of its own: its key 0 is un-masked (encoder_decoder.py:359-360, skeleton.py:98-99)
+// and sees a different attention bias than the other masked tokens do.
+int rowplan(const float* mask_s, int bs, int ns, int K, int* plan, int* rowmap, int* copy_src, int* copy_dst, hipStream_t st);
+// dst rows <- src rows of up to 4 fp32 tensors (row pitch ld[t] floats, ncols[t] % 4 == 0 or ncols == 2), pair list of a rowplan
+struct BcastP { float* ptr[4] = {nullptr, nullptr, nullptr, nullptr}; long ld[4] = {0, 0, 0, 0}; int ncols[4] = {0, 0, 0, 0}; int n = 0; };
+int bcast_rows(const BcastP& t, const int* plan, const int* copy_src, const int* copy_dst, int max_pairs, hipStream_t st);
 int rownorm(const float* x, float* y, int rows, int cols, hipStream_t st);
 // skeleton.py:134-161 — combine cosine similarity with the prior, soft-normalise, Markov matrix
 int adj_combine(const float* P, const float* binary, const float* valid, const float* zc_w, const float* zc_b,

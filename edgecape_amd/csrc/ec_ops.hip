@@ -427,6 +427,86 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const int32_t* edges, co
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// rowplan (ec_ops.h): ONE workgroup of 16 waves.  Pass 1: wave w counts the samples w, w + 16, ... (ballots over the K <= 128 mask
+// bits); a serial prefix over the samples by thread 0 (ns <= a few hundred: sub-microsecond against the ~5 us the launch costs);
+// pass 2: every wave writes its samples' entries.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void rowplan_kernel(const float* mask_s, int bs, int ns, int K, int* plan, int* rowmap, int* copy_src,
+                                                       int* copy_dst) {
+  extern __shared__ int pl_lds[];        // [ns] active offsets, [ns] copy offsets
+  int* a_off = pl_lds;
+  int* c_off = pl_lds + ns;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto masks = [&](int i, unsigned long long& v0, unsigned long long& v1) {
+    const float* mrow = mask_s + (long)(i % bs) * K;
+    v0 = __ballot(lane < K && mrow[lane] != 0.f);
+    v1 = __ballot(lane + 64 < K && mrow[min(lane + 64, K - 1)] != 0.f);
+    if (v0 == 0ull && v1 == 0ull) v0 = 1ull;   // no valid token: token 0 is a row of its own (see ec_ops.h)
+  };
+  for (int i = wave; i < ns; i += 16) {
+    unsigned long long v0, v1;
+    masks(i, v0, v1);
+    const int nv = __popcll(v0) + __popcll(v1);
+    if (lane == 0) {
+      a_off[i] = nv + (nv < K ? 1 : 0);          // valid tokens + one representative of the masked ones
+      c_off[i] = nv < K ? K - nv - 1 : 0;        // the other masked tokens are copies
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int a = 0, c = 0;
+    for (int i = 0; i < ns; ++i) {
+      const int na = a_off[i], nc = c_off[i];
+      a_off[i] = a; c_off[i] = c;
+      a += na; c += nc;
+    }
+    plan[0] = a; plan[1] = c;
+  }
+  __syncthreads();
+  for (int i = wave; i < ns; i += 16) {
+    unsigned long long v0, v1;
+    masks(i, v0, v1);
+    const int nv = __popcll(v0) + __popcll(v1);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // representative: the first masked token
+    const unsigned long long m0 = ~v0 & (K >= 64 ? ~0ull : ((1ull << K) - 1ull));
+    const unsigned long long m1 = K > 64 ? (~v1 & (K >= 128 ? ~0ull : ((1ull << (K - 64)) - 1ull))) : 0ull;
+    const int rep = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : -1);
+    const long base = (long)i * K;
+    const int ao = a_off[i], co = c_off[i];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int k = lane + 64 * half;
+      if (k >= K) continue;
+      const unsigned long long v = half ? v1 : v0, mk = half ? m1 : m0;
+      const int vrank = (half ? __popcll(v0) : 0) + __popcll(v & below);
+      const int mrank = (half ? __popcll(m0) : 0) + __popcll(mk & below);
+      if ((v >> lane) & 1ull) rowmap[ao + vrank] = (int)(base + k);
+      else if (k == rep) rowmap[ao + nv] = (int)(base + k);
+      else {                                  // masked, not the representative: mrank >= 1
+        copy_dst[co + mrank - 1] = (int)(base + k);
+        copy_src[co + mrank - 1] = (int)(base + rep);
+      }
+    }
+  }
+}
+
+// bcast_rows (ec_ops.h): 64 threads per (dst, src) pair, 4 pairs per block; blocks past plan[1] leave at once
+__global__ __launch_bounds__(256) void bcast_rows_kernel(BcastP t, const int* plan, const int* copy_src, const int* copy_dst) {
+  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (pair >= plan[1]) return;
+  const long src = copy_src[pair], dst = copy_dst[pair];
+  for (int i = 0; i < t.n; ++i) {
+    float* base = t.ptr[i];
+    if (t.ncols[i] & 3) {
+      if (lane < t.ncols[i]) base[dst * t.ld[i] + lane] = base[src * t.ld[i] + lane];
+      continue;
+    }
+    for (int c = lane * 4; c < t.ncols[i]; c += 256) *(f32x4*)(base + dst * t.ld[i] + c) = *(const f32x4*)(base + src * t.ld[i] + c);
+  }
+}
+
 __global__ __launch_bounds__(256) void rownorm_kernel(const float* x, float* y, int rows, int cols) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -945,6 +1025,22 @@ int adj_build(const int32_t* edges, const int32_t* offsets, const float* mask_s,
   EC_REQUIRE(K * K <= 64 * 1024, -1, "adj_build: K too large");
   hipLaunchKernelGGL(adj_build_kernel, dim3(bs, 5), dim3(256), (size_t)K * K, st, edges, offsets, mask_s, valid, kmask, kmask_fixed,
                      binary, adj_r1, K);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int rowplan(const float* mask_s, int bs, int ns, int K, int* plan, int* rowmap, int* copy_src, int* copy_dst, hipStream_t st) {
+  EC_REQUIRE(K >= 1 && K <= 128 && ns >= 1 && ns <= 8192 && bs >= 1, -1, "rowplan: K <= 128, samples <= 8192");
+  hipLaunchKernelGGL(rowplan_kernel, dim3(1), dim3(1024), (size_t)ns * 2 * sizeof(int), st, mask_s, bs, ns, K, plan, rowmap, copy_src, copy_dst);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int bcast_rows(const BcastP& t, const int* plan, const int* copy_src, const int* copy_dst, int max_pairs, hipStream_t st) {
+  if (t.n == 0 || max_pairs <= 0) return 0;
+  EC_REQUIRE(t.n <= 4, -1, "bcast_rows: at most 4 tensors");
+  for (int i = 0; i < t.n; ++i) EC_REQUIRE((t.ncols[i] % 4 == 0 && t.ld[i] % 4 == 0) || t.ncols[i] <= 64, -1, "bcast_rows: column count");
+  hipLaunchKernelGGL(bcast_rows_kernel, dim3(cdiv(max_pairs, 4)), dim3(256), 0, st, t, plan, copy_src, copy_dst);
   EC_LAUNCH_CHECK();
   return 0;
 }

@@ -6,6 +6,8 @@
   * evaluation loop (a30 - a32)    the real HIP model through apis.single_gpu_test -> evaluation.evaluate, vs the same loop over
                                    the CPU oracle's forward_test
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -164,6 +166,83 @@ def test_eval_loop_real_model_vs_oracle(tmp_path):
         assert a["bbox_ids"] == b["bbox_ids"] and a["image_paths"] == b["image_paths"] and np.array_equal(a["boxes"], b["boxes"])
         m = gt[int(a["bbox_ids"][0])]["mask"]
         assert np.abs(a["preds"][0, m, :2] - b["preds"][0, m, :2]).max() < 0.3 if m.any() else True
+
+
+_COMPACT_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from edgecape_amd import synth
+from edgecape_amd.engine import HipEngine
+arch, H, bs, S = sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+d = np.load(sys.argv[2])
+sd = synth.make_weights(arch, seed=7)
+eng = HipEngine(sd, arch=arch, image_size=H, max_batch=bs, max_shots=S, backbone_precision="fp16", head_precision="mixed")
+skel = [d["edges"][d["off"][b]:d["off"][b + 1]].tolist() for b in range(bs)]
+o = eng.forward(d["img_q"], [d["img_s%d" % s] for s in range(S)], [d["target_s%d" % s] for s in range(S)], d["mask"], skel)
+torch.cuda.synchronize()
+np.savez(sys.argv[7], **{k: o[k].cpu().numpy() for k in ("output_kpts", "initial_proposals", "similarity_map", "adj", "attn_adj", "out_points")})
+"""
+
+
+@pytest.mark.parametrize("arch,H,bs,S", [("dinov2_vits14", 224, 6, 1), ("dinov2_vits14", 224, 5, 3)])
+def test_row_compaction_bit_equal(tmp_path, arch, H, bs, S):
+    """Row compaction of the token-row chains (round 4: the chains compute the valid keypoint tokens and ONE representative masked
+    token per sample, the other masked rows are copies - exact in the reference, head.py:187, skeleton.py:186-189): every output of
+    ec_forward (EC_COMPACT=2: compaction in every call; by default only pipelined calls compact, where it pays) bit-equal to a run with
+    EC_COMPACT=0 (every row computed; a child process), on a batch with
+    the awkward masks - no valid keypoint at all (token 0 then stays a row of its own: its key is un-masked,
+    encoder_decoder.py:359-360), every keypoint valid (nothing to copy), one valid, one masked, scattered masks - and 1 / 3 shots."""
+    import subprocess
+    import sys
+    from edgecape_amd.engine import HipEngine
+    b = synth.make_pairs(bs, S, H, seed=4321, fixed_n_kp=False)
+    mask = b["target_weight_s"][0].copy()
+    for tw in b["target_weight_s"]:
+        mask = mask * tw
+    K = mask.shape[1]
+    mask[0] = 0.0                                   # no valid keypoint
+    mask[1] = 1.0                                   # all valid
+    mask[2] = 0.0; mask[2, 37] = 1.0                # one valid, in the second ballot half's neighbourhood
+    mask[3] = 1.0; mask[3, 70] = 0.0                # one masked (its own representative, nothing to copy)
+    if bs > 4:
+        rng = np.random.default_rng(5)
+        mask[4] = (rng.random((K, 1)) < 0.4).astype(np.float32)   # scattered
+    skels = [m["sample_skeleton"][0] for m in b["img_metas"]]
+    old = os.environ.get("EC_COMPACT")
+    os.environ["EC_COMPACT"] = "2"                  # compaction in EVERY call of this engine (default: pipelined calls only; read at ec_finalize)
+    try:
+        eng = HipEngine(synth.make_weights(arch, seed=7), arch=arch, image_size=H, max_batch=bs, max_shots=S, backbone_precision="fp16",
+                        head_precision="mixed")
+    finally:
+        if old is None:
+            del os.environ["EC_COMPACT"]
+        else:
+            os.environ["EC_COMPACT"] = old
+    o = eng.forward(b["img_q"], b["img_s"], b["target_s"], mask, skels)
+    torch.cuda.synchronize()
+    edges, off = eng._edges(skels, bs)
+    inp = dict(img_q=b["img_q"], mask=mask, edges=edges.reshape(-1, 2), off=off)
+    for s in range(S):
+        inp["img_s%d" % s] = b["img_s"][s]; inp["target_s%d" % s] = b["target_s"][s]
+    np.savez(tmp_path / "in.npz", **inp)
+    (tmp_path / "child.py").write_text(_COMPACT_CHILD)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, str(tmp_path / "child.py"), root, str(tmp_path / "in.npz"), arch, str(H), str(bs), str(S), str(tmp_path / "out.npz")],
+                       env=dict(os.environ, EC_COMPACT="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = np.load(tmp_path / "out.npz")
+    for k in ("output_kpts", "initial_proposals", "similarity_map", "adj", "attn_adj", "out_points"):
+        got = o[k].cpu().numpy()
+        assert np.isfinite(got).all(), k
+        assert np.array_equal(got, ref[k]), (k, float(np.abs(got - ref[k]).max()))
+    # and the masked slots of a sample are indistinguishable tokens, as in the reference (sample 0: all but token 0)
+    kp = o["output_kpts"].cpu().numpy()
+    for bi in range(bs):
+        pad = np.nonzero(mask[bi, :, 0] == 0)[0]
+        if bi == 0:
+            pad = pad[1:]
+        if len(pad) > 1:
+            assert np.abs(kp[:, bi, pad] - kp[:, bi, pad[:1]]).max() == 0.0
 
 
 def test_submit_returns_before_its_head_has_finished():
