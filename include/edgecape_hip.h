@@ -59,8 +59,9 @@ enum ec_precision {
                      encoder, proposal generator - encoder_decoder.py:91-110 is the path's one discontinuity) and in the small MLPs;
                      single-pass fp16 MFMAs (fp32 data rounded to fp16 operands, fp32 accumulate) in the Linear layers AND the
                      attentions of the skeleton head (skeleton.py:58-161) and of the decoder layers (encoder_decoder.py:584-651),
-                     whose image K|V are also stored as fp16 - all of which only move the output continuously: max |d kpt| on
-                     flip-free samples 2.8e-4 over 512 pairs, the same as with a bf16x3 head (profiles/r03_conformance_*.json) */
+                     whose image K|V are also stored as fp16 - all of which only move the output continuously: with the fp16 backbone,
+                     max |d kpt| on flip-free samples 1.65e-4 (cfg2) / 1.87e-4 (ViT-S/14 @ 224) over 512 disjoint pairs each, 13 argmax
+                     flips of ~20 000 valid keypoints on either (profiles/r04_conformance_*.json) */
 };
 enum ec_dtype { EC_DT_F32 = 0, EC_DT_F16 = 1, EC_DT_BF16 = 2, EC_DT_F64 = 3 };
 enum ec_layout { EC_LAYOUT_TOKENS = 0, EC_LAYOUT_NCHW = 1 };
