@@ -282,6 +282,7 @@ template <int N> __device__ __forceinline__ void g8_wait_vm() { asm volatile("s_
 // state, 8 no MFMAs, 32 no epilogue at all, 64 the load stream is drained at the tile seam (the round-1 seam, for A/B),
 // 512 (round 4) s_memtime stamps of one wave per wave group at the tile milestones (kernel start | per tile: K loop start, K loop
 // end, epilogue end | kernel end), kept in LDS and dumped to p.aux[blockIdx][64] at the end: the per-tile cycle ledger of DESIGN.md;
+// 4096 (round 4) the prologue waits for all five half-tiles before the first phase (the round-3 form, for A/B);
 // 2048 (round 4) no LDS fragment reads after the first K-tile pair of a workgroup (the MFMAs reuse the registers: what the ds_read
 // traffic of the partner group costs the MFMA blocks); 1024 (round 4) every tile STORES to the rows of tile row 0 (the output of a launch aliases onto 256 x N: dirty lines stay in the
 // L2s, nothing is written back in the burst): what the seam costs without the fabric write-back.
@@ -376,8 +377,10 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   int t_nxt = t_first + nslot, t_nn = t_first + 2 * nslot;
   int* const sched_lds = (int*)(smem + G8_SCHED);
   int fetch_s = 1;                              // wave 0: operand (1) and return value of the scalar atomic in flight
-  int pro_v = 0;                                // second tile of this workgroup: asked for now, handed over behind the prologue's drain
-  if (dyn && tid == 0) pro_v = __hip_atomic_fetch_add(p.sched + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int pro_s = 1;                                // second tile of this workgroup: asked for now (scalar atomic, as in the K loop: the value
+                                                // returns into an SGPR and is counted by lgkmcnt - it stays out of the vector-memory queue
+                                                // whose counted wait ends the prologue), handed over behind that wait
+  if (dyn && wave == 0) asm volatile("s_atomic_add %0, %1, 0x0 glc" : "+s"(pro_s) : "s"(p.sched + xcd) : "memory");
 
   // ---- load stream (LDS-DMA) state -------------------------------------------------------------------------------
   // wave w stages row-group w (16 rows) of every half-tile as two pieces of 8 rows (2 wave-instructions of 1 KiB).
@@ -452,9 +455,17 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   issue(rsA, vo0, lda8, 0); issue(rsB, vo1, ldb8, 1); issue(rsB, vo2, ldb8, 2); issue(rsA, vo3, lda8, 3);
   advance();
   issue(rsA, vo0, lda8, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue half-tiles have landed (this wave's part)
+  // The first phase reads stream indices 0 and 1 (A-h0, B-h0 of the first K-tile) and the bias slice: the oldest NB + 4 of the NB + 10
+  // pieces in flight.  Kinds whose seam is not drained wait for exactly those (round 4; the phases' own counted waits - "after issuing
+  // index q + 5, index q + 2 has landed" - take over from there): the MFMAs start under the rest of the cold 80 KiB burst instead of
+  // behind it (the prologue is 6 % of a QKV launch, 14 % of a proj launch: profiles/r04_g8_cycle_ledger.txt).  The generic kind's first
+  // tile has no counted waits (its seam is drained): it waits for everything.
+  if constexpr (NODRAIN && !(LAB & 4096)) g8_wait_vm<6>(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lab_steady = true;
-  if (dyn && tid == 0) sched_lds[0] = t_begin + nslot + pro_v;
+  if (dyn && wave == 0) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pro_s));
+    if (g8_lane_now() == 0) sched_lds[0] = t_begin + nslot + pro_s;
+  }
   G8_BAR();
   if (dyn) {                                         // second tile of this workgroup (fetched by thread 0 at the top)
     t_nxt = __builtin_amdgcn_readfirstlane(sched_lds[0]);
@@ -780,6 +791,10 @@ extern "C" int ec_lab_gemm8(const void* A, const void* W, const float* bias, voi
     case 1008: k = gemm8_bf16_kernel<1, 1, true, 8>; break;     // ... no MFMAs
     case 2024: k = gemm8_bf16_kernel<1, 1, true, 1024>; break;  // ... stores aliased onto tile row 0 (L2-resident)
     case 1004: k = gemm8_bf16_kernel<1, 1, true, 4>; break;     // ... no LDS-DMA in the steady state
+    case 5096: k = gemm8_bf16_kernel<1, 1, true, 4096>; break;  // ... the prologue waits for all five half-tiles (round-3 form)
+    case 6096: k = gemm8_bf16_kernel<2, 4, true, 4096>; break;  // LayerScale kind, same
+    case 7096: k = gemm8_bf16_kernel<3, 3, true, 4096>; break;  // GELU kind, same
+    case 3128: k = gemm8_bf16_kernel<3, 3, true, 128>; break;   // fp16 fc1 + GELU through the LDS staging slot (whole-line stores)
     case 3048: k = gemm8_bf16_kernel<1, 1, true, 2048>; break;  // ... no fragment reads in the steady state
     case 3052: k = gemm8_bf16_kernel<1, 1, true, 2052>; break;  // ... neither
     case 1000: k = gemm8_bf16_kernel<1, 1, true, 0>; break;     // the shipped fp16 instantiations: qkv / proj (bias)

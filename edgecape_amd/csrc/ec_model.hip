@@ -676,7 +676,9 @@ struct ChainBuild {
     p.rows = rows; p.lds_bytes = top;
     p.h1 = p.st[0].h1;   // one arithmetic per chain (run_chain checks that every stage was packed for it)
     // two workgroups per slab while that still fits one round of the chip and there is a stage to deal out
-    p.split = (may_split && p.n_stages > 1 && ((rows + CH_BM - 1) / CH_BM) * 2 <= 256) ? 2 : 1;
+    // (not under a row plan: compaction runs where the head's CU time counts, not its latency - pipelined calls - and two workgroups
+    //  per slab buy latency with duplicated work: both compute the stages that later stages read)
+    p.split = (!plan && may_split && p.n_stages > 1 && ((rows + CH_BM - 1) / CH_BM) * 2 <= 256) ? 2 : 1;
     if (!plan) return run_chain(p, st);
     p.rowmap = plan->rowmap; p.n_active = plan->plan;
     RUN(run_chain(p, st));

@@ -176,10 +176,40 @@ def make_head_weights(C=384, F_s=None, seed=1, d=256, F_d=384, prefix="keypoint_
     return {prefix + k: v for k, v in w.items()}
 
 
-def make_weights(arch="dinov2_vits14", seed=0):
+def make_weights(arch="dinov2_vits14", seed=0, outliers=False):
     C = ARCHS[arch]["C"]
     sd = make_backbone_weights(arch, seed)
     sd.update(make_head_weights(C=C, seed=seed + 1))
+    if outliers:
+        add_activation_outliers(sd, arch, seed)
+    return sd
+
+
+def add_activation_outliers(sd, arch, seed=0, prefix="encoder_query."):
+    """Give random-init backbone weights the activation statistics released DINOv2 checkpoints are known for (the checkpoints themselves
+    are unreachable offline, README.md:96 of the reference), so that the 16-bit modes are exercised on them at MODEL level:
+      * "massive activations": from block 2 on, four channels of the fp32 residual stream carry values ~ 100-200 x the typical ones
+        (a handful of fc2 rows scaled up), which every later LayerNorm then has to normalise against - the other channels of a token
+        come out an order of magnitude smaller than usual;
+      * outlier neurons in the MLP hidden layer: a few fc1 rows of every block scaled so that their pre-activations reach the
+        hundreds (fp16 range 65504: far inside; what is stressed is the uniform RELATIVE rounding across five orders of magnitude);
+      * a few LayerNorm gains of 10-15 (outlier channels of the normalised operand of the QKV / fc1 GEMMs).
+    Returns the dict (modified in place)."""
+    a = ARCHS[arch]
+    C, depth = a["C"], a["depth"]
+    rng = np.random.default_rng(seed + 7777)
+    big = rng.choice(C, 4, replace=False)
+    for i in range(depth):
+        p = f"{prefix}blocks.{i}."
+        if i == 2:
+            sd[p + "mlp.fc2.weight"][big] *= 150.0
+            sd[p + "ls2.gamma"][big] = 1.0
+        hot = rng.choice(4 * C, 6, replace=False)
+        sd[p + "mlp.fc1.weight"][hot] *= 40.0
+        sd[p + "mlp.fc2.weight"][:, hot] *= 0.05          # their contribution to the output stays ordinary
+        g = rng.choice(C, 3, replace=False)
+        sd[p + "norm1.weight"][g] *= rng.uniform(10.0, 15.0, 3).astype(np.float32)
+        sd[p + "norm2.weight"][g] *= rng.uniform(10.0, 15.0, 3).astype(np.float32)
     return sd
 
 

@@ -105,9 +105,14 @@ def dinov2_features(sd, img, heads, prefix="encoder_query.", taps=None, pos_tabl
         x = x + b("ls1.gamma") * y
         y = F.layer_norm(x, (C,), b("norm2.weight"), b("norm2.bias"), 1e-6)
         y = F.linear(y, b("mlp.fc1.weight"), b("mlp.fc1.bias"))
+        if taps is not None:   # activation statistics (tests/test_gpu_precision_modes.py: planted outliers must really be there)
+            taps["hidden_absmax"] = max(float(taps.get("hidden_absmax", 0.0)), float(y.abs().max()))
         y = F.gelu(y)
         y = F.linear(y, b("mlp.fc2.weight"), b("mlp.fc2.bias"))
         x = x + b("ls2.gamma") * y
+        if taps is not None:
+            taps["resid_absmax"] = max(float(taps.get("resid_absmax", 0.0)), float(x.abs().max()))
+            taps["resid_absmedian"] = float(x.abs().median())
         if taps is not None and i == 0:
             taps["block0"] = x.clone()
     x = F.layer_norm(x, (C,), w("norm.weight"), w("norm.bias"), 1e-6)

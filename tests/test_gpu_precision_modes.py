@@ -244,6 +244,46 @@ def test_headline_conformance_at_scale(name):
     assert g["flips_caught"] == g["flips"] and g["sample_frac"] > 0.25, g
 
 
+def test_fp16_backbone_on_outlier_activation_statistics():
+    """Model-level evidence that the fp16 backbone survives the activation statistics of released DINOv2 checkpoints (VERDICT r3
+    missing item 5; the checkpoints are unreachable offline, so the statistics are planted into random-init weights by
+    synth.add_activation_outliers: massive residual-stream channels from block 2 on, outlier neurons in every MLP hidden layer,
+    LayerNorm gains of 10-15).  ViT-S/14 @ 224, 16 pairs against the oracle on the SAME weights: the planted statistics must really be
+    there (oracle features / hidden layer, recorded in the printout), every output finite, and the continuous error of the same
+    order as on ordinary weights.  bf16x3 on the same weights stays inside the tolerance outright."""
+    from edgecape_amd.engine import HipEngine
+    from oracle import edgecape_oracle as orc   # the checker
+    arch, H, bs = "dinov2_vits14", 224, 16
+    w = synth.make_weights(arch, seed=5, outliers=True)
+    batch = synth.make_pairs(bs, 1, H, seed=5000, fixed_n_kp=False)
+    mask = batch["target_weight_s"][0].copy()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    _, out = orc.forward_test(w, batch, synth.ARCHS[arch]["heads"])
+    ref = {k: out[k].numpy() for k in ("output_kpts", "similarity_map", "adj")}
+    taps = {}
+    feat = orc.dinov2_features(w, torch.from_numpy(batch["img_q"]), synth.ARCHS[arch]["heads"], taps=taps).numpy()   # [B, C, g, g]
+    print("planted statistics (oracle): |feature| max", float(np.abs(feat).max()), "median", float(np.median(np.abs(feat))),
+          {k: v for k, v in taps.items() if isinstance(v, float)})
+    assert taps["resid_absmax"] > 50.0 * taps["resid_absmedian"] and taps["hidden_absmax"] > 100.0      # the statistics are there
+    res = {}
+    for bb, hd in (("fp16", "mixed"), ("bf16x3", "bf16x3")):
+        eng = HipEngine(w, arch=arch, image_size=H, max_batch=bs, max_shots=1, backbone_precision=bb, head_precision=hd)
+        o = eng.forward(batch["img_q"], batch["img_s"], batch["target_s"], mask, [m["sample_skeleton"][0] for m in batch["img_metas"]])
+        torch.cuda.synchronize()
+        got = {k: o[k].cpu().numpy() for k in ("output_kpts", "similarity_map", "adj")}
+        assert all(np.isfinite(v).all() for v in got.values()), (bb, hd)
+        res[bb] = stats(got, ref, mask[:, :, 0] > 0, H)
+        f = eng.backbone(batch["img_q"]).cpu().numpy()
+        res[bb]["feat_err_over_max"] = float(np.abs(f - feat).max() / np.abs(feat).max())
+        del eng
+    print("outlier statistics: fp16/mixed", res["fp16"], "\n                    bf16x3", res["bf16x3"])
+    assert res["bf16x3"]["flips"] == 0 and res["bf16x3"]["max_all"] < 1e-3
+    s = res["fp16"]
+    # observed (MI355X, round 4): residual-stream maximum 516 against a median of 1.0, hidden-layer maximum 199; fp16 / mixed: 1 flip of 520,
+    # max 3.3e-4 on the flip-free samples (1.9e-4 on ordinary weights), p99 2.2e-4; bf16x3: 6.3e-6
+    assert s["flips"] <= 2 and s["max_clean"] < 5e-4 and s["p99"] < 3.3e-4 and s["pck_vs_oracle"] >= 0.98, s
+
+
 def test_bf16_mode_cfg2_bounded():
     """bf16 backbone + bf16x3 head (the north-star's literal bf16 MFMA tiles): NOT parity-grade - 8 significand bits put the
     continuous error at the 1e-3 gate and flip ~1.3 % of the argmaxes with random weights.  Bounded here so a kernel bug cannot
