@@ -1564,7 +1564,7 @@ int ec_create(const ec_config* cfg, ec_handle* out) {
   EC_REQUIRE(cfg->embed_dim % 64 == 0 && cfg->embed_dim / cfg->num_heads == 64, EC_ERR_ARG, "backbone head dim must be 64");
   EC_REQUIRE(cfg->d_model == 256 && cfg->nhead == 8, EC_ERR_ARG, "head d_model/nhead must be 256/8");
   // K is dynamic in the reference (target_s[0].shape[1]; 100 in the test configs, the number of clicked points in the demos)
-  EC_REQUIRE(cfg->num_kpts > 0 && cfg->num_kpts <= 128, EC_ERR_ARG, "num_kpts must be within 1..128");
+  EC_REQUIRE(cfg->num_kpts > 0 && cfg->num_kpts <= 256, EC_ERR_ARG, "num_kpts must be within 1..256");   // (adjacency kernels: one K x K byte map in LDS, four columns per lane)
   EC_REQUIRE(cfg->max_hops == 4, EC_ERR_ARG, "max_hops must be 4");
   // layer counts: the workspace and the launch plans are sized from them; the helper-stream plan of the decoder carries per-layer
   // timeline names for up to 8 layers.  skel_layers >= 1: the skeleton head's image lane is joined through its first layer.

@@ -539,9 +539,9 @@ __global__ __launch_bounds__(256) void adj_combine_kernel(const float* P, const 
   for (int i = blockIdx.y * 4 + wave; i < K; i += 4 * gridDim.y) {
     const float vi = valid[b * K + i];
     const float ni = gram ? 1.f / (sqrtf(Pb[i * K + i]) + 1e-8f) : 1.f;
-    float u[2], rs = 0.f;
+    float u[4], rs = 0.f;   // K <= 256: four columns per lane
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < 4; ++t) {
       const int j = lane + t * 64;
       u[t] = 0.f;
       if (j < K) {
@@ -556,13 +556,13 @@ __global__ __launch_bounds__(256) void adj_combine_kernel(const float* P, const 
     rs = wave_sum(rs);
     float rs2 = 0.f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < 4; ++t) {
       u[t] = u[t] / (rs + 1e-8f);
       rs2 += u[t];
     }
     rs2 = wave_sum(rs2);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < 4; ++t) {
       const int j = lane + t * 64;
       if (j < K) {
         a0[i * K + j] = (i == j) ? vi : 0.f;
@@ -1053,7 +1053,7 @@ int rownorm(const float* x, float* y, int rows, int cols, hipStream_t st) {
 
 int adj_combine(const float* P, const float* binary, const float* valid, const float* zc_w, const float* zc_b, float* adj_out,
                 float* adj1, float* attn_adj, int bs, int K, hipStream_t st, int gram) {
-  EC_REQUIRE(K <= 128, -1, "adj_combine: K must be <= 128");
+  EC_REQUIRE(K <= 256, -1, "adj_combine: K must be <= 256");
   hipLaunchKernelGGL(adj_combine_kernel, dim3(bs, (K + 3) / 4), dim3(256), 0, st, P, binary, valid, zc_w, zc_b, adj_out, adj1, attn_adj, bs, K, gram);
   EC_LAUNCH_CHECK();
   return 0;

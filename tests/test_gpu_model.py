@@ -237,6 +237,30 @@ def _fwd(eng, batch):
     return {k: v.cpu().numpy() for k, v in o.items() if isinstance(v, torch.Tensor)}, mask[:, :, 0] > 0
 
 
+@pytest.mark.parametrize("K,n_kp", [(7, 7), (150, 131), (256, 40)])
+def test_dynamic_keypoint_count_vs_oracle(K, n_kp):
+    """The reference takes any number of keypoint slots (head.py:175-184; the demo passes the number of clicked points,
+    gradio_utils/utils.py:142-148); VERDICT r3 missing item 4: K up to 256 (was 128).  ViT-S/14 @ 224, 2 pairs, exact-fp32 engine
+    against the oracle: a handful of slots, 150 (not a multiple of 4: the scalar tail of the attention-bias loads; 131 valid) and
+    256 (the adjacency kernels' limit), plus the bench's default precision on the same pairs."""
+    from oracle import edgecape_oracle as orc
+    arch, H, bs = "dinov2_vits14", 224, 2
+    sd = synth.make_weights(arch, seed=21)
+    batch = synth.make_pairs(bs, 1, H, seed=1234 + K, n_kp=n_kp, K=K)
+    _, out = orc.forward_test(sd, batch, synth.ARCHS[arch]["heads"])
+    ref = {k: out[k].numpy() for k in ("output_kpts", "similarity_map", "adj", "initial_proposals")}
+    for prec, tol in ((dict(), 1e-4), (dict(backbone_precision="fp16", head_precision="mixed"), 1e-3)):
+        eng = _engine(sd, arch, H, bs, 1, num_kpts=K, **prec)
+        got, valid = _fwd(eng, batch)
+        assert got["output_kpts"].shape == (3, bs, K, 2) and got["adj"].shape == (bs, 2, K, K)
+        flips = (got["similarity_map"].reshape(bs, K, -1).argmax(-1) != ref["similarity_map"].reshape(bs, K, -1).argmax(-1))[valid].sum()
+        err = np.abs(got["output_kpts"] - ref["output_kpts"])[:, valid].max()
+        print("K", K, prec or "fp32", "kpt err", err, "adj err", np.abs(got["adj"] - ref["adj"]).max(), "flips", flips)
+        assert flips == 0 and err < tol
+        assert np.abs(got["adj"] - ref["adj"]).max() < 1e-4
+        del eng
+
+
 def test_forward_vs_oracle_5shot_vitb_256():
     """BASELINE config 4 shape (5 support images per query, ViT-B/14 @256) at a batch the CPU oracle finishes in seconds:
     support-stack pooling (mean over shots), per-shot skeleton refinement, mask = product of the shots' weights."""

@@ -3,7 +3,7 @@
 # configuration, the bench lines (headline + BASELINE configs 4 / 5 + the reference's shipped ViT-S configuration, each WITH the CPU
 # baseline / parity sample and with `traffic` from the PMC summary of the same library), rocprofv3 kernel trace + stats.
 #   usage: bash tools/gpu_round_end.sh <tag> [--no-tests]   -> gpurun_out/<tag>/...   (copy what should be judged into profiles/)
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT $OUT/pmc

@@ -14,7 +14,9 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-template <int M, int F, int P, int E, int SPLIT>
+// X (round 4): groups of the transcendental-free exp2 the attention softmax could use instead of v_exp_f32 - per score
+//   x = fma(s, c, -m); i = cvt_flr_i32(x); r = fract(x); p = ((c3 r + c2) r + c1) r + 1; e = ldexp(p, i)   (7 plain VALU instructions)
+template <int M, int F, int P, int E, int SPLIT, int X = 0>
 __global__ void probe(float* out, unsigned* cyc, int iters) {
   f32x16 acc[2];
   for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
@@ -43,6 +45,16 @@ __global__ void probe(float* out, unsigned* cyc, int iters) {
         if (k < F) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[k & 7]) : "v"(c1), "v"(c2));
         if (k < -F) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(f[k & 7]));   // F < 0: one-source filler
         if (k < P) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(pk[k & 7]) : "v"(p1), "v"(p2));
+        if (k < X) {
+          float x, r, pp; int xi;
+          asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(x) : "v"(f[k & 7]), "v"(c1), "v"(c2));
+          asm volatile("v_cvt_flr_i32_f32 %0, %1" : "=v"(xi) : "v"(x));
+          asm volatile("v_fract_f32 %0, %1" : "=v"(r) : "v"(x));
+          asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(pp) : "v"(r), "v"(c2), "v"(c1));
+          asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(pp) : "v"(r), "v"(c1));
+          asm volatile("v_fma_f32 %0, %0, %1, 1.0" : "+v"(pp) : "v"(r));
+          asm volatile("v_ldexp_f32 %0, %1, %2" : "=v"(f[k & 7]) : "v"(pp), "v"(xi));
+        }
       }
     }
   }
@@ -55,15 +67,15 @@ __global__ void probe(float* out, unsigned* cyc, int iters) {
   if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) atomicMax(cyc, t1 - t0);
 }
 
-template <int M, int F, int P, int E, int SPLIT>
+template <int M, int F, int P, int E, int SPLIT, int X = 0>
 void run(float* out, unsigned* cyc, const char* tag) {
   const int iters = 2000;
-  printf("%-34s M=%d F=%2d P=%2d E=%2d split=%d :", tag, M, F, P, E, SPLIT);
+  printf("%-34s M=%d F=%2d P=%2d E=%2d X=%2d split=%d :", tag, M, F, P, E, X, SPLIT);
   for (int waves : {4, 8, 12}) {   // per CU: 1, 2, 3 waves per SIMD
     unsigned best = ~0u;
     for (int rep = 0; rep < 3; ++rep) {
       CK(hipMemset(cyc, 0, 4));
-      hipLaunchKernelGGL((probe<M, F, P, E, SPLIT>), dim3(256), dim3(waves * 64), 0, 0, out, cyc, iters);
+      hipLaunchKernelGGL((probe<M, F, P, E, SPLIT, X>), dim3(256), dim3(waves * 64), 0, 0, out, cyc, iters);
       CK(hipDeviceSynchronize());
       unsigned h;
       CK(hipMemcpy(&h, cyc, 4, hipMemcpyDeviceToHost));
@@ -103,5 +115,15 @@ int main() {
   run<8, 16, 16, 16, 0>(out, cyc, "8 MFMA then 16f 16p 16e");
   run<8, 16, 16, 16, 1>(out, cyc, "8 x (MFMA + 2f 2p 2e)");
   run<8, 24, 8, 16, 1>(out, cyc, "8 x (MFMA + 3f 1p 2e)");
+  // round 4: how much PLAIN vector work hides under the MFMAs, and the transcendental-free exp2
+  run<1, 16, 0, 0, 0>(out, cyc, "MFMA + 16 fma");
+  run<1, 20, 0, 0, 0>(out, cyc, "MFMA + 20 fma");
+  run<1, 24, 0, 0, 0>(out, cyc, "MFMA + 24 fma");
+  run<0, 0, 0, 0, 0, 2>(out, cyc, "2 poly-exp2 groups (14 VALU)");
+  run<1, 0, 0, 0, 0, 2>(out, cyc, "MFMA + 2 poly-exp2 groups");
+  run<1, 6, 0, 0, 0, 2>(out, cyc, "MFMA + 2 poly-exp2 + 6 fma");
+  run<1, 6, 0, 2, 0>(out, cyc, "MFMA + 2 exp + 6 fma");
+  run<8, 48, 0, 0, 1, 16>(out, cyc, "8 x (MFMA + 2 poly-exp2 + 6 fma)");
+  run<8, 48, 0, 16, 1>(out, cyc, "8 x (MFMA + 2 exp + 6 fma)");
   return 0;
 }
