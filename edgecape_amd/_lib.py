@@ -14,7 +14,7 @@ from . import build as _build
 _LIB = None
 
 EC_F32, EC_BF16, EC_BF16X3, EC_F16, EC_MIXED = 0, 1, 2, 3, 4
-EC_ABI_VERSION = 3   # include/edgecape_hip.h EC_ABI_VERSION: bumped whenever a struct layout or a signature changes
+EC_ABI_VERSION = 4   # include/edgecape_hip.h EC_ABI_VERSION: bumped whenever a struct layout or a signature changes
 EC_DT_F32, EC_DT_F16, EC_DT_BF16, EC_DT_F64 = 0, 1, 2, 3
 EC_LAYOUT_TOKENS, EC_LAYOUT_NCHW = 0, 1
 
@@ -27,7 +27,7 @@ class EcConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "embed_dim", "depth", "num_heads", "image_size", "patch", "num_kpts", "d_model", "nhead", "enc_layers",
         "dec_layers", "skel_layers", "ffn_dim", "skel_ffn_dim", "max_hops", "heatmap_size", "max_shots", "max_batch",
-        "backbone_precision", "head_precision")]
+        "backbone_precision", "head_precision", "image_width")]
 
 
 class EcOutputs(C.Structure):

@@ -75,7 +75,8 @@ using namespace ec;
 
 struct ec_model {
   ec_config cfg;
-  int g = 0, HW = 0, T = 0, C = 0, K = 0, d = 0, L = 0, E = 0;
+  int gh = 0, gw = 0, HW = 0, T = 0, C = 0, K = 0, d = 0, L = 0, E = 0;   // token grid gh rows x gw columns (H / 14, W / 14: floor), HW = gh * gw
+  int H = 0, W = 0;                                                       // input height / width (ec_config::image_size / image_width)
   int Kp = 640;  // padded im2col width (588 -> 640: multiple of 128 bytes for fp32 and bf16)
   bool finalized = false;
   bool bb16 = false;         // backbone GEMM operands / activations are 16-bit ...
@@ -318,16 +319,16 @@ static std::vector<float> host_nt(const float* A, long lda, const float* B, long
 }
 
 // SinePositionalEncoding.forward on an all-False mask (positional_encoding.py:57-94) -> [HW, 2*nf] token-major
-static std::vector<float> sine_table(int g, int nf, std::vector<float>* dim_t_out) {
+static std::vector<float> sine_table(int gh, int gw, int nf, std::vector<float>* dim_t_out) {
   std::vector<float> dim_t(nf);
   for (int i = 0; i < nf; ++i) dim_t[i] = powf(10000.f, (float)(2 * (i / 2)) / (float)nf);
   const float scale = 2.f * (float)M_PI;
-  std::vector<float> t((size_t)g * g * 2 * nf);
-  for (int y = 0; y < g; ++y)
-    for (int x = 0; x < g; ++x) {
-      const float ye = (float)(y + 1) / ((float)g + 1e-6f) * scale;
-      const float xe = (float)(x + 1) / ((float)g + 1e-6f) * scale;
-      float* o = &t[((size_t)y * g + x) * 2 * nf];
+  std::vector<float> t((size_t)gh * gw * 2 * nf);
+  for (int y = 0; y < gh; ++y)
+    for (int x = 0; x < gw; ++x) {
+      const float ye = (float)(y + 1) / ((float)gh + 1e-6f) * scale;   // cumsum over rows / (last row + eps)
+      const float xe = (float)(x + 1) / ((float)gw + 1e-6f) * scale;
+      float* o = &t[((size_t)y * gw + x) * 2 * nf];
       for (int i = 0; i < nf; ++i) {
         const float ay = ye / dim_t[i], ax = xe / dim_t[i];
         o[i] = (i & 1) ? cosf(ay) : sinf(ay);
@@ -464,7 +465,7 @@ static int ln(const float* x, long ldx, void* y, long ldy, int y16, const Norm& 
 // gathered by the im2col step so that the whole ViT runs ONCE over n = n_src * n_each images (one large-M GEMM
 // per layer instead of 1+S smaller ones).
 static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_each, float* feat_out, hipStream_t st) {
-  const int C = m->C, T = m->T, HW = m->HW, g = m->g, H = m->cfg.image_size;
+  const int C = m->C, T = m->T, HW = m->HW;
   const bool h16 = m->bb16;
   const int hfmt = h16 ? (m->bbf16 ? 2 : 1) : 0;   // 16-bit storage format: 0 fp32, 1 bf16, 2 fp16
   const int nh = m->cfg.num_heads;
@@ -477,7 +478,7 @@ static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_
   const bool px3 = m->patch_w16x3 != nullptr;
   const int Kpe = px3 ? 3 * m->Kp : m->Kp;
   for (int s = 0; s < n_src; ++s)
-    RUN(im2col14(imgs[s], (char*)m->bb_h + (size_t)s * n_each * T * Kpe * (h16 ? 2 : 4), px3 ? 3 : hfmt, n_each, H, g, m->Kp, st));
+    RUN(im2col14(imgs[s], (char*)m->bb_h + (size_t)s * n_each * T * Kpe * (h16 ? 2 : 4), px3 ? 3 : hfmt, n_each, m->H, m->W, m->gh, m->gw, m->Kp, st));
   {  // patch embedding: ONE GEMM over all n*T token rows (the zero cls rows produce bias + pos[0], overwritten below);
      // epilogue adds the conv bias and the positional table row m % T
     GemmP p;
@@ -924,7 +925,7 @@ static int build_row_plans(ec_model* m, const float* mask, int bs, int S, hipStr
 
 static int run_head_support(ec_model* m, const float* const* fs, const float* const* target_s, const float* mask_s, int bs, int S,
                             hipStream_t st, const SupportState& ss, hipEvent_t ev_sk = nullptr, int part = 0) {
-  const int C = m->C, d = m->d, K = m->K, HW = m->HW, g = m->g;
+  const int C = m->C, d = m->d, K = m->K, HW = m->HW, gh = m->gh, gw = m->gw;
   const int Fs = m->cfg.skel_ffn_dim, hops1 = m->cfg.max_hops + 1;
   const int Mk = bs * K, Mi = bs * HW;
   float* adj_out = ss.adj_out;
@@ -942,7 +943,7 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
     RUN(build_row_plans(m, mask_s, bs, S, st));
     for (int s = 0; s < S; ++s)
       RUN(pool_taps(target_s[s], mask_s, 1.f / (float)S, m->tap_n + (long)s * Mk, m->tap_i + (long)s * Mk * HW, m->tap_w + (long)s * Mk * HW,
-                    bs, K, m->cfg.heatmap_size, g, st));
+                    bs, K, m->cfg.heatmap_size, gh, gw, st));
     return 0;
   }
   if (ov2) {
@@ -976,9 +977,9 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
   for (int s = 0; s < S; ++s) {
     if (part == 2)
       RUN(pool_apply(m->tap_n + (long)s * Mk, m->tap_i + (long)s * Mk * HW, m->tap_w + (long)s * Mk * HW, fs[s], m->pooled,
-                     s == 0 ? 0.f : 1.f, bs, K, m->cfg.heatmap_size, g, C, st));
+                     s == 0 ? 0.f : 1.f, bs, K, m->cfg.heatmap_size, gh, gw, C, st));
     else
-      RUN(pool_gather(target_s[s], mask_s, 1.f / (float)S, fs[s], m->pooled, s == 0 ? 0.f : 1.f, bs, K, m->cfg.heatmap_size, g, C, st));
+      RUN(pool_gather(target_s[s], mask_s, 1.f / (float)S, fs[s], m->pooled, s == 0 ? 0.f : 1.f, bs, K, m->cfg.heatmap_size, gh, gw, C, st));
   }
   if (m->ev_feat_read_p) EC_HIP(hipEventRecord(m->ev_feat_read_p, st));
   RUN(linear(m->pooled, C, false, m->query_proj, ss.sk, d, false, Mk, ACT_NONE, st));
@@ -1094,7 +1095,7 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
 // Query half of TwoStageHead.forward (head.py:169-173, 202-222): input_proj, encoder, proposal generator, decoder, kpt branches.
 static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, const ec_outputs* out, const SupportState& ss,
                           hipEvent_t wait_sk = nullptr, hipEvent_t wait_adj = nullptr) {
-  const int C = m->C, d = m->d, E = m->E, K = m->K, HW = m->HW, L = m->L, g = m->g, nh = m->cfg.nhead;
+  const int C = m->C, d = m->d, E = m->E, K = m->K, HW = m->HW, L = m->L, nh = m->cfg.nhead;
   const int Fd = m->cfg.ffn_dim, hops1 = m->cfg.max_hops + 1;
   const int Mk = bs * K;
   float* sim = out->similarity_map_dev;
@@ -1263,7 +1264,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     p.C = sim; p.ldc = HW; p.sC = (long)K * HW; p.M = K; p.N = HW; p.K = d; p.batch = bs;
     RUN(bgemm_small(p, st));
   }
-  RUN(proposals(sim, out->initial_proposals_dev, pts, Mk, g, st));   // pts[0] = decoder proposals b_0
+  RUN(proposals(sim, out->initial_proposals_dev, pts, Mk, m->gh, m->gw, st));   // pts[0] = decoder proposals b_0
   RUN(tl_mark(m, "Q.prop", st));
 
   // (6) decoder (encoder_decoder.py:330-425): x lives as the left half of d_qin = [x | qpe].
@@ -1576,8 +1577,11 @@ int ec_create(const ec_config* cfg, ec_handle* out) {
   EC_REQUIRE(cfg->max_batch > 0 && cfg->max_shots > 0, EC_ERR_ARG, "max_batch / max_shots must be positive");
   ec_model* m = new ec_model();
   m->cfg = *cfg;
-  m->g = cfg->image_size / cfg->patch;
-  m->HW = m->g * m->g; m->T = m->HW + 1; m->C = cfg->embed_dim; m->K = cfg->num_kpts; m->d = cfg->d_model;
+  // inputs are image_size (height) x image_width pixels; image_width = 0: square.  The reference takes any img.shape[-2:]
+  // (EdgeCape.py:143); the DINOv2 patch embedding floors both
+  m->H = cfg->image_size; m->W = cfg->image_width > 0 ? cfg->image_width : cfg->image_size;
+  m->gh = m->H / cfg->patch; m->gw = m->W / cfg->patch;
+  m->HW = m->gh * m->gw; m->T = m->HW + 1; m->C = cfg->embed_dim; m->K = cfg->num_kpts; m->d = cfg->d_model;
   m->L = m->HW + m->K; m->E = 2 * m->d;
   EC_REQUIRE(cfg->backbone_precision >= EC_F32 && cfg->backbone_precision <= EC_F16, EC_ERR_ARG,
              "backbone_precision: EC_F32 (exact), EC_BF16X3 (split bf16, fp32-class), EC_BF16 or EC_F16 (16-bit MFMA operands)");
@@ -1587,7 +1591,7 @@ int ec_create(const ec_config* cfg, ec_handle* out) {
   m->head_split = cfg->head_precision == EC_BF16X3 || cfg->head_precision == EC_MIXED;
   m->head_mixed = cfg->head_precision == EC_MIXED;
   m->head_chain = m->head_split && !(getenv("EC_CHAIN") && atoi(getenv("EC_CHAIN")) == 0);
-  EC_REQUIRE(m->g >= 2 && m->g <= 32, EC_ERR_ARG, "token grid must be within 2..32");
+  EC_REQUIRE(m->gh >= 2 && m->gh <= 32 && m->gw >= 2 && m->gw <= 32, EC_ERR_ARG, "token grid must be within 2..32 in both directions");
   *out = m;
   return EC_OK;
 }
@@ -1634,7 +1638,7 @@ int ec_load_tensor(ec_handle m, const char* name, const void* host, const int64_
 
 int ec_set_pos_embed(ec_handle m, const float* table, int64_t rows, int64_t cols) {
   EC_REQUIRE(m && table, EC_ERR_ARG, "bad argument");
-  EC_REQUIRE(rows == m->T && cols == m->C, EC_ERR_ARG, "pos table must be [1+g*g, C]");
+  EC_REQUIRE(rows == m->T && cols == m->C, EC_ERR_ARG, "pos table must be [1 + gh*gw, C]");
   int64_t shape[2] = {rows, cols};
   return ec_load_tensor(m, "@pos_table", table, shape, 2, EC_DT_F32);
 }
@@ -1688,7 +1692,7 @@ int ec_finalize(ec_handle m) {
   }
   // ---------------- head
   std::vector<float> dim_t;
-  std::vector<float> pos_img = sine_table(m->g, d / 2, &dim_t);
+  std::vector<float> pos_img = sine_table(m->gh, m->gw, d / 2, &dim_t);
   if ((rc = upload(m, pos_img, &m->pos_img)) || (rc = upload(m, dim_t, &m->dim_t))) return rc;
   {
     std::vector<float> pc((size_t)L * d, 0.f);

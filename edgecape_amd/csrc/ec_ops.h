@@ -36,7 +36,7 @@ int gather_rows(float* dst, const float* src, const int32_t* idx_dev, long row, 
 int f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t st, int f16 = 0);   // f16: IEEE fp16 instead of bf16
 // src [B][L][E] fp32 -> dst [B][E][Lp] bf16 (columns >= L zeroed); test helper for the bf16 attention kernel
 int transpose_pad_bf16(const float* src, bf16_t* dst, int B, int L, int E, int Lp, hipStream_t st);
-int im2col14(const float* img, void* patches, int out_bf16, int n_img, int H, int g, int Kp, hipStream_t st);
+int im2col14(const float* img, void* patches, int out_bf16, int n_img, int H, int W, int gh, int gw, int Kp, hipStream_t st);
 int set_cls_rows(float* x, long ldx, const float* cls, const float* pos0, int n_img, int T, int C, hipStream_t st);
 int nchw_to_tokens(const float* src, float* dst, int n, int C, int HW, hipStream_t st);
 int tokens_to_nchw(const float* src, float* dst, int n, int C, int HW, hipStream_t st);
@@ -68,11 +68,11 @@ int msra_targets(const float* joints, const float* visible, float* target, float
 
 // head.py:175-184 — bilinear(g->hm) + normalised-heatmap pooling expressed as weights over the g*g cells
 int pool_gather(const float* target, const float* mask_s, float inv_shots, const float* F, float* pooled, float beta, int bs, int K,
-                int hm, int g, int C, hipStream_t st);
-int pool_taps(const float* target, const float* mask_s, float inv_shots, int* tap_n, int* tap_i, float* tap_w, int bs, int K, int hm, int g,
-              hipStream_t st);
-int pool_apply(const int* tap_n, const int* tap_i, const float* tap_w, const float* F, float* pooled, float beta, int bs, int K, int hm, int g,
-               int C, hipStream_t st);
+                int hm, int gh, int gw, int C, hipStream_t st);
+int pool_taps(const float* target, const float* mask_s, float inv_shots, int* tap_n, int* tap_i, float* tap_w, int bs, int K, int hm, int gh,
+              int gw, hipStream_t st);
+int pool_apply(const int* tap_n, const int* tap_i, const float* tap_w, const float* F, float* pooled, float beta, int bs, int K, int hm, int gh,
+               int gw, int C, hipStream_t st);
 // skeleton.py:171-205 — edges -> binary adjacency, validity vectors, soft-normalised adjacency
 int adj_build(const int32_t* edges, const int32_t* offsets, const float* mask_s, float* valid, uint8_t* kmask,
               uint8_t* kmask_fixed, float* binary, float* adj_r1, int bs, int K, hipStream_t st);
@@ -99,7 +99,7 @@ int bias_mlp_layers(const float* attn_adj, const float* const* w1, const float* 
 int bias_mlp(const float* attn_adj, const float* w1, const float* b1, const float* w2, const float* b2, float* out,
              int hops1, int hidden, int nhead, int bs, int K, hipStream_t st);
 // encoder_decoder.py:76-112 — softmax, soft-argmax, argmax 3x3 window local soft-argmax
-int proposals(const float* sim, float* prop_loss, float* prop, int rows, int g, hipStream_t st);
+int proposals(const float* sim, float* prop_loss, float* prop, int rows, int gh, int gw, hipStream_t st);
 // positional_encoding.py:96-122
 int sincos_coords(const float* coords, const float* inv_dim_t, float* out, long ldo, int rows, int num_feats, hipStream_t st);
 // head.py:216-220 / encoder_decoder.py:395-431 — Linear(d->2) + sigmoid(inverse_sigmoid(prev) + delta)

@@ -140,25 +140,25 @@ __global__ void transpose_pad_bf16_kernel(const float* src, bf16_t* dst, int L, 
   dst[(long)b * E * Lp + i] = t < L ? f2bf(src[((long)b * L + t) * E + e]) : (bf16_t)0;
 }
 
-// im2col for Conv2d(3, C, k=14, s=14) (DINOv2 PatchEmbed): patches[(n*g+py)*g+px][c*196+ky*14+kx],
-// row length Kp >= 588 (zero padded) so the GEMM K is a multiple of 128 bytes.
+// im2col for Conv2d(3, C, k=14, s=14) (DINOv2 PatchEmbed): patches[(n*gh+py)*gw+px][c*196+ky*14+kx] of an H x W image,
+// gh = H / 14, gw = W / 14 (floor: stride-14 VALID convolution), row length Kp >= 588 (zero padded) so the GEMM K is a multiple of 128 bytes.
 template <int OUT>   // 0 fp32, 1 bf16, 2 fp16, 3 fp16 split [hi | lo | hi]
-__global__ __launch_bounds__(256) void im2col14_kernel(const float* img, void* out, int H, int g, int Kp) {
+__global__ __launch_bounds__(256) void im2col14_kernel(const float* img, void* out, int H, int W, int gh, int gw, int Kp) {
   // output rows are TOKEN rows: image n owns rows n*(g*g+1) .. ; row 0 of each image (the cls token) is zero-filled so the
   // patch embedding is ONE GEMM over M = n_img * T contiguous rows (its cls rows are overwritten by set_cls_rows).
   // One workgroup per row: the 588 pixels of the patch go through LDS and leave as 16-byte stores (Kp % 8 == 0, Kp <= 1024).
   __shared__ __attribute__((aligned(16))) float px[1024];
-  const int T = g * g + 1;
+  const int T = gh * gw + 1;
   const int n = blockIdx.x / T, tok = blockIdx.x % T;
   const long orow = blockIdx.x;
   const int pp = tok - 1;
-  const int py = pp / g, pxx = pp % g;
-  const float* src = img + (long)n * 3 * H * H;
+  const int py = pp / gw, pxx = pp % gw;
+  const float* src = img + (long)n * 3 * H * W;
   for (int k = threadIdx.x; k < Kp; k += blockDim.x) {
     float v = 0.f;
     if (tok > 0 && k < 588) {
       const int c = k / 196, r = k % 196, ky = r / 14, kx = r % 14;
-      v = src[((long)c * H + (py * 14 + ky)) * H + pxx * 14 + kx];
+      v = src[((long)c * H + (py * 14 + ky)) * W + pxx * 14 + kx];
     }
     px[k] = v;
   }
@@ -246,17 +246,22 @@ __device__ inline void bilinear_src(int dst, float scale, int in_size, int& i0, 
 // call runs it BESIDE its backbone and the caller's inputs are consumed long before the caller's stream reaches the end of the call.
 template <int MODE>
 __global__ __launch_bounds__(256) void pool_gather_kernel(const float* target, const float* mask_s, float inv_shots, const float* F,
-                                                          float* pooled, float beta, int K, int hm, int g, int C, int* tap_n, int* tap_i,
-                                                          float* tap_w) {
+                                                          float* pooled, float beta, int K, int hm, int gh, int gw, int C, int* tap_n,
+                                                          int* tap_i, float* tap_w) {
+  // token grid gh rows x gw columns (round 4: the two axes have their own tap tables; a square grid gives the old arithmetic)
   extern __shared__ float sm[];
+  const int gg = gh * gw;
   float* t = sm;                       // hm*hm heatmap
-  float* tmp = t + hm * hm;            // g*hm : tmp[cy][x]
-  float* wts = tmp + g * hm;           // g*g tap weights
-  float* tl = wts + g * g;             // hm   : lambda of source coordinate
-  int* ti0 = (int*)(tl + hm);          // hm   : first target cell of source coordinate
-  int* ti1 = ti0 + hm;                 // hm   : second target cell
-  int* nzi = ti1 + hm;                 // g*g  : compacted non-zero cells
-  float* red = (float*)(nzi + g * g);  // 4 + 1 (count)
+  float* tmp = t + hm * hm;            // gh*hm : tmp[cy][x]
+  float* wts = tmp + gh * hm;          // gh*gw tap weights
+  float* tl = wts + gg;                // hm   : lambda of source ROW y
+  float* tlx = tl + hm;                // hm   : lambda of source COLUMN x
+  int* ti0 = (int*)(tlx + hm);         // hm   : first target cell row of source row y
+  int* ti1 = ti0 + hm;                 // hm   : second
+  int* tx0 = ti1 + hm;                 // hm   : first target cell column of source column x
+  int* tx1 = tx0 + hm;                 // hm   : second
+  int* nzi = tx1 + hm;                 // gh*gw: compacted non-zero cells
+  float* red = (float*)(nzi + gg);     // 4 + 1 (count)
   const int bk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = bk / K;
   float* out = pooled + (long)bk * C;
@@ -268,9 +273,9 @@ __global__ __launch_bounds__(256) void pool_gather_kernel(const float* target, c
       return;
     }
     for (int i = tid; i < n; i += 256) {
-      const int cell = tap_i[(long)bk * g * g + i];
+      const int cell = tap_i[(long)bk * gg + i];
       nzi[i] = cell;
-      wts[cell] = tap_w[(long)bk * g * g + i];
+      wts[cell] = tap_w[(long)bk * gg + i];
     }
     if (tid == 0) ((int*)red)[4] = n;
     __syncthreads();
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(256) void pool_gather_kernel(const float* target, c
     return;
   }
   const float* src = target + (long)bk * hm * hm;
-  const float scale = (float)g / (float)hm;
+  const float scale = (float)gh / (float)hm, scale_x = (float)gw / (float)hm;
   float s = 0.f;
   for (int i = tid; i < hm * hm; i += 256) {
     const float v = src[i];
@@ -295,16 +300,18 @@ __global__ __launch_bounds__(256) void pool_gather_kernel(const float* target, c
   }
   if (tid < hm) {
     int i0, i1; float l;
-    bilinear_src(tid, scale, g, i0, i1, l);
+    bilinear_src(tid, scale, gh, i0, i1, l);
     ti0[tid] = i0; ti1[tid] = i1; tl[tid] = l;
+    bilinear_src(tid, scale_x, gw, i0, i1, l);
+    tx0[tid] = i0; tx1[tid] = i1; tlx[tid] = l;
   }
   s = wave_sum(s);
   if (lane == 0) red[wave] = s;
   __syncthreads();
   const float total = red[0] + red[1] + red[2] + red[3];
-  const float inv_scale = (float)hm / (float)g;
+  const float inv_scale = (float)hm / (float)gh, inv_scale_x = (float)hm / (float)gw;
   // tmp[cy][x] = sum_y wy(cy, y) t[y][x], y ascending; only sources within one cell of cy can contribute
-  for (int idx = tid; idx < g * hm; idx += 256) {
+  for (int idx = tid; idx < gh * hm; idx += 256) {
     const int cy = idx / hm, x = idx - cy * hm;
     const int ylo = max(0, (int)((float)(cy - 1) * inv_scale) - 1), yhi = min(hm - 1, (int)((float)(cy + 2) * inv_scale) + 1);
     float acc = 0.f;
@@ -317,15 +324,15 @@ __global__ __launch_bounds__(256) void pool_gather_kernel(const float* target, c
   }
   __syncthreads();
   const float norm = msk * inv_shots / (total + 1e-8f);
-  for (int cell = tid; cell < g * g; cell += 256) {
-    const int cy = cell / g, cx = cell - cy * g;
-    const int xlo = max(0, (int)((float)(cx - 1) * inv_scale) - 1), xhi = min(hm - 1, (int)((float)(cx + 2) * inv_scale) + 1);
+  for (int cell = tid; cell < gg; cell += 256) {
+    const int cy = cell / gw, cx = cell - cy * gw;
+    const int xlo = max(0, (int)((float)(cx - 1) * inv_scale_x) - 1), xhi = min(hm - 1, (int)((float)(cx + 2) * inv_scale_x) + 1);
     float acc = 0.f;
     for (int x = xlo; x <= xhi; ++x) {
-      const float l = tl[x];
+      const float l = tlx[x];
       float w = 0.f;
-      if (ti0[x] == cx) w += 1.f - l;
-      if (ti1[x] == cx) w += l;
+      if (tx0[x] == cx) w += 1.f - l;
+      if (tx1[x] == cx) w += l;
       if (w != 0.f) acc += w * tmp[cy * hm + x];
     }
     wts[cell] = acc * norm;
@@ -333,9 +340,9 @@ __global__ __launch_bounds__(256) void pool_gather_kernel(const float* target, c
   __syncthreads();
   if (wave == 0) {   // ordered compaction of the non-zero cells
     int n = 0;
-    for (int c0 = 0; c0 < g * g; c0 += 64) {
+    for (int c0 = 0; c0 < gg; c0 += 64) {
       const int cell = c0 + lane;
-      const bool nz = cell < g * g && wts[cell] != 0.f;
+      const bool nz = cell < gg && wts[cell] != 0.f;
       const unsigned long long m = __ballot(nz);
       if (nz) nzi[n + __popcll(m & ((1ull << lane) - 1ull))] = cell;
       n += __popcll(m);
@@ -346,15 +353,15 @@ __global__ __launch_bounds__(256) void pool_gather_kernel(const float* target, c
   if constexpr (MODE == 1) {
     const int n = ((const int*)red)[4];
     for (int i = tid; i < n; i += 256) {
-      tap_i[(long)bk * g * g + i] = nzi[i];
-      tap_w[(long)bk * g * g + i] = wts[nzi[i]];
+      tap_i[(long)bk * gg + i] = nzi[i];
+      tap_w[(long)bk * gg + i] = wts[nzi[i]];
     }
     if (tid == 0) tap_n[bk] = n;
     return;
   }
   }   // MODE != 2
   const int nnz = ((const int*)red)[4];
-  const float* Fb = F + (long)b * g * g * C;
+  const float* Fb = F + (long)b * gg * C;
   for (int c = tid; c < C; c += 256) {
     float acc = 0.f;
     int i = 0;
@@ -646,11 +653,11 @@ __global__ void bias_mlp_kernel(const float* attn_adj, const float* w1, const fl
 }
 
 // ProposalGenerator tail (encoder_decoder.py:76-112): one wave per (sample, keypoint) row of the similarity map
-__global__ __launch_bounds__(256) void proposals_kernel(const float* sim, float* prop_loss, float* prop, int rows, int g) {
+__global__ __launch_bounds__(256) void proposals_kernel(const float* sim, float* prop_loss, float* prop, int rows, int gh, int gw) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const int HW = g * g;
+  const int HW = gh * gw;
   const float* s = sim + (long)row * HW;
   constexpr int MAXC = 16;  // g <= 32
   float v[MAXC];
@@ -677,20 +684,21 @@ __global__ __launch_bounds__(256) void proposals_kernel(const float* sim, float*
     se += v[t];
   }
   se = wave_sum(se);
-  // the reference reshapes the one-hot to (w, h) before the 3x3 max-pool (:93); for square maps this is the
-  // natural (row, col) = (p / g, p % g)
-  const int ar = am / g, ac = am % g;
+  // the reference reshapes the one-hot - a flat index over (h, w) - to (w, h) before the 3x3 max-pool (:93-97): the local window is
+  // taken in THAT layout, (p / h, p % h); for square maps it is the natural (row, col), for h != w it is not a spatial
+  // neighbourhood, and the reference's arithmetic is what is reproduced
+  const int ar = am / gh, ac = am % gh;
   float sx = 0.f, sy = 0.f, lx = 0.f, ly = 0.f, ls = 0.f;
 #pragma unroll
   for (int t = 0; t < MAXC; ++t) {
     const int p = lane + t * 64;
     if (p < HW) {
       const float pr = v[t] / se;
-      const int r = p / g, c = p % g;
+      const int r = p / gw, c = p % gw;
       const float gx = (float)c + 0.5f, gy = (float)r + 0.5f;
       sx += pr * gx;
       sy += pr * gy;
-      const int dr = r - ar, dc = c - ac;
+      const int dr = p / gh - ar, dc = p % gh - ac;
       if (dr >= -1 && dr <= 1 && dc >= -1 && dc <= 1) {
         ls += pr;
         lx += pr * gx;
@@ -700,11 +708,11 @@ __global__ __launch_bounds__(256) void proposals_kernel(const float* sim, float*
   }
   sx = wave_sum(sx); sy = wave_sum(sy); lx = wave_sum(lx); ly = wave_sum(ly); ls = wave_sum(ls);
   if (lane == 0) {
-    prop_loss[row * 2 + 0] = sx / (float)g;
-    prop_loss[row * 2 + 1] = sy / (float)g;
+    prop_loss[row * 2 + 0] = sx / (float)gw;
+    prop_loss[row * 2 + 1] = sy / (float)gh;
     const float d = ls + 1e-10f;
-    prop[row * 2 + 0] = (lx / d) / (float)g;
-    prop[row * 2 + 1] = (ly / d) / (float)g;
+    prop[row * 2 + 0] = (lx / d) / (float)gw;
+    prop[row * 2 + 1] = (ly / d) / (float)gh;
   }
 }
 
@@ -963,12 +971,13 @@ int transpose_pad_bf16(const float* src, bf16_t* dst, int B, int L, int E, int L
   return 0;
 }
 
-int im2col14(const float* img, void* patches, int out_bf16, int n_img, int H, int g, int Kp, hipStream_t st) {
+int im2col14(const float* img, void* patches, int out_bf16, int n_img, int H, int W, int gh, int gw, int Kp, hipStream_t st) {
   EC_REQUIRE(Kp % 8 == 0 && Kp <= 1024, -1, "im2col14: padded row length must be a multiple of 8, at most 1024");
-  if (out_bf16 == 3) hipLaunchKernelGGL(im2col14_kernel<3>, dim3(n_img * (g * g + 1)), dim3(256), 0, st, img, patches, H, g, Kp);
-  else if (out_bf16 == 2) hipLaunchKernelGGL(im2col14_kernel<2>, dim3(n_img * (g * g + 1)), dim3(256), 0, st, img, patches, H, g, Kp);
-  else if (out_bf16) hipLaunchKernelGGL(im2col14_kernel<1>, dim3(n_img * (g * g + 1)), dim3(256), 0, st, img, patches, H, g, Kp);
-  else hipLaunchKernelGGL(im2col14_kernel<0>, dim3(n_img * (g * g + 1)), dim3(256), 0, st, img, patches, H, g, Kp);
+  const dim3 grid(n_img * (gh * gw + 1));
+  if (out_bf16 == 3) hipLaunchKernelGGL(im2col14_kernel<3>, grid, dim3(256), 0, st, img, patches, H, W, gh, gw, Kp);
+  else if (out_bf16 == 2) hipLaunchKernelGGL(im2col14_kernel<2>, grid, dim3(256), 0, st, img, patches, H, W, gh, gw, Kp);
+  else if (out_bf16) hipLaunchKernelGGL(im2col14_kernel<1>, grid, dim3(256), 0, st, img, patches, H, W, gh, gw, Kp);
+  else hipLaunchKernelGGL(im2col14_kernel<0>, grid, dim3(256), 0, st, img, patches, H, W, gh, gw, Kp);
   EC_LAUNCH_CHECK();
   return 0;
 }
@@ -991,31 +1000,31 @@ int tokens_to_nchw(const float* src, float* dst, int n, int C, int HW, hipStream
 }
 
 int pool_gather(const float* target, const float* mask_s, float inv_shots, const float* F, float* pooled, float beta, int bs, int K,
-                int hm, int g, int C, hipStream_t st) {
-  const size_t lds = (size_t)(hm * hm + g * hm + g * g + hm) * sizeof(float) + (size_t)(2 * hm + g * g) * sizeof(int) + 8 * sizeof(float);
+                int hm, int gh, int gw, int C, hipStream_t st) {
+  const size_t lds = (size_t)(hm * hm + gh * hm + gh * gw + 2 * hm) * sizeof(float) + (size_t)(4 * hm + gh * gw) * sizeof(int) + 8 * sizeof(float);
   EC_REQUIRE(lds <= 64 * 1024, -1, "pool_gather: heatmap too large for LDS");
-  hipLaunchKernelGGL(pool_gather_kernel<0>, dim3(bs * K), dim3(256), lds, st, target, mask_s, inv_shots, F, pooled, beta, K, hm, g, C,
+  hipLaunchKernelGGL(pool_gather_kernel<0>, dim3(bs * K), dim3(256), lds, st, target, mask_s, inv_shots, F, pooled, beta, K, hm, gh, gw, C,
                      (int*)nullptr, (int*)nullptr, (float*)nullptr);
   EC_LAUNCH_CHECK();
   return 0;
 }
 
-// The two halves of pool_gather (see pool_gather_kernel): tap lists from the heatmaps, then the gather.  tap_n [bs*K], tap_i / tap_w [bs*K, g*g].
-int pool_taps(const float* target, const float* mask_s, float inv_shots, int* tap_n, int* tap_i, float* tap_w, int bs, int K, int hm, int g,
-              hipStream_t st) {
-  const size_t lds = (size_t)(hm * hm + g * hm + g * g + hm) * sizeof(float) + (size_t)(2 * hm + g * g) * sizeof(int) + 8 * sizeof(float);
+// The two halves of pool_gather (see pool_gather_kernel): tap lists from the heatmaps, then the gather.  tap_n [bs*K], tap_i / tap_w [bs*K, gh*gw].
+int pool_taps(const float* target, const float* mask_s, float inv_shots, int* tap_n, int* tap_i, float* tap_w, int bs, int K, int hm, int gh,
+              int gw, hipStream_t st) {
+  const size_t lds = (size_t)(hm * hm + gh * hm + gh * gw + 2 * hm) * sizeof(float) + (size_t)(4 * hm + gh * gw) * sizeof(int) + 8 * sizeof(float);
   EC_REQUIRE(lds <= 64 * 1024, -1, "pool_taps: heatmap too large for LDS");
   hipLaunchKernelGGL(pool_gather_kernel<1>, dim3(bs * K), dim3(256), lds, st, target, mask_s, inv_shots, (const float*)nullptr,
-                     (float*)nullptr, 0.f, K, hm, g, 0, tap_n, tap_i, tap_w);
+                     (float*)nullptr, 0.f, K, hm, gh, gw, 0, tap_n, tap_i, tap_w);
   EC_LAUNCH_CHECK();
   return 0;
 }
 
-int pool_apply(const int* tap_n, const int* tap_i, const float* tap_w, const float* F, float* pooled, float beta, int bs, int K, int hm, int g,
-               int C, hipStream_t st) {
-  const size_t lds = (size_t)(hm * hm + g * hm + g * g + hm) * sizeof(float) + (size_t)(2 * hm + g * g) * sizeof(int) + 8 * sizeof(float);
+int pool_apply(const int* tap_n, const int* tap_i, const float* tap_w, const float* F, float* pooled, float beta, int bs, int K, int hm, int gh,
+               int gw, int C, hipStream_t st) {
+  const size_t lds = (size_t)(hm * hm + gh * hm + gh * gw + 2 * hm) * sizeof(float) + (size_t)(4 * hm + gh * gw) * sizeof(int) + 8 * sizeof(float);
   hipLaunchKernelGGL(pool_gather_kernel<2>, dim3(bs * K), dim3(256), lds, st, (const float*)nullptr, (const float*)nullptr, 0.f, F, pooled, beta,
-                     K, hm, g, C, const_cast<int*>(tap_n), const_cast<int*>(tap_i), const_cast<float*>(tap_w));
+                     K, hm, gh, gw, C, const_cast<int*>(tap_n), const_cast<int*>(tap_i), const_cast<float*>(tap_w));
   EC_LAUNCH_CHECK();
   return 0;
 }
@@ -1095,9 +1104,9 @@ int bias_mlp_layers(const float* attn_adj, const float* const* w1, const float* 
   return 1;
 }
 
-int proposals(const float* sim, float* prop_loss, float* prop, int rows, int g, hipStream_t st) {
-  EC_REQUIRE(g * g <= 16 * 64, -1, "proposals: grid too large");
-  hipLaunchKernelGGL(proposals_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, sim, prop_loss, prop, rows, g);
+int proposals(const float* sim, float* prop_loss, float* prop, int rows, int gh, int gw, hipStream_t st) {
+  EC_REQUIRE(gh * gw <= 16 * 64, -1, "proposals: grid too large");
+  hipLaunchKernelGGL(proposals_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, sim, prop_loss, prop, rows, gh, gw);
   EC_LAUNCH_CHECK();
   return 0;
 }

@@ -110,15 +110,13 @@ class EdgeCape:
 
     def predict(self, img_s, target_s, target_weight_s, img_q, img_metas=None):
         """EdgeCape.predict (EdgeCape.py:165-184); returns device tensors."""
-        bs, _, H, W = img_q.shape
-        if H != W:
-            raise ValueError("square inputs only")
+        bs, _, H, W = img_q.shape                     # any height / width (EdgeCape.py:143); an engine per input size
         K = target_s[0].shape[1]
         mask_s = torch.as_tensor(target_weight_s[0]).float()
         for tw in target_weight_s:                    # EdgeCape.py:175-177
             mask_s = mask_s * torch.as_tensor(tw).float()
         skeletons = [m["sample_skeleton"][0] for m in img_metas]   # EdgeCape.py:179
-        eng = self._engine(H, bs, len(img_s), K)
+        eng = self._engine(H if H == W else (H, W), bs, len(img_s), K)
         o = eng.forward(img_q, img_s, target_s, mask_s, skeletons)
         return o["output_kpts"], o["initial_proposals"], o["similarity_map"], mask_s, None, o["adj"]
 
@@ -146,13 +144,11 @@ class EdgeCape:
         batch through ec_forward_pipelined and the device -> host copies of its results on a copy stream that waits for THIS
         batch's head only; returns a ticket for collect().  The batch's head then overlaps the next submit()'s backbone."""
         height, width = img_q.shape[-2:]
-        if height != width:
-            raise ValueError("square inputs only")
         bs, K = img_q.shape[0], target_s[0].shape[1]
         mask_s = torch.as_tensor(target_weight_s[0]).float()
         for tw in target_weight_s:
             mask_s = mask_s * torch.as_tensor(tw).float()
-        eng = self._engine(height, bs, len(img_s), K)
+        eng = self._engine(height if height == width else (height, width), bs, len(img_s), K)
         iq = eng._dev(img_q)
         is_ = [eng._dev(x) for x in img_s]
         ts = [eng._dev(t) for t in target_s]

@@ -85,15 +85,18 @@ class HipEngine:
             raise _lib.EdgeCapeHipError("no MI355X / HIP device visible: the EdgeCape hot path has no CPU fallback")
         self.lib = _lib.load()
         a = ARCHS[arch]
-        self.arch, self.C, self.image_size = arch, a["C"], image_size
-        self.g = image_size // PATCH
-        self.HW = self.g * self.g
+        # image_size: an int (square) or (H, W) - the reference takes any img.shape[-2:] (EdgeCape.py:143)
+        H, Wd = (image_size, image_size) if isinstance(image_size, (int, np.integer)) else (int(image_size[0]), int(image_size[1]))
+        self.arch, self.C, self.image_size = arch, a["C"], (H if H == Wd else (H, Wd))
+        self.gh, self.gw = H // PATCH, Wd // PATCH
+        self.g = self.gh if self.gh == self.gw else (self.gh, self.gw)
+        self.HW = self.gh * self.gw
         self.K, self.max_batch, self.max_shots = num_kpts, max_batch, max_shots
         self.dec_layers, self.max_hops = dec_layers, max_hops
         prec = {"fp32": _lib.EC_F32, "bf16": _lib.EC_BF16, "bf16x3": _lib.EC_BF16X3, "fp16": _lib.EC_F16, "mixed": _lib.EC_MIXED}
         if backbone_precision not in ("fp32", "bf16x3", "bf16", "fp16") or head_precision not in ("fp32", "bf16x3", "mixed"):
             raise ValueError("backbone_precision must be fp32 / bf16x3 / bf16 / fp16 and head_precision fp32 / bf16x3 / mixed")
-        cfg = _lib.EcConfig(embed_dim=a["C"], depth=a["depth"], num_heads=a["heads"], image_size=image_size, patch=PATCH,
+        cfg = _lib.EcConfig(embed_dim=a["C"], depth=a["depth"], num_heads=a["heads"], image_size=H, image_width=(0 if H == Wd else Wd), patch=PATCH,
                             num_kpts=num_kpts, d_model=d_model, nhead=nhead, enc_layers=enc_layers, dec_layers=dec_layers,
                             skel_layers=skel_layers, ffn_dim=ffn_dim, skel_ffn_dim=skel_ffn_dim or a["C"], max_hops=max_hops,
                             heatmap_size=heatmap_size, max_shots=max_shots, max_batch=max_batch,
@@ -109,7 +112,7 @@ class HipEngine:
                 continue
             if name == "encoder_query.pos_embed":
                 pv = v.detach().cpu().float().numpy() if isinstance(v, torch.Tensor) else np.asarray(v, np.float32)
-                pos = interpolate_pos_embed(pv, self.g)
+                pos = interpolate_pos_embed(pv, (self.gh, self.gw))
                 continue
             keep, ptr, shape, dt = _host_array(v)
             shp = (C.c_int64 * len(shape))(*shape)
@@ -151,7 +154,7 @@ class HipEngine:
         dev = "cuda"
         o = dict(output_kpts=torch.empty(self.dec_layers, bs, self.K, 2, device=dev),
                  initial_proposals=torch.empty(bs, self.K, 2, device=dev),
-                 similarity_map=torch.empty(bs, self.K, self.g, self.g, device=dev),
+                 similarity_map=torch.empty(bs, self.K, self.gh, self.gw, device=dev),
                  adj=torch.empty(bs, 2, self.K, self.K, device=dev),
                  attn_adj=torch.empty(self.max_hops + 1, bs, self.K, self.K, device=dev),
                  out_points=torch.empty(self.dec_layers + 1, bs, self.K, 2, device=dev))
@@ -168,7 +171,7 @@ class HipEngine:
         """EdgeCape.extract_features for one image batch -> [n,C,g,g] (or [n,HW,C] tokens)."""
         img = self._dev(img)
         n = img.shape[0]
-        out = torch.empty((n, self.C, self.g, self.g) if nchw else (n, self.HW, self.C), device="cuda")
+        out = torch.empty((n, self.C, self.gh, self.gw) if nchw else (n, self.HW, self.C), device="cuda")
         _lib.check(self.lib.ec_backbone(self.h, img.data_ptr(), n, out.data_ptr(),
                                         _lib.EC_LAYOUT_NCHW if nchw else _lib.EC_LAYOUT_TOKENS, _lib.current_stream()))
         return out

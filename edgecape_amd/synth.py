@@ -223,7 +223,10 @@ def msra_target(joints_xy, visible, image_size, heatmap_size=64, sigma=1):
     joints_xy = np.asarray(joints_xy)
     K, hm, r = len(joints_xy), heatmap_size, 3 * sigma
     patch = gaussian_7x7(sigma)
-    stride = np.float32(image_size / hm)
+    if isinstance(image_size, (tuple, list)):    # (H, W): feat_stride = image_size / heatmap_size per axis (x: W, y: H)
+        stride = np.array([image_size[1] / hm, image_size[0] / hm], np.float32)
+    else:
+        stride = np.float32(image_size / hm)
     mu = (joints_xy[:, :2] / stride + 0.5).astype(np.int64)                      # int(): truncation toward zero
     inside = (mu[:, 0] - r < hm) & (mu[:, 1] - r < hm) & (mu[:, 0] + r + 1 >= 0) & (mu[:, 1] + r + 1 >= 0)
     weight = (np.asarray(visible, np.float32).reshape(K) * inside).astype(np.float32)
@@ -247,10 +250,11 @@ def random_skeleton(rng, n_kp):
     return edges
 
 
-def _smooth_image(rng, H):
+def _smooth_image(rng, H, W=None):
     """N(0,1) pixels plus a low-frequency field so backbone features are not degenerate."""
-    img = rng.standard_normal((3, H, H)).astype(np.float32) * 0.5
-    yy, xx = np.meshgrid(np.linspace(0, 1, H, dtype=np.float32), np.linspace(0, 1, H, dtype=np.float32), indexing="ij")
+    W = H if W is None else W
+    img = rng.standard_normal((3, H, W)).astype(np.float32) * 0.5
+    yy, xx = np.meshgrid(np.linspace(0, 1, H, dtype=np.float32), np.linspace(0, 1, W, dtype=np.float32), indexing="ij")
     for c in range(3):
         for _ in range(4):
             fx, fy = rng.uniform(0.5, 6.0, 2)
@@ -268,9 +272,13 @@ def make_pairs(bs, shots=1, image_size=224, seed=0, n_kp=17, K=100, fixed_n_kp=T
     target_weight_q, img_metas) of numpy arrays / python lists, plus 'gt_q' [bs,K,2] pixel
     keypoints for a PCK figure.
     """
-    H = image_size
-    img_q = np.zeros((bs, 3, H, H), np.float32)
-    img_s = [np.zeros((bs, 3, H, H), np.float32) for _ in range(shots)]
+    # image_size: an int (square) or (H, W); the square path draws exactly the random numbers it always did
+    square = not isinstance(image_size, (tuple, list))
+    H, Wd = (image_size, image_size) if square else (int(image_size[0]), int(image_size[1]))
+    size = H if square else (H, Wd)
+    hi = H if square else np.array([Wd, H], np.float32)          # per-coordinate (x, y) upper bounds
+    img_q = np.zeros((bs, 3, H, Wd), np.float32)
+    img_s = [np.zeros((bs, 3, H, Wd), np.float32) for _ in range(shots)]
     target_s = [np.zeros((bs, K, 64, 64), np.float32) for _ in range(shots)]
     tw_s = [np.zeros((bs, K, 1), np.float32) for _ in range(shots)]
     target_q = np.zeros((bs, K, 64, 64), np.float32)
@@ -283,16 +291,16 @@ def make_pairs(bs, shots=1, image_size=224, seed=0, n_kp=17, K=100, fixed_n_kp=T
         nk = min(nk, K)
         vis = np.zeros(K, np.float32)
         vis[:nk] = 1
-        img_q[i] = _smooth_image(rng, H)
-        base = rng.uniform(8, H - 8, size=(K, 2)).astype(np.float32)
+        img_q[i] = _smooth_image(rng, H, Wd)
+        base = rng.uniform(8, hi - 8, size=(K, 2)).astype(np.float32)
         for s in range(shots):
-            img_s[s][i] = _smooth_image(rng, H)
-            kp = np.clip(base + rng.normal(0, 2.0, base.shape), 0, H - 1).astype(np.float32)
-            t, tw = msra_target(kp, vis, H)
+            img_s[s][i] = _smooth_image(rng, H, Wd)
+            kp = np.clip(base + rng.normal(0, 2.0, base.shape), 0, hi - 1).astype(np.float32)
+            t, tw = msra_target(kp, vis, size)
             target_s[s][i], tw_s[s][i] = t, tw
-        gq = np.clip(base + rng.normal(0, 4.0, base.shape), 0, H - 1).astype(np.float32)
+        gq = np.clip(base + rng.normal(0, 4.0, base.shape), 0, hi - 1).astype(np.float32)
         gt_q[i] = gq
-        target_q[i], tw_q[i] = msra_target(gq, vis, H)
+        target_q[i], tw_q[i] = msra_target(gq, vis, size)
         if skeleton == "auto":
             edges = list(COCO17_EDGES) if nk == 17 else random_skeleton(rng, nk)
         elif skeleton == "empty":
@@ -302,13 +310,13 @@ def make_pairs(bs, shots=1, image_size=224, seed=0, n_kp=17, K=100, fixed_n_kp=T
         metas.append({
             "sample_skeleton": [edges for _ in range(shots)],
             "query_skeleton": edges,
-            "query_center": np.array([H / 2, H / 2], np.float32),
-            "query_scale": np.array([H / 200 * 1.25, H / 200 * 1.25], np.float32),
+            "query_center": np.array([Wd / 2, H / 2], np.float32),
+            "query_scale": np.array([Wd / 200 * 1.25, H / 200 * 1.25], np.float32),
             "query_image_file": f"synthetic/q{seed + first_index + i}.png",
             "sample_image_file": [f"synthetic/s{seed + first_index + i}_{s}.png" for s in range(shots)],
             "query_bbox_score": 1.0,
             "bbox_id": first_index + i,
-            "query_bbox": np.array([0, 0, H, H], np.float32),
+            "query_bbox": np.array([0, 0, Wd, H], np.float32),
         })
     return dict(img_s=img_s, target_s=target_s, target_weight_s=tw_s, img_q=img_q, target_q=target_q,
                 target_weight_q=tw_q, img_metas=metas, gt_q=gt_q)
@@ -322,10 +330,19 @@ def make_head_inputs(bs, shots, C, g, seed, n_kps, skeletons="auto", K=100, imag
     is planted at a random query cell so similarity maps are peaky (SURVEY §7 "Discontinuities").
     Returns dict(feature_q [bs,C,g,g], feature_s list[shots], target_s, mask_s [bs,K,1], skeleton list).
     """
-    image_size = image_size or g * PATCH
+    # g: an int (square grid) or (gh, gw); the square path draws exactly the random numbers it always did
+    square = not isinstance(g, (tuple, list))
+    gh, gw = (g, g) if square else (int(g[0]), int(g[1]))
+    if square:
+        image_size = image_size or g * PATCH
+        hi = image_size
+        cell = np.float32(image_size)
+    else:
+        image_size = (gh * PATCH, gw * PATCH)                       # (H, W)
+        hi = np.array([gw * PATCH, gh * PATCH], np.float32)         # per-coordinate (x, y) upper bounds
     rng = np.random.default_rng(seed)
-    feature_q = rng.standard_normal((bs, C, g, g)).astype(np.float32)
-    feature_s = [rng.standard_normal((bs, C, g, g)).astype(np.float32) for _ in range(shots)]
+    feature_q = rng.standard_normal((bs, C, gh, gw)).astype(np.float32)
+    feature_s = [rng.standard_normal((bs, C, gh, gw)).astype(np.float32) for _ in range(shots)]
     target_s = [np.zeros((bs, K, 64, 64), np.float32) for _ in range(shots)]
     mask_s = np.zeros((bs, K, 1), np.float32)
     skel = []
@@ -333,18 +350,23 @@ def make_head_inputs(bs, shots, C, g, seed, n_kps, skeletons="auto", K=100, imag
         nk = n_kps[i]
         vis = np.zeros(K, np.float32)
         vis[:nk] = 1
-        base = rng.uniform(8, image_size - 8, size=(K, 2)).astype(np.float32)
+        base = rng.uniform(8, hi - 8, size=(K, 2)).astype(np.float32)
         m = np.ones((K, 1), np.float32)
         for s in range(shots):
-            kp = np.clip(base + rng.normal(0, 2.0, base.shape), 0, image_size - 1).astype(np.float32)
+            kp = np.clip(base + rng.normal(0, 2.0, base.shape), 0, hi - 1).astype(np.float32)
             t, tw = msra_target(kp, vis, image_size)
             target_s[s][i] = t
             m = m * tw
         mask_s[i] = m
         for k in range(nk):
-            cx = min(int(base[k, 0] / image_size * g), g - 1)
-            cy = min(int(base[k, 1] / image_size * g), g - 1)
-            qy, qx = rng.integers(0, g, 2)
+            if square:
+                cx = min(int(base[k, 0] / image_size * g), g - 1)
+                cy = min(int(base[k, 1] / image_size * g), g - 1)
+                qy, qx = rng.integers(0, g, 2)
+            else:
+                cx = min(int(base[k, 0] / hi[0] * gw), gw - 1)
+                cy = min(int(base[k, 1] / hi[1] * gh), gh - 1)
+                qy, qx = int(rng.integers(0, gh)), int(rng.integers(0, gw))
             feature_q[i, :, qy, qx] += 1.5 * feature_s[0][i, :, cy, cx]
         if skeletons == "auto":
             skel.append(list(COCO17_EDGES) if nk == 17 else random_skeleton(rng, nk))

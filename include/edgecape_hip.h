@@ -70,7 +70,8 @@ typedef struct ec_config {
   int32_t embed_dim;          /* backbone width C: 384 / 768 / 1024 */
   int32_t depth;              /* 12 / 24 */
   int32_t num_heads;          /* C / 64 */
-  int32_t image_size;         /* square input, e.g. 224 / 256 / 384; grid g = image_size / patch (floor) */
+  int32_t image_size;         /* input HEIGHT, e.g. 224 / 256 / 384 (the width too unless image_width is set); token grid rows
+                                 gh = image_size / patch (floor) */
   int32_t patch;              /* 14 */
   int32_t num_kpts;           /* K = 100 (configs/test/1shot_split1.py:31) */
   int32_t d_model;            /* 256 */
@@ -86,12 +87,14 @@ typedef struct ec_config {
   int32_t max_batch;          /* bs_max (pairs per call) */
   int32_t backbone_precision; /* ec_precision: operand type of the backbone MFMA GEMMs/attention (fp32 accumulate always) */
   int32_t head_precision;     /* EC_F32, EC_BF16X3 or EC_MIXED: GEMM operand handling in the head (LayerNorm / softmax statistics stay fp32) */
+  int32_t image_width;        /* input WIDTH; 0 = square (image_size).  The reference takes any img.shape[-2:] (EdgeCape.py:143); token
+                                 grid columns gw = image_width / patch.  (ABI version 4) */
 } ec_config;
 
 typedef struct ec_outputs {
   float* output_kpts_dev;        /* [dec_layers, bs, K, 2]   head.py:222 */
   float* initial_proposals_dev;  /* [bs, K, 2]               encoder_decoder.py:87-89 (proposal_for_loss) */
-  float* similarity_map_dev;     /* [bs, K, g, g]            encoder_decoder.py:75 */
+  float* similarity_map_dev;     /* [bs, K, gh, gw]          encoder_decoder.py:75 */
   float* adj_dev;                /* [bs, 2, K, K]            skeleton.py:142 */
   float* attn_adj_dev;           /* optional (may be NULL): [max_hops+1, bs, K, K]  skeleton.py:152-161 */
   float* out_points_dev;         /* optional (may be NULL): [dec_layers+1, bs, K, 2] encoder_decoder.py:357,403 */
@@ -100,7 +103,7 @@ typedef struct ec_outputs {
 const char* ec_last_error(void);
 /* ABI version of the library (EC_ABI_VERSION of the header it was built from): bumped whenever a struct layout, an enum value, the set of entry points
    or a signature changes, so a binding can refuse a stale prebuilt library instead of calling it with mismatched layouts. */
-#define EC_ABI_VERSION 3
+#define EC_ABI_VERSION 4
 int ec_version(void);
 /* sizeof(ec_config) / sizeof(ec_outputs) as the library was compiled: a binding compares them with its own mirrors. */
 int ec_abi_sizes(int* config_bytes, int* outputs_bytes);

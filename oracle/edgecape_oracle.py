@@ -54,19 +54,20 @@ class W:
 # --------------------------------------------------------------------------------------
 def interpolate_pos_embed(pos_embed, g):
     """dinov2 `interpolate_pos_encoding`: bicubic, align_corners=False, antialias=False,
-    scale_factor=(g+0.1)/M (interpolate_offset=0.1).  pos_embed [1,1+M*M,C] -> [1+g*g, C]."""
+    scale_factor=(g+0.1)/M per axis (interpolate_offset=0.1).  pos_embed [1,1+M*M,C] -> [1+gh*gw, C]; g: int (square) or
+    (gh, gw) = (rows, columns) - upstream scales the first spatial axis of the table with x.shape[2] // 14 (it calls it `w`)."""
+    gh, gw = (g, g) if isinstance(g, int) else (int(g[0]), int(g[1]))
     pos_embed = _t(pos_embed)
     N = pos_embed.shape[1] - 1
     M = int(math.sqrt(N))
     C = pos_embed.shape[-1]
     cls_pos = pos_embed[0, :1]
-    if g == M:
+    if gh == M and gw == M:
         return pos_embed[0]
     patch = pos_embed[0, 1:].reshape(1, M, M, C).permute(0, 3, 1, 2)
-    s = float(g + 0.1) / M
-    patch = F.interpolate(patch, scale_factor=(s, s), mode="bicubic", antialias=False)
-    assert patch.shape[-2:] == (g, g)
-    patch = patch.permute(0, 2, 3, 1).reshape(g * g, C)
+    patch = F.interpolate(patch, scale_factor=(float(gh + 0.1) / M, float(gw + 0.1) / M), mode="bicubic", antialias=False)
+    assert patch.shape[-2:] == (gh, gw)
+    patch = patch.permute(0, 2, 3, 1).reshape(gh * gw, C)
     return torch.cat([cls_pos, patch], 0)
 
 
@@ -78,12 +79,12 @@ def dinov2_features(sd, img, heads, prefix="encoder_query.", taps=None, pos_tabl
     w = W(sd, prefix)
     img = _t(img)
     B, _, H, Wd = img.shape
-    g = H // PATCH
+    gh, gw = H // PATCH, Wd // PATCH
     pw = w("patch_embed.proj.weight")
     C = pw.shape[0]
     x = F.conv2d(img, pw, w("patch_embed.proj.bias"), stride=PATCH)  # PatchEmbed.forward
-    x = x[:, :, :g, :g].flatten(2).transpose(1, 2)  # [B, HW, C]
-    pos = interpolate_pos_embed(w("pos_embed"), g) if pos_table is None else _t(pos_table)
+    x = x[:, :, :gh, :gw].flatten(2).transpose(1, 2)  # [B, HW, C]
+    pos = interpolate_pos_embed(w("pos_embed"), (gh, gw)) if pos_table is None else _t(pos_table)
     x = torch.cat([w("cls_token").expand(B, -1, -1), x], 1) + pos[None]  # prepare_tokens_with_masks
     if taps is not None:
         taps["tokens0"] = x.clone()
@@ -119,7 +120,7 @@ def dinov2_features(sd, img, heads, prefix="encoder_query.", taps=None, pos_tabl
     x = x[:, 1:]  # drop cls
     if taps is not None:
         taps["feat_tokens"] = x.clone()
-    return x.reshape(B, g, g, C).permute(0, 3, 1, 2).contiguous()
+    return x.reshape(B, gh, gw, C).permute(0, 3, 1, 2).contiguous()
 
 
 # --------------------------------------------------------------------------------------
@@ -130,9 +131,10 @@ def _dim_t(num_feats=128, temperature=10000):
     return temperature ** (2 * (d // 2) / num_feats)
 
 
-def sine_pos_embed_image(bs, g, num_feats=128, scale=2 * math.pi, eps=1e-6):
-    """positional_encoding.py:57-94 with an all-False mask -> [bs, 2*num_feats, g, g]."""
-    not_mask = torch.ones(bs, g, g, dtype=torch.int)
+def sine_pos_embed_image(bs, g, num_feats=128, scale=2 * math.pi, eps=1e-6, gw=None):
+    """positional_encoding.py:57-94 with an all-False mask -> [bs, 2*num_feats, g, gw] (gw defaults to g: square)."""
+    gw = g if gw is None else gw
+    not_mask = torch.ones(bs, g, gw, dtype=torch.int)
     y_embed = not_mask.cumsum(1, dtype=torch.float32)
     x_embed = not_mask.cumsum(2, dtype=torch.float32)
     y_embed = y_embed / (y_embed[:, -1:, :] + eps) * scale
@@ -140,8 +142,8 @@ def sine_pos_embed_image(bs, g, num_feats=128, scale=2 * math.pi, eps=1e-6):
     dim_t = _dim_t(num_feats)
     pos_x = x_embed[:, :, :, None] / dim_t
     pos_y = y_embed[:, :, :, None] / dim_t
-    pos_x = torch.stack((pos_x[..., 0::2].sin(), pos_x[..., 1::2].cos()), dim=4).view(bs, g, g, -1)
-    pos_y = torch.stack((pos_y[..., 0::2].sin(), pos_y[..., 1::2].cos()), dim=4).view(bs, g, g, -1)
+    pos_x = torch.stack((pos_x[..., 0::2].sin(), pos_x[..., 1::2].cos()), dim=4).view(bs, g, gw, -1)
+    pos_y = torch.stack((pos_y[..., 0::2].sin(), pos_y[..., 1::2].cos()), dim=4).view(bs, g, gw, -1)
     return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
 
 
@@ -420,7 +422,7 @@ def head_forward(sd, feature_q, feature_s, target_s, mask_s, skeleton, prefix="k
     target_s = [_t(t) for t in target_s]
     fq = F.conv2d(feature_q, w("input_proj.weight"), w("input_proj.bias"))
     bs, d, h, wd = fq.shape
-    pos_img = sine_pos_embed_image(bs, h)
+    pos_img = sine_pos_embed_image(bs, h, gw=wd)
     embeds = []
     for feat, tgt in zip(feature_s, target_s):
         rf = F.interpolate(feat, size=tgt.shape[-2:], mode="bilinear", align_corners=False)

@@ -78,7 +78,7 @@ def test_missing_weight_and_call_order():
     y = torch.zeros(1, 256, 384, device="cuda")
     assert lib.ec_backbone(h, x.data_ptr(), 1, y.data_ptr(), 0, None) == -3 and b"finalized" in lib.ec_last_error()      # EC_ERR_STATE
     assert lib.ec_finalize(h) == -3 and b"missing tensor" in lib.ec_last_error()
-    bad = _lib.EcConfig(**{**{f[0]: getattr(cfg, f[0]) for f in cfg._fields_}, "num_kpts": 129})
+    bad = _lib.EcConfig(**{**{f[0]: getattr(cfg, f[0]) for f in cfg._fields_}, "num_kpts": 257})
     h2 = C.c_void_p()
     assert lib.ec_create(C.byref(bad), C.byref(h2)) == -1 and b"num_kpts" in lib.ec_last_error()                           # EC_ERR_ARG
     assert lib.ec_destroy(h) == 0

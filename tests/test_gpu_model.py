@@ -13,7 +13,8 @@ from edgecape_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-HEAD = ["head_s1_c384_g16_kp17", "head_s5_c384_g16_mixed", "head_s1_c768_g18_edge", "head_s5_c768_g18_kp17"]
+HEAD = ["head_s1_c384_g16_kp17", "head_s5_c384_g16_mixed", "head_s1_c768_g18_edge", "head_s5_c768_g18_kp17",
+        "head_s2_c384_g14x20_kp17", "head_s1_c768_g21x16_mixed"]   # the last two (round 4): the real head on NON-SQUARE feature maps
 ARCH_OF_C = {384: "dinov2_vits14", 768: "dinov2_vitb14", 1024: "dinov2_vitl14"}
 
 
@@ -33,11 +34,13 @@ def _valid_mask(n_kps, K=100):
 def test_head_vs_reference_golden(name):
     gold, meta = load_golden(name)
     C, g = meta["C"], meta["g"]
+    g = tuple(g) if isinstance(g, list) else g
+    gh, gw = g if isinstance(g, tuple) else (g, g)
     arch = ARCH_OF_C[C]
     sd = synth.make_backbone_weights(arch, seed=3)       # backbone weights are not used by ec_head
     sd.update(synth.make_head_weights(C=C, seed=meta["weight_seed"]))
     inp = synth.make_head_inputs(len(meta["n_kps"]), meta["shots"], C, g, meta["input_seed"], meta["n_kps"], meta["skeletons"])
-    eng = _engine(sd, arch, g * 14, len(meta["n_kps"]), meta["shots"])
+    eng = _engine(sd, arch, (gh * 14, gw * 14) if gh != gw else gh * 14, len(meta["n_kps"]), meta["shots"])
     o = eng.head(inp["feature_q"], inp["feature_s"], inp["target_s"], inp["mask_s"], inp["skeleton"])
     torch.cuda.synchronize()
     got = {k: v.cpu().numpy() for k, v in o.items()}
@@ -45,8 +48,8 @@ def test_head_vs_reference_golden(name):
                                                                "out_points", "output_kpts")}
     sk = eng.debug("support_keypoints").reshape(gold["support_keypoints"].shape)
     errs["support_keypoints"] = float(np.abs(sk - gold["support_keypoints"]).max())
-    enc = eng.debug("enc").reshape(len(meta["n_kps"]), g * g + 100, 256)
-    errs["enc_kp"] = float(np.abs(enc[:, g * g:].transpose(1, 0, 2) - gold["enc_kp"]).max())
+    enc = eng.debug("enc").reshape(len(meta["n_kps"]), gh * gw + 100, 256)
+    errs["enc_kp"] = float(np.abs(enc[:, gh * gw:].transpose(1, 0, 2) - gold["enc_kp"]).max())
     print(name, errs)
     assert errs["support_keypoints"] < 2e-5
     assert errs["adj"] < 1e-5 and errs["attn_adj"] < 1e-5
@@ -77,14 +80,17 @@ def test_backbone_vs_oracle(arch, image_size):
     assert np.array_equal(tok.reshape(3, g, g, -1).transpose(0, 3, 1, 2), got)
 
 
-@pytest.mark.parametrize("arch,image_size", [("dinov2_vits14", 224), ("dinov2_vitb14", 256), ("dinov2_vitl14", 384)])
+@pytest.mark.parametrize("arch,image_size", [("dinov2_vits14", 224), ("dinov2_vitb14", 256), ("dinov2_vitl14", 384),
+                                             ("dinov2_vits14", (224, 308))])
 def test_backbone_vs_hf_golden(arch, image_size):
     name = {"dinov2_vits14": "bb_hf_vits14_224", "dinov2_vitb14": "bb_hf_vitb14_256", "dinov2_vitl14": "bb_hf_vitl14_384"}[arch]
+    if isinstance(image_size, tuple):
+        name = "bb_hf_vits14_224x308"                    # round 4: a non-square image
     gold, meta = load_golden(name)
     sd = synth.make_backbone_weights(arch, seed=meta["weight_seed"])
     sd.update(synth.make_head_weights(C=synth.ARCHS[arch]["C"], seed=1))
     rng = np.random.default_rng(meta["input_seed"])
-    img = np.stack([synth._smooth_image(rng, image_size)])
+    img = np.stack([synth._smooth_image(rng, *image_size) if isinstance(image_size, tuple) else synth._smooth_image(rng, image_size)])
     eng = _engine(sd, arch, image_size, 1, 1)
     tok = eng.backbone(img, nchw=False).cpu().numpy()[0]
     assert np.abs(tok[:8] - gold["feat_tokens_first8"]).max() < 3e-4
@@ -235,6 +241,49 @@ def _fwd(eng, batch):
     o = eng.forward(batch["img_q"], batch["img_s"], batch["target_s"], mask, [m["sample_skeleton"][0] for m in batch["img_metas"]])
     torch.cuda.synchronize()
     return {k: v.cpu().numpy() for k, v in o.items() if isinstance(v, torch.Tensor)}, mask[:, :, 0] > 0
+
+
+@pytest.mark.parametrize("size", [(224, 308), (294, 196)])
+def test_nonsquare_forward_vs_oracle(size):
+    """The reference takes any img_q.shape[-2:] (EdgeCape.py:143; VERDICT r3 missing item 4): whole forward_test on non-square
+    images - wider than high and higher than wide, one of them not a multiple of 14 (floor semantics) - through the registry-built
+    detector, against the oracle (itself pinned on non-square maps by the real head and by HF: tests/test_oracle_golden.py); exact-fp32
+    and the bench's default precision, plus the pipelined entry point bit-equal to ec_forward."""
+    from oracle import edgecape_oracle as orc
+    from edgecape_amd.engine import HipEngine
+    arch, bs = "dinov2_vits14", 3
+    H, W = size
+    sd = synth.make_weights(arch, seed=31)
+    batch = synth.make_pairs(bs, 2, (H + 5, W + 3), seed=77, fixed_n_kp=False)      # + 5 / + 3 pixels: the patch embedding floors
+    res, out = orc.forward_test(sd, batch, synth.ARCHS[arch]["heads"])
+    ref = {k: out[k].numpy() for k in ("output_kpts", "similarity_map", "adj", "initial_proposals")}
+    mask = batch["target_weight_s"][0] * batch["target_weight_s"][1]
+    valid = mask[:, :, 0] > 0
+    skel = [m["sample_skeleton"][0] for m in batch["img_metas"]]
+    for prec, tol in ((dict(), 1e-4), (dict(backbone_precision="fp16", head_precision="mixed"), 1e-3)):
+        eng = HipEngine(sd, arch=arch, image_size=(H + 5, W + 3), max_batch=bs, max_shots=2, **prec)
+        assert (eng.gh, eng.gw) == ((H + 5) // 14, (W + 3) // 14)
+        o = eng.forward(batch["img_q"], batch["img_s"], batch["target_s"], mask, skel)
+        torch.cuda.synchronize()
+        got = {k: o[k].cpu().numpy() for k in ref}
+        assert got["similarity_map"].shape == ref["similarity_map"].shape
+        flips = (got["similarity_map"].reshape(bs, 100, -1).argmax(-1) != ref["similarity_map"].reshape(bs, 100, -1).argmax(-1))[valid].sum()
+        err = np.abs(got["output_kpts"] - ref["output_kpts"])[:, valid].max()
+        perr = np.abs(got["initial_proposals"] - ref["initial_proposals"])[valid].max()
+        print(size, prec or "fp32", "kpt err", err, "proposal err", perr, "adj err", np.abs(got["adj"] - ref["adj"]).max(), "flips", flips)
+        assert flips == 0 and err < tol and perr < (2e-4 if not prec else 2e-3)
+        assert np.abs(got["adj"] - ref["adj"]).max() < 1e-4
+        if prec:                                       # the pipelined entry point on the same engine: bit-equal
+            dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+            e, off = eng._edges(skel, bs)
+            outs = eng._outputs(bs)
+            eng.forward_pipelined(dev(batch["img_q"]), [dev(x) for x in batch["img_s"]], [dev(x) for x in batch["target_s"]],
+                                  dev(mask.reshape(bs, -1)), e, off, outs)
+            eng.pipeline_flush()
+            torch.cuda.synchronize()
+            for k in ref:
+                assert np.array_equal(outs[0][k].cpu().numpy(), got[k]), k
+        del eng
 
 
 @pytest.mark.parametrize("K,n_kp", [(7, 7), (150, 131), (256, 40)])

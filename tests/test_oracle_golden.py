@@ -12,13 +12,15 @@ from conftest import load_golden
 from edgecape_amd import synth
 from oracle import edgecape_oracle as orc
 
-HEAD = ["head_s1_c384_g16_kp17", "head_s5_c384_g16_mixed", "head_s1_c768_g18_edge", "head_s5_c768_g18_kp17"]
+HEAD = ["head_s1_c384_g16_kp17", "head_s5_c384_g16_mixed", "head_s1_c768_g18_edge", "head_s5_c768_g18_kp17",
+        "head_s2_c384_g14x20_kp17", "head_s1_c768_g21x16_mixed"]      # the last two (round 4): NON-SQUARE feature maps through the real head
 TOL = 1e-5
 
 
 def _run_head(meta):
     sd = synth.make_head_weights(C=meta["C"], seed=meta["weight_seed"])
-    inp = synth.make_head_inputs(len(meta["n_kps"]), meta["shots"], meta["C"], meta["g"], meta["input_seed"],
+    g = tuple(meta["g"]) if isinstance(meta["g"], list) else meta["g"]
+    inp = synth.make_head_inputs(len(meta["n_kps"]), meta["shots"], meta["C"], g, meta["input_seed"],
                                  meta["n_kps"], meta["skeletons"])
     taps = {}
     with torch.no_grad():
@@ -79,13 +81,15 @@ def test_detector_matches_reference(name):
     assert np.all(res["preds"][..., 2] == 1)  # head.py:374
 
 
-@pytest.mark.parametrize("name", ["bb_hf_vits14_224", "bb_hf_vitb14_256", "bb_hf_vitl14_384"])
+@pytest.mark.parametrize("name", ["bb_hf_vits14_224", "bb_hf_vitb14_256", "bb_hf_vitl14_384", "bb_hf_vits14_224x308"])
 def test_backbone_matches_hf(name):
+    """(the 224 x 308 fixture, round 4: a non-square image, positional table interpolated by HF itself with per-axis scale factors)"""
     gold, meta = load_golden(name)
     arch = meta["arch"]
     sd = synth.make_backbone_weights(arch, seed=meta["weight_seed"])
     rng = np.random.default_rng(meta["input_seed"])
-    img = np.stack([synth._smooth_image(rng, meta["image_size"])])
+    size = meta["image_size"]
+    img = np.stack([synth._smooth_image(rng, *size) if isinstance(size, list) else synth._smooth_image(rng, size)])
     taps = {}
     with torch.no_grad():
         orc.dinov2_features(sd, img, synth.ARCHS[arch]["heads"], taps=taps)
@@ -117,6 +121,25 @@ def test_pipeline_oracle_matches_reference_msra():
         j, v = g[f"joints_{i}"], g[f"visible_{i}"]
         t, w = msra_target_ref64(j[:, :2], v[:, 0], image_size, heatmap_size=hm, sigma=meta["sigma"])
         assert np.array_equal(t, g[f"target_{i}"]) and np.array_equal(w, g[f"weight_{i}"]), i
+
+
+@pytest.mark.parametrize("M,gh,gw", [(37, 16, 22), (37, 27, 18), (37, 37, 20), (16, 18, 37)])
+def test_posembed_interpolation_nonsquare_vs_torch(M, gh, gw):
+    """Per-axis scale factors for a non-square token grid (rows: (gh + 0.1) / M, columns: (gw + 0.1) / M), incl. one axis at the native
+    size - upstream still resamples it (scale (M + 0.1) / M)."""
+    import torch.nn.functional as F
+    from edgecape_amd.posembed import interpolate_pos_embed
+    rng = np.random.default_rng(M * 1000 + gh * 40 + gw)
+    C = 24
+    pe = rng.normal(0, 0.02, (1, 1 + M * M, C)).astype(np.float32)
+    got = interpolate_pos_embed(pe, (gh, gw))
+    patch = torch.from_numpy(pe[0, 1:]).reshape(1, M, M, C).permute(0, 3, 1, 2)
+    ref = F.interpolate(patch, scale_factor=(float(gh + 0.1) / M, float(gw + 0.1) / M), mode="bicubic", antialias=False)
+    assert ref.shape[-2:] == (gh, gw)
+    ref = ref.permute(0, 2, 3, 1).reshape(gh * gw, C).numpy()
+    assert got.shape == (1 + gh * gw, C) and np.array_equal(got[0], pe[0, 0])
+    assert np.abs(got[1:] - ref).max() < 1e-6
+    assert np.abs(got - orc.interpolate_pos_embed(pe, (gh, gw)).numpy()).max() < 1e-6
 
 
 @pytest.mark.parametrize("M,g", [(37, 16), (37, 18), (37, 27), (16, 18), (37, 37), (10, 27)])
