@@ -282,6 +282,8 @@ template <int N> __device__ __forceinline__ void g8_wait_vm() { asm volatile("s_
 // state, 8 no MFMAs, 32 no epilogue at all, 64 the load stream is drained at the tile seam (the round-1 seam, for A/B),
 // 512 (round 4) s_memtime stamps of one wave per wave group at the tile milestones (kernel start | per tile: K loop start, K loop
 // end, epilogue end | kernel end), kept in LDS and dumped to p.aux[blockIdx][64] at the end: the per-tile cycle ledger of DESIGN.md;
+// 8192 / 16384 (round 4) no per-phase s_setprio flips: a static priority 1 for the younger wave group (MI355X_MICROARCH.md "Two waves
+// per SIMD", item 4) / no priorities at all;
 // 4096 (round 4) the prologue waits for all five half-tiles before the first phase (the round-3 form, for A/B);
 // 2048 (round 4) no LDS fragment reads after the first K-tile pair of a workgroup (the MFMAs reuse the registers: what the ds_read
 // traffic of the partner group costs the MFMA blocks); 1024 (round 4) every tile STORES to the rows of tile row 0 (the output of a launch aliases onto 256 x N: dirty lines stay in the
@@ -529,6 +531,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
     }
   };
 
+  if constexpr (LAB & 8192) { if (wr == 1) __builtin_amdgcn_s_setprio(1); }   // lab: STATIC priority for the younger wave group, no per-phase flips
   int it = 0;                                          // tile counter of this workgroup (bias parity)
   for (int t = t_first; t < t_end; t = t_nxt, t_nxt = t_nn, t_nn = dyn ? t_end : t_nxt + nslot, ++it) {
     const int m0 = (t / ntn) << 8, n0 = (t % ntn) << 8;
@@ -567,7 +570,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
           }
         }
         G8_BAR();
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (!(LAB & 24576)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -575,7 +578,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
 #pragma unroll
             for (int f = 0; f < 2; ++f)
               if constexpr (LAB & 8) asm volatile("" ::"v"(b0[f][kh]), "v"(af[fi][kh])); else acc[fi][f] = mfma16x16x32_h<F16>(b0[f][kh], af[fi][kh], acc[fi][f]);
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (!(LAB & 24576)) __builtin_amdgcn_s_setprio(0);
         G8_BAR();
         // ---------------- phase 1: quadrant (0, 1)
         if (rd) {
@@ -591,7 +594,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
           if (!head) g8_wait_vm<6>();
         }
         G8_BAR();
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (!(LAB & 24576)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -599,7 +602,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
 #pragma unroll
             for (int f = 0; f < 2; ++f)
               if constexpr (LAB & 8) asm volatile("" ::"v"(b1[f][kh]), "v"(af[fi][kh])); else acc[fi][2 + f] = mfma16x16x32_h<F16>(b1[f][kh], af[fi][kh], acc[fi][2 + f]);
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (!(LAB & 24576)) __builtin_amdgcn_s_setprio(0);
         G8_BAR();
         // ---------------- phase 2: quadrant (1, 1)
         if (rd) {
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
           if (!head) g8_wait_vm<6>();
         }
         G8_BAR();
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (!(LAB & 24576)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
 #pragma unroll
             for (int f = 0; f < 2; ++f)
               if constexpr (LAB & 8) asm volatile("" ::"v"(b1[f][kh]), "v"(af[fi][kh])); else acc[4 + fi][2 + f] = mfma16x16x32_h<F16>(b1[f][kh], af[fi][kh], acc[4 + fi][2 + f]);
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (!(LAB & 24576)) __builtin_amdgcn_s_setprio(0);
         G8_BAR();
         // ---------------- phase 3: quadrant (1, 0); the load stream moves on to the next K-tile
         advance();
@@ -650,7 +653,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
           }
         }
         G8_BAR();
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (!(LAB & 24576)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -658,7 +661,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
 #pragma unroll
             for (int f = 0; f < 2; ++f)
               if constexpr (LAB & 8) asm volatile("" ::"v"(b0[f][kh]), "v"(af[fi][kh])); else acc[4 + fi][f] = mfma16x16x32_h<F16>(b0[f][kh], af[fi][kh], acc[4 + fi][f]);
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (!(LAB & 24576)) __builtin_amdgcn_s_setprio(0);
         if (buf == 0 || kt2 + 2 < nk) G8_BAR();   // the tile's last barrier is placed around its epilogue
       }
     }
@@ -791,6 +794,8 @@ extern "C" int ec_lab_gemm8(const void* A, const void* W, const float* bias, voi
     case 1008: k = gemm8_bf16_kernel<1, 1, true, 8>; break;     // ... no MFMAs
     case 2024: k = gemm8_bf16_kernel<1, 1, true, 1024>; break;  // ... stores aliased onto tile row 0 (L2-resident)
     case 1004: k = gemm8_bf16_kernel<1, 1, true, 4>; break;     // ... no LDS-DMA in the steady state
+    case 9192: k = gemm8_bf16_kernel<1, 1, true, 8192>; break;  // ... static priority for the younger wave group
+    case 9384: k = gemm8_bf16_kernel<1, 1, true, 16384>; break; // ... no priorities
     case 5096: k = gemm8_bf16_kernel<1, 1, true, 4096>; break;  // ... the prologue waits for all five half-tiles (round-3 form)
     case 6096: k = gemm8_bf16_kernel<2, 4, true, 4096>; break;  // LayerScale kind, same
     case 7096: k = gemm8_bf16_kernel<3, 3, true, 4096>; break;  // GELU kind, same

@@ -13,16 +13,18 @@ Modes (backbone / head):
   bf16x3 / bf16x3  "parity mode": every MFMA operand split hi+lo bf16 - fp32-class; must meet 1e-3 outright, no flips.
   fp16   / bf16x3  headline throughput mode: IEEE fp16 operands at the bf16 MFMA rate; continuous error ~1e-4.
   bf16   / bf16x3  the north-star's literal bf16 tiles: continuous error ~1e-3, reported and bounded, not parity-grade.
-MEASURED on MI355X, 256 DISJOINT pairs x 2 weight seeds per configuration against the oracle (tools/conformance.py, records under
-profiles/; the at-scale gates below are these observations + <= 50 %):
-  fp16 / mixed   cfg1 (ViT-S/14 @ 224, the reference's shipped config)  13 flips of 19 288 valid keypoints (6.7e-4), 6.2e-4 outside 1e-3,
-                      max |d| 1.87e-4 on the 499 flip-free samples, PCK@0.2 vs the oracle's answers 0.9994  (r04_conformance_cfg1_fp16_mixed)
-                 cfg2 13 of 20 293 (6.4e-4), 5.2e-4, 1.65e-4 on 500 samples, 0.9997                          (r04_conformance_fp16_mixed)
-                 cfg4  9 of  9 841 (9.1e-4), 1.5e-4 on 248 samples, 0.9995  (256 pairs)                  (r03_conformance_cfg4_fp16_mixed)
-                 cfg5  7 of  4 753 (1.5e-3), 1.6e-4 on 121 samples, 0.9992  (128 pairs)                  (r03_conformance_cfg5_fp16_mixed)
+MEASURED on MI355X against the oracle, disjoint pairs x 2 weight seeds per configuration, on the round's FINAL library
+(tools/gpu_conformance_all.sh, records profiles/r04_conformance_*.json; the at-scale gates below are these observations + <= 50 %):
+  fp16 / mixed   cfg1 (ViT-S/14 @ 224, the reference's shipped config; 512 pairs)  11 flips of 19 288 valid keypoints (5.7e-4), 5.4e-4
+                      outside 1e-3, max |d| 2.39e-4 on the 501 flip-free samples, PCK@0.2 vs the oracle's answers 0.9995
+                 cfg2 (512 pairs) 12 of 20 293 (5.9e-4), 5.4e-4, 2.02e-4 on 501 samples, 0.9996
+                 cfg4 (512 pairs) 17 of 19 699 (8.6e-4), 6.6e-4, 1.62e-4 on 496 samples, 0.9995
+                 cfg5 (256 pairs) 14 of  9 645 (1.45e-3), 1.45e-3, 1.56e-4 on 242 samples, 0.9991
   bf16x3 / bf16x3  cfg1 0 flips, max 9.1e-6 over all 512 pairs; cfg2 1 flip (a 4.9e-5 near-tie), 1.1e-5 on the other 511.
+(At the start of round 4, before the GELU / accumulator changes of the GEMM epilogue: cfg1 13 flips, cfg2 13 - the same rates.)
 A device-side near-tie guard is NOT viable (near_tie_guard in the records): the similarity map (scale ~ 60) is up to 2.8e-2 off in
-fp16, and 55-62 % of the samples hold a valid keypoint whose top-2 gap is below twice that (2.4-2.9 % of the keypoints).
+fp16 (3.2e-2 on the final library), and 54-70 % of the samples hold a valid keypoint whose top-2 gap is below twice that (2.4-3.9 % of
+the keypoints).
 """
 import functools
 
@@ -138,12 +140,12 @@ def _headline_gates(s, name):
     """One full batch of a configuration in the bench's default backbone precision.  Observed on every configuration (rounds 2-4):
     0 flips on these batches, max |d| 1.4-1.9e-4, p99 <= 8e-5, median <= 6e-6; gates = that + <= 50 %.  A near-tie may flip on another
     box (a flip moves ONE sample by up to a grid cell): at most one, and then only that sample may leave the tolerance."""
-    assert s["max_clean"] < 2.8e-4, s                     # every sample without an argmax flip: 3.5x inside the north-star tolerance
+    assert s["max_clean"] < 3.0e-4, s                     # every sample without an argmax flip: > 3x inside the north-star tolerance
     assert s["p99"] < 1.2e-4 and s["median"] < 9e-6, s
     assert s["flips"] <= 1, s
     assert s["clean_samples"] >= CFG[name]["bs"] - 1
     if s["flips"] == 0:
-        assert s["max_all"] < 2.8e-4 and s["frac_gt_1e3"] == 0.0
+        assert s["max_all"] < 3.0e-4 and s["frac_gt_1e3"] == 0.0
     assert s["pck_vs_oracle"] >= 0.99                     # north star: PCK@0.2 within +-0.1 (here against the oracle's own answers)
 
 
@@ -214,10 +216,11 @@ def conformance_at_scale(n_batches=8, wseeds=(0, 1), backbone="fp16", head="mixe
     return per_seed, pooled
 
 
-# Observed at scale (256 disjoint pairs x 2 weight seeds, fp16 / mixed; profiles/r04_conformance_*): the gates are these + <= 50 %.
+# Observed at scale (256 disjoint pairs x 2 weight seeds, fp16 / mixed, the round's final library; profiles/r04_conformance_*): the gates
+# are these + <= 50 %.
 AT_SCALE = {
-    "cfg1": dict(flips=13, n_valid=19288, frac_gt_1e3=6.2e-4, max_clean=1.87e-4, p99=7.0e-5, median=5.1e-6, flipped_samples=13, pck=0.9994, seed_flips=8),
-    "cfg2": dict(flips=13, n_valid=20293, frac_gt_1e3=5.2e-4, max_clean=1.65e-4, p99=7.0e-5, median=3.3e-6, flipped_samples=12, pck=0.9997, seed_flips=9),
+    "cfg1": dict(flips=11, n_valid=19288, frac_gt_1e3=5.4e-4, max_clean=2.39e-4, p99=6.9e-5, median=5.0e-6, flipped_samples=11, pck=0.9995, seed_flips=6),
+    "cfg2": dict(flips=12, n_valid=20293, frac_gt_1e3=5.4e-4, max_clean=2.02e-4, p99=7.1e-5, median=3.3e-6, flipped_samples=11, pck=0.9996, seed_flips=7),
 }
 
 
