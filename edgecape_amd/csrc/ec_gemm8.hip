@@ -283,7 +283,8 @@ template <int N> __device__ __forceinline__ void g8_wait_vm() { asm volatile("s_
 // 512 (round 4) s_memtime stamps of one wave per wave group at the tile milestones (kernel start | per tile: K loop start, K loop
 // end, epilogue end | kernel end), kept in LDS and dumped to p.aux[blockIdx][64] at the end: the per-tile cycle ledger of DESIGN.md;
 // 8192 / 16384 (round 4) no per-phase s_setprio flips: a static priority 1 for the younger wave group (MI355X_MICROARCH.md "Two waves
-// per SIMD", item 4) / no priorities at all;
+// per SIMD", item 4) / no priorities at all - measured: QKV 67.1-69.3 vs 67.2-69.4 / 66.7-67.4 us, 4096^3 98.6-100.1 vs 98.6-100.1 /
+// 98.3-100.9, fc2 73.7-75.4 vs 73.7-74.0 / 73.7-74.5: no difference either way (profiles/r04_g8_setprio_ab.txt), the flips stay;
 // 4096 (round 4) the prologue waits for all five half-tiles before the first phase (the round-3 form, for A/B);
 // 2048 (round 4) no LDS fragment reads after the first K-tile pair of a workgroup (the MFMAs reuse the registers: what the ds_read
 // traffic of the partner group costs the MFMA blocks); 1024 (round 4) every tile STORES to the rows of tile row 0 (the output of a launch aliases onto 256 x N: dirty lines stay in the

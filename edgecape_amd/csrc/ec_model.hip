@@ -1446,7 +1446,7 @@ static int join_on_error(ec_model* m, int rc) {
 
 // TwoStageHead.forward (head.py:161-222).  fq: [bs,HW,C] tokens, fs: S pointers [bs,HW,C].
 static int run_head(ec_model* m, const float* fq, const float* const* fs, const float* const* target_s, const float* mask_s,
-                    int bs, int S, hipStream_t st, const ec_outputs* out, bool pre = false) {
+                    int bs, int S, hipStream_t st, const ec_outputs* out) {
   const SupportState ss = workspace_support(m, out);
   RUN(tl_mark(m, "head", st));
   if (m->overlap) {
@@ -1467,9 +1467,7 @@ static int run_head(ec_model* m, const float* fq, const float* const* fs, const 
       m->feat_read_pending = true;
       return tl_dump(m);
     }
-    // (pre: what reads the caller's heatmaps / masks - adjacency build, pooling tap lists, row plans - already ran on the side stream
-    //  beside the call's backbone, run_head_pre; the rest of the support lane follows it there)
-    RUN(join_on_error(m, run_head_support(m, fs, target_s, mask_s, bs, S, m->side, ss, m->ev_sk, pre ? 2 : 0)));
+    RUN(join_on_error(m, run_head_support(m, fs, target_s, mask_s, bs, S, m->side, ss, m->ev_sk)));
     EC_HIP(hipEventRecord(m->ev_join, m->side));
     RUN(join_on_error(m, run_head_query(m, fq, bs, st, out, ss, m->ev_sk, m->ev_join)));   // st joins the side stream before the decoder
     // A pipelined call leaves the support lane and the decoder running when `st` moves on to the next backbone, which ends by
@@ -1930,18 +1928,16 @@ static int forward_impl(ec_handle m, const float* img_q, const float* const* img
     srcs[1 + s] = img_s[s];
     fsp[s] = m->feat + (1 + s) * per;
   }
-  // Plain calls too (round 4): the support lane's first kernels need no backbone output, so they run on the side stream beside the
-  // call's own backbone instead of behind it (EC_HEAD_PRE=0: behind it, as before; bit-identical - the two halves of the pooling are).
-  static const bool pre_off = getenv("EC_HEAD_PRE") && atoi(getenv("EC_HEAD_PRE")) == 0;
-  const bool pre = full || (!pipelined && !pre_off && m->overlap && m->side != nullptr);
-  if (pre) RUN(run_head_pre(m, target_s, mask_s, bs, S, st, out));
+  // (round 4, measured and not adopted: the same for plain calls - the support lane's input-only kernels on the side stream beside
+  //  the call's own backbone: 4781 / 4803 / 4806 vs 4795 / 4790 / 4806 pairs/s through ec_forward, no difference; profiles/r04_head_pre_ab.txt)
+  if (full) RUN(run_head_pre(m, target_s, mask_s, bs, S, st, out));
   if (m->timeline_defer) RUN(tl_mark(m, "BB", st));
   RUN(run_backbone(m, srcs.data(), 1 + S, bs, m->feat, st));   // (beside the previous pipelined call's decoder, if one is pending)
   m->taps["feature_q"] = {m->feat, (long)per};
   if (m->timeline_defer) RUN(tl_mark(m, "BBend", st));
   // ... which owns the head workspace until it is done (FULL mode: the next head waits for it on its own streams, run_head)
   if (!full) RUN(wait_pending_decoder(m, st));
-  return run_head(m, m->feat, fsp.data(), target_s, mask_s, bs, S, st, out, pre && !full);
+  return run_head(m, m->feat, fsp.data(), target_s, mask_s, bs, S, st, out);
 }
 
 int ec_forward(ec_handle m, const float* img_q, const float* const* img_s, const float* const* target_s, const float* mask_s,

@@ -73,7 +73,8 @@ typedef struct ec_config {
   int32_t image_size;         /* input HEIGHT, e.g. 224 / 256 / 384 (the width too unless image_width is set); token grid rows
                                  gh = image_size / patch (floor) */
   int32_t patch;              /* 14 */
-  int32_t num_kpts;           /* K = 100 (configs/test/1shot_split1.py:31) */
+  int32_t num_kpts;           /* K keypoint slots, 1..256: 100 in the shipped configs (configs/test/1shot_split1.py:31), the number of clicked
+                                 points in the demo (gradio_utils/utils.py:142-148) */
   int32_t d_model;            /* 256 */
   int32_t nhead;              /* 8 */
   int32_t enc_layers;         /* 3 */
