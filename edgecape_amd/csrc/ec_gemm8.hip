@@ -837,7 +837,8 @@ extern "C" int ec_lab_gemm8(const void* A, const void* W, const float* bias, voi
 
 // Lab build only (tools/g8_ledger.py): ONE launch of the shipped QKV-kind fp16 kernel with s_memtime stamps (LAB 512) after two warm
 // launches; trace: device buffer of grid x 64 uint64 (per workgroup: [wave group][32 stamps], see the LAB comment).
-extern "C" int ec_lab_gemm8_trace(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int kind, void* trace, void* stream) {
+extern "C" int ec_lab_gemm8_trace(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int kind, void* trace, void* stream,
+                                  float* traced_ms) {
   typedef void (*kern_t)(GemmP);
   kern_t k = kind == 3 ? (kern_t)gemm8_bf16_kernel<3, 3, true, 512> : kind == 2 ? (kern_t)gemm8_bf16_kernel<2, 4, true, 512> : (kern_t)gemm8_bf16_kernel<1, 1, true, 512>;
   kern_t k0 = kind == 3 ? (kern_t)gemm8_bf16_kernel<3, 3, true, 0> : kind == 2 ? (kern_t)gemm8_bf16_kernel<2, 4, true, 0> : (kern_t)gemm8_bf16_kernel<1, 1, true, 0>;
@@ -852,11 +853,19 @@ extern "C" int ec_lab_gemm8_trace(const void* A, const void* W, const float* bia
   EC_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
   const long ntiles = (long)((M + 255) / 256) * ((N + 255) / 256);
   const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k0, dim3(grid), dim3(512), G8_LDS, st, p);
+  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k0, dim3(grid), dim3(512), G8_LDS, st, p);   // (warm clocks: the stamps are read against the launch's wall time)
   p.aux = (const float*)trace;
+  hipEvent_t e0, e1;
+  EC_HIP(hipEventCreate(&e0));
+  EC_HIP(hipEventCreate(&e1));
+  EC_HIP(hipEventRecord(e0, st));
   hipLaunchKernelGGL(k, dim3(grid), dim3(512), G8_LDS_LAB, st, p);
+  EC_HIP(hipEventRecord(e1, st));
   EC_LAUNCH_CHECK();
-  EC_HIP(hipStreamSynchronize(st));
+  EC_HIP(hipEventSynchronize(e1));
+  if (traced_ms) EC_HIP(hipEventElapsedTime(traced_ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return 0;
 }
 #endif

@@ -420,7 +420,7 @@ def test_runtime_switch_matrix(switch):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, **dict(kv.split("=") for kv in switch.split()))
-    sel = "reference_golden or (headline_mode_fp16_mixed_head and cfg2) or (forward_pipelined_bit_equal and 224-4)"
+    sel = "reference_golden or (headline_mode_fp16_mixed_head and cfg2) or (forward_pipelined_bit_equal and 224-4) or support_cache_matches"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_model.py"), os.path.join(here, "test_gpu_precision_modes.py"),
                         os.path.join(here, "test_gpu_next_rows.py"), "-q", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -20,7 +20,7 @@ def main():
     path = os.environ.get("EC_LAB_LIB", build.LIB.replace(".so", "_lab.so"))
     lib = C.CDLL(path)
     vp, ci = C.c_void_p, C.c_int
-    lib.ec_lab_gemm8_trace.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]
+    lib.ec_lab_gemm8_trace.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, C.POINTER(C.c_float)]
     lib.ec_last_error.restype = C.c_char_p
     for name in (sys.argv[1:] or ["qkv", "fc1", "proj", "fc2", "sq4096"]):
         M, N, K, kind = SHAPES[name]
@@ -33,10 +33,14 @@ def main():
         ntiles = ((M + 255) // 256) * ((N + 255) // 256)
         grid = min(ntiles, torch.cuda.get_device_properties(0).multi_processor_count)
         tr = torch.zeros(grid * 64, device="cuda", dtype=torch.int64)
-        rc = lib.ec_lab_gemm8_trace(A.data_ptr(), W.data_ptr(), b.data_ptr(), Cd.data_ptr(), M, N, K, kind, tr.data_ptr(), None)
+        ms = C.c_float()
+        rc = lib.ec_lab_gemm8_trace(A.data_ptr(), W.data_ptr(), b.data_ptr(), Cd.data_ptr(), M, N, K, kind, tr.data_ptr(), None, C.byref(ms))
         assert rc == 0, lib.ec_last_error().decode()
         t = tr.cpu().numpy().reshape(grid, 2, 32).astype(np.int64)
         nk = K // 64
+        span = float(np.mean(t[:, :, 31] - t[:, :, 0]))
+        print(f"== {name}: traced launch {ms.value * 1e3:.1f} us between HIP events (incl. ~2-3 us of launch / event overhead); mean workgroup span "
+              f"{span:.0f} ticks -> {span / (ms.value * 1e3):.0f} ticks per us")
         print(f"== {name}: M={M} N={N} K={K} ({ntiles} tiles of 256x256 on {grid} workgroups, {nk} K-tiles per tile; ideal MFMA time per tile "
               f"{nk * 8 * 16 * 16.1:.0f} cycles = {nk} K-tiles x 8 phase slots x 16 MFMAs x 16.1)")
         for g in range(2):
