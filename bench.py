@@ -35,7 +35,10 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "bf16x3": 2500.0 / 3, "fp32": 157
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=24,
+                    help="timed steps (default 24 = two passes over the 12 backbone blocks: the QKV launch sampled in step i is block i %% depth, "
+                         "so every block weighs the same in roofline.frac - the early blocks of a pipelined step share the chip with the "
+                         "previous step's head, the late ones do not)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="pairs per GPU per step (configs[1]: 32)")
     ap.add_argument("--shots", type=int, default=1)

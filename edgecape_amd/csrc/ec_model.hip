@@ -591,17 +591,13 @@ struct LayerIO {
 // The image K|V of a single-pass fp16 layer (head_precision = EC_MIXED) are STORED as IEEE fp16 (round 3): they come out of a GEMM on
 // fp16-rounded operands, so the extra rounding is of the size of the error they already carry, the projection writes half the bytes
 // (it is bound by its output: the decoder's stacked K|V were 127 MB per step and the most expensive single kernel of the head,
-// 171 us of step time) and the cross attention reads half (attn_split_kernel<64, true>).  EC_KV16=0: fp32 as before.
+// 171 us of step time) and the cross attention reads half (attn_split_kernel<64, true>).
 // The attentions of the single-pass fp16 layers (head_precision = EC_MIXED: skeleton head, decoder layers) with ONE fp16 MFMA per product
-// instead of three bf16 ones (AttnP::one).  The encoder's self-attention, on the proposal argmax's path, stays bf16x3.  EC_ATTN_ONE=0: off.
-static bool attn_one(const ec_model* m, const DecLayer& L) {
-  static const bool off = getenv("EC_ATTN_ONE") && atoi(getenv("EC_ATTN_ONE")) == 0;
-  return !off && m->head_mixed && m->head_split && L.sa_in.h1;
-}
-static bool kv16_on(const ec_model* m, const Lin& kv) {
-  static const bool off = getenv("EC_KV16") && atoi(getenv("EC_KV16")) == 0;
-  return !off && m->head_mixed && m->head_split && kv.h1 && m->E / m->cfg.nhead == 64;
-}
+// instead of three bf16 ones (AttnP::one).  The encoder's self-attention, on the proposal argmax's path, stays bf16x3.
+// (the A/B switches of round 3, EC_ATTN_ONE / EC_KV16, are gone in round 4: the bf16x3 head keeps the three-MFMA attention and the fp32
+//  K|V path alive and tested)
+static bool attn_one(const ec_model* m, const DecLayer& L) { return m->head_mixed && m->head_split && L.sa_in.h1; }
+static bool kv16_on(const ec_model* m, const Lin& kv) { return m->head_mixed && m->head_split && kv.h1 && m->E / m->cfg.nhead == 64; }
 
 static int project_image_kv(ec_model* m, const DecLayer& L, const float* mem, long s_mem, int nb, float* kv, hipStream_t st,
                             const bf16_t* mem16 = nullptr) {

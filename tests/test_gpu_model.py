@@ -409,7 +409,7 @@ def test_support_cache_matches_pairwise_forward(shots):
 
 # Switches of different subsystems share a run (each alternative path is still exercised; a failing pair is bisected by hand): the
 # matrix is ~30 s of GPU-box time per entry.
-@pytest.mark.parametrize("switch", ["EC_CHAIN=0 EC_G8_DYN=1", "EC_OVERLAP=0 EC_KV16=0 EC_DEC_PRE=0", "EC_OVERLAP=1 EC_G8_TAB=0 EC_ATTN_ONE=0",
+@pytest.mark.parametrize("switch", ["EC_CHAIN=0 EC_G8_DYN=1", "EC_OVERLAP=0 EC_DEC_PRE=0", "EC_OVERLAP=1 EC_G8_TAB=0",
                                     "EC_KPT_CHAIN=0 EC_PATCH_X3=0 EC_ENC_CHAIN=0 EC_G8_DYN=0", "EC_GEMM8_OFF=1 EC_COMPACT=2", "EC_PIPE_FULL=0 EC_COMPACT=0"])
 def test_runtime_switch_matrix(switch):
     """Every A/B switch that keeps an alternative code path alive in the shipped library (README "Runtime switches") through the
