@@ -136,7 +136,7 @@ def detector_fixture(name, arch, image_size, shots, seed):
                     img_metas=batch["img_metas"], return_loss=False)
     arrays = dict(preds=res["preds"], boxes=res["boxes"], points=res["points"], skeleton=res["skeleton"],
                   bbox_ids=np.array(res["bbox_ids"], np.int64))
-    meta = dict(kind="detector", arch=arch, image_size=image_size, shots=shots, input_seed=seed, weight_seed=wseed,
+    meta = dict(kind="detector", arch=arch, image_size=list(image_size) if isinstance(image_size, tuple) else image_size, shots=shots, input_seed=seed, weight_seed=wseed,
                 bs=2, reference="orhir/EdgeCape EdgeCape.forward_test with the oracle DINOv2 as torch.hub stand-in")
     save(name, arrays, meta)
 
@@ -384,6 +384,8 @@ def round4_fixtures():
     ns = ref_stubs.install()
     head_fixture(ns, "head_s2_c384_g14x20_kp17", 384, (14, 20), 2, [17, 30], "auto", 105)
     head_fixture(ns, "head_s1_c768_g21x16_mixed", 768, (21, 16), 1, [60, 0], "auto", 106)
+    # the reference DETECTOR on non-square images (forward_test -> decode with img_size = [width, height], head.py:324-387)
+    detector_fixture("det_vits14_229x311_s2", "dinov2_vits14", (229, 311), 2, 203)
 
 
 def main():

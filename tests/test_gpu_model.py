@@ -98,7 +98,7 @@ def test_backbone_vs_hf_golden(arch, image_size):
     assert np.abs(tok.mean(0) - gold["feat_mean"]).max() < 3e-4
 
 
-@pytest.mark.parametrize("name", ["det_vits14_224_s1", "det_vits14_224_s5"])
+@pytest.mark.parametrize("name", ["det_vits14_224_s1", "det_vits14_224_s5", "det_vits14_229x311_s2"])
 def test_forward_test_vs_reference_golden(name):
     """Whole `model(..., return_loss=False)` through the reference-shaped Python face."""
     from edgecape_amd import Config  # noqa: F401
@@ -106,7 +106,8 @@ def test_forward_test_vs_reference_golden(name):
     gold, meta = load_golden(name)
     arch = meta["arch"]
     sd = synth.make_weights(arch, seed=meta["weight_seed"])
-    batch = synth.make_pairs(meta["bs"], meta["shots"], meta["image_size"], seed=meta["input_seed"])
+    size = tuple(meta["image_size"]) if isinstance(meta["image_size"], list) else meta["image_size"]   # (H, W): a non-square fixture (round 4)
+    batch = synth.make_pairs(meta["bs"], meta["shots"], size, seed=meta["input_seed"])
     head_cfg = dict(type="TwoStageHead", in_channels=synth.ARCHS[arch]["C"],
                     transformer=dict(type="TwoStageSupportRefineTransformer", d_model=256, nhead=8, num_encoder_layers=3,
                                      num_decoder_layers=3, dim_feedforward=384, dropout=0.1, similarity_proj_dim=256,
@@ -130,7 +131,7 @@ def test_forward_test_vs_reference_golden(name):
     print(name, "points err valid", ep[:, valid].max(), "all", ep.max(), "skeleton", np.abs(res["skeleton"] - gold["skeleton"]).max())
     assert ep[:, valid].max() < 1e-3                      # north star: 1e-3 abs on normalised coordinates
     assert np.abs(res["skeleton"] - gold["skeleton"]).max() < 1e-4
-    assert np.abs(res["preds"] - gold["preds"])[valid].max() < 0.3   # pixels: 1e-3 * 224 * 1.25
+    assert np.abs(res["preds"] - gold["preds"])[valid].max() < 0.4   # pixels: 1e-3 * 224 (311) * 1.25
     assert np.array_equal(res["boxes"], gold["boxes"])
     assert list(res["bbox_ids"]) == list(gold["bbox_ids"])
     assert np.all(res["preds"][..., 2] == 1)

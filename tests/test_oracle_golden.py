@@ -67,15 +67,17 @@ def test_structural_invariants(name):
         assert np.array_equal(attn[0, b], np.eye(100, dtype=np.float32))
 
 
-@pytest.mark.parametrize("name", ["det_vits14_224_s1", "det_vits14_224_s5"])
+@pytest.mark.parametrize("name", ["det_vits14_224_s1", "det_vits14_224_s5", "det_vits14_229x311_s2"])
 def test_detector_matches_reference(name):
+    """(det_vits14_229x311_s2, round 4: the real reference detector on NON-SQUARE images - decode with img_size = [width, height])"""
     gold, meta = load_golden(name)
     sd = synth.make_weights(meta["arch"], seed=meta["weight_seed"])
-    batch = synth.make_pairs(meta["bs"], meta["shots"], meta["image_size"], seed=meta["input_seed"])
+    size = tuple(meta["image_size"]) if isinstance(meta["image_size"], list) else meta["image_size"]
+    batch = synth.make_pairs(meta["bs"], meta["shots"], size, seed=meta["input_seed"])
     res, _ = orc.forward_test(sd, batch, synth.ARCHS[meta["arch"]]["heads"])
     assert np.abs(res["points"] - gold["points"]).max() <= TOL
     assert np.abs(res["skeleton"] - gold["skeleton"]).max() <= TOL
-    assert np.abs(res["preds"] - gold["preds"]).max() <= 2e-3  # pixels (x224 of 1e-5)
+    assert np.abs(res["preds"] - gold["preds"]).max() <= 3e-3  # pixels (x224 .. x311 of 1e-5)
     assert np.array_equal(res["boxes"], gold["boxes"])
     assert list(res["bbox_ids"]) == list(gold["bbox_ids"])
     assert np.all(res["preds"][..., 2] == 1)  # head.py:374
