@@ -94,6 +94,7 @@ struct ec_model {
   // 5464 / 5466: a deferred head costs the backbone beside it CU time), -0.7 % through ec_forward (4927 -> 4883 / 4901: there the head's
   // LATENCY counts, a chain workgroup takes as long as before and every chain now drags a copy launch behind it).  So: pipelined
   // calls only (compact_mode 1, default); EC_COMPACT=2: every call, EC_COMPACT=0: never.  Results are bit-identical either way.
+  // On ViT-S/14 @224, where the head is as long as the backbone, it is worth +4-5 % (11 170 -> 11 610-11 710 pairs/s).
   int compact_mode = 0;
   bool compact = false;          // ... for the call being enqueued
   // the support half of the head (pooling + SkeletonPredictor) has no query input: it runs on a side stream, concurrently
@@ -673,8 +674,9 @@ struct ChainBuild {
     p.rows = rows; p.lds_bytes = top;
     p.h1 = p.st[0].h1;   // one arithmetic per chain (run_chain checks that every stage was packed for it)
     // two workgroups per slab while that still fits one round of the chip and there is a stage to deal out
-    // (not under a row plan: compaction runs where the head's CU time counts, not its latency - pipelined calls - and two workgroups
-    //  per slab buy latency with duplicated work: both compute the stages that later stages read)
+    // (not under a row plan: two workgroups per slab buy latency with duplicated work - both compute the stages that later stages read.
+    //  Measured with compaction on, two / one workgroup per slab / no compaction, pipelined, interleaved (profiles/r04_compact_split_ab.txt):
+    //  cfg2 5645 / 5645 / 5545 pairs/s, ViT-S/14 @224 11 610 / 11 710 / 11 170 - one per slab is never worse)
     p.split = (!plan && may_split && p.n_stages > 1 && ((rows + CH_BM - 1) / CH_BM) * 2 <= 256) ? 2 : 1;
     if (!plan) return run_chain(p, st);
     p.rowmap = plan->rowmap; p.n_active = plan->plan;
