@@ -172,7 +172,7 @@ def test_headline_mode_fp16_mixed_head(name):
     assert s["adj_err"] < 1e-4
 
 
-def conformance_at_scale(n_batches=8, wseeds=(0, 1), backbone="fp16", head="mixed", name="cfg2"):
+def conformance_at_scale(n_batches=8, wseeds=(0, 1), backbone="fp16", head="mixed", name="cfg2", outliers=False):
     """The headline precision against the oracle on n_batches x bs pairs per weight seed (cfg2: 8 x 32 = 256 pairs, 2 seeds): the
     MEASURED rate of argmax flips and of keypoints outside 1e-3, instead of one lucky 32-pair sample.  Returns one stats dict per
     weight seed plus the pooled one.  (Also run by tools/conformance.py, which writes the record under profiles/.)"""
@@ -182,7 +182,7 @@ def conformance_at_scale(n_batches=8, wseeds=(0, 1), backbone="fp16", head="mixe
     torch.set_num_threads(min(32, torch.get_num_threads()))
     per_seed, pooled_got, pooled_ref, pooled_valid = [], [], [], []
     for ws in wseeds:
-        w = synth.make_weights(c["arch"], seed=ws)
+        w = synth.make_weights(c["arch"], seed=ws, outliers=outliers)   # outliers: planted DINOv2-like activation statistics (synth.add_activation_outliers)
         eng = HipEngine(w, arch=c["arch"], image_size=c["H"], max_batch=c["bs"], max_shots=c["S"], backbone_precision=backbone, head_precision=head)
         gots, refs, valids = [], [], []
         for b in range(n_batches):

@@ -19,11 +19,12 @@ ap.add_argument("--head", default="mixed")
 ap.add_argument("--batches", type=int, default=8)
 ap.add_argument("--seeds", default="0,1")
 ap.add_argument("--config", default="cfg2", help="cfg1 | cfg2 | cfg4 | cfg5 (tests/test_gpu_precision_modes.py CFG)")
+ap.add_argument("--outliers", action="store_true", help="weights with planted DINOv2-like activation outliers (synth.add_activation_outliers)")
 ap.add_argument("--out", default=None)
 a = ap.parse_args()
-per_seed, pooled = T.conformance_at_scale(a.batches, tuple(int(x) for x in a.seeds.split(",")), a.backbone, a.head, a.config)
+per_seed, pooled = T.conformance_at_scale(a.batches, tuple(int(x) for x in a.seeds.split(",")), a.backbone, a.head, a.config, outliers=a.outliers)
 c = T.CFG[a.config]
-rec = dict(config=f"{a.config}: {c['S']}-shot, batch {c['bs']}, {c['H']}x{c['H']}, {c['arch']}; {a.batches} disjoint batches per weight seed", backbone=a.backbone, head=a.head, oracle="oracle/edgecape_oracle.py (fp32 CPU)",
+rec = dict(config=f"{a.config}: {c['S']}-shot, batch {c['bs']}, {c['H']}x{c['H']}, {c['arch']}; {a.batches} disjoint batches per weight seed" + ("; weights with planted activation outliers" if a.outliers else ""), backbone=a.backbone, head=a.head, oracle="oracle/edgecape_oracle.py (fp32 CPU)",
            tolerance="1e-3 abs on output_kpts of valid keypoints", per_weight_seed=per_seed, pooled=pooled)
 print(json.dumps(rec, indent=1))
 if a.out:
