@@ -213,8 +213,28 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  // XCD-aware workgroup map (round 5).  Workgroups are dealt to the eight XCDs round-robin by their linear id, and each XCD has its
+  // own L2: with a (query block, head, image) grid the query blocks of one (image, head) - consecutive ids - landed on DIFFERENT XCDs
+  // and every one of them pulled that head's K / V through its own L2 (FETCH_SIZE: exactly 7/3 of the Q|K|V bytes at three query
+  // blocks, profiles/r04_qkv_gemm_pmc_kernels.csv).  1-D launch; id L -> xcd = L % 8, slot = L / 8; the nqb query blocks of an item
+  // take consecutive slots of ONE xcd: item = (slot / nqb) * 8 + xcd, query block = slot % nqb.  Bijective on the first
+  // (items / 8) * 8 * nqb ids; the at most seven items left over keep the plain order.
+  int item, qb;
+  {
+    const int nqb = (p.Lq + 127) >> 7, NI = p.H * p.B, L = blockIdx.x;
+    const int Gm = (NI >> 3) * 8 * nqb;
+    if (p.plain_map) {
+      item = L / nqb; qb = L - item * nqb;
+    } else if (L < Gm) {
+      const int slot = L >> 3, grp = slot / nqb;
+      item = grp * 8 + (L & 7); qb = slot - grp * nqb;
+    } else {
+      const int Lt = L - Gm, it = Lt / nqb;
+      item = (NI & ~7) + it; qb = Lt - it * nqb;
+    }
+  }
+  const int b = item / p.H, h = item - b * p.H;
+  const int q0 = qb * 128 + wave * 32;
   const char* Qb = (const char*)p.Q + ((long)b * p.sQ + h * 64) * 2;
   const char* Kb = (const char*)p.K + ((long)b * p.sK + h * 64) * 2;
   const char* Vb = (const char*)p.V + ((long)b * p.sV + h * 64) * 2;
@@ -261,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
   stage(0, smem);
   int cur = 0;
   const bool active = q0 < p.Lq;   // a wave whose 32 queries are all past Lq only helps staging (wave-uniform)
-  const bool tr_on = TRACE && blockIdx.x == gridDim.x / 2;
+  const bool tr_on = TRACE && blockIdx.x == gridDim.x / 2;   // (one mid-grid workgroup)
   for (int k0 = 0; k0 < p.Lk; k0 += 64) {
     A16_STAMP(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -735,7 +755,7 @@ int attention(const AttnP& p, hipStream_t st) {
       EC_HIP(hipMemsetAsync(d_tr, 0, 4 * 128 * sizeof(unsigned), st));
       AttnP q = p;
       q.bias = (const float*)d_tr;
-      hipLaunchKernelGGL((attn_bf16_kernel<true, false>), grid, dim3(256), A16_LDS, st, q);
+      hipLaunchKernelGGL((attn_bf16_kernel<true, false>), dim3(grid.x * grid.y * grid.z), dim3(256), A16_LDS, st, q);
       EC_LAUNCH_CHECK();
       EC_HIP(hipStreamSynchronize(st));
       unsigned h[4 * 128];
@@ -755,8 +775,11 @@ int attention(const AttnP& p, hipStream_t st) {
       return 0;
     }
     EC_REQUIRE((long)p.Lk * p.ldk * 2 < (1l << 31) && (long)p.Lk * p.ldv * 2 < (1l << 31), -1, "attention(bf16): K / V rows of one head beyond 2 GiB");
-    if (p.f16) hipLaunchKernelGGL((attn_bf16_kernel<false, true>), grid, dim3(256), A16_LDS, st, p);
-    else hipLaunchKernelGGL((attn_bf16_kernel<false, false>), grid, dim3(256), A16_LDS, st, p);
+    static const bool plain = getenv("EC_ATTN_PLAIN") && atoi(getenv("EC_ATTN_PLAIN")) != 0;   // A/B switch of the round-5 measurement
+    AttnP q = p;
+    q.plain_map = plain ? 1 : 0;
+    if (p.f16) hipLaunchKernelGGL((attn_bf16_kernel<false, true>), dim3(grid.x * grid.y * grid.z), dim3(256), A16_LDS, st, q);
+    else hipLaunchKernelGGL((attn_bf16_kernel<false, false>), dim3(grid.x * grid.y * grid.z), dim3(256), A16_LDS, st, q);
     EC_LAUNCH_CHECK();
     return 0;
   }

@@ -55,9 +55,15 @@ struct ChainP {
   // (head.py:187 multiplies the pooled support features by mask_s; adjacency rows / columns and key masks of masked tokens are
   // zeroed, skeleton.py:186-189), 62 % of the token rows on average.  With a plan (ec_ops.hip rowplan): slab row i of the launch
   // is token row rowmap[i], i < *n_active - every valid token plus ONE representative masked token per sample; workgroups past
-  // *n_active leave at once.  The masked rows that were not computed are filled in by bcast_rows (ec_ops.h) right behind the launch.
+  // *n_active leave at once.
   const int* rowmap = nullptr;
   const int* n_active = nullptr;
+  // ... and every global output row of a representative is copied, inside the kernel, to the token rows of its sample's other masked
+  // tokens (round 5; round 4: a bcast_rows launch behind every chain): active index i fans out to fan_cnt[i] rows fan_dst[fan_off[i] ..]
+  // (0 for valid tokens), so every token row of every output is (re)written by every launch, as without compaction.
+  const int* fan_off = nullptr;
+  const int* fan_cnt = nullptr;
+  const int* fan_dst = nullptr;
   int trace_stage = -1;        // TRACE: stage whose K loop / epilogue is stamped finely into trace[64..127]
   unsigned* trace = nullptr;   // EC_CHAIN_TRACE=1 (debug instantiation): s_memtime stamps of one mid-grid workgroup's wave 0
 };

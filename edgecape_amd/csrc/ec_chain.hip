@@ -93,7 +93,15 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
   if (row0 >= n_rows) return;                       // whole workgroup, before any barrier
   int* const rowm = (int*)(smem + 3072);            // [32] (CH_RED = 4096: LayerNorm partials 0..2047, keypoint tail ..2303)
   auto map_row = [&](int i) { const int c = min(i, n_rows - 1); return p.rowmap ? p.rowmap[c] : c; };
-  if (tid < CH_BM) rowm[tid] = map_row(row0 + tid);
+  // Fan-out of the representative rows (ChainP::fan_*): slab row r is written to fanc[r] further token rows fan_dst[fano[r] ..]
+  int* const fano = (int*)(smem + 3200);            // [32]
+  int* const fanc = (int*)(smem + 3328);            // [32]
+  if (tid < CH_BM) {
+    rowm[tid] = map_row(row0 + tid);
+    const bool on = p.fan_cnt != nullptr && row0 + tid < n_rows;
+    fano[tid] = on ? p.fan_off[row0 + tid] : 0;
+    fanc[tid] = on ? p.fan_cnt[row0 + tid] : 0;
+  }
   int grow_l[2];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) grow_l[mi] = map_row(row0 + mi * 16 + lrow);
@@ -313,7 +321,11 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
           const float z = dl + logf(fmaxf(x, 1e-3f) / fmaxf(1.f - x, 1e-3f));
           const float bn = 1.f / (1.f + expf(-z));
           coord[r * 2 + c] = bn;
-          if (row0 + r < n_rows && part == 0) S.kp_next[(long)gr * 2 + c] = bn;
+          if (row0 + r < n_rows && part == 0) {
+            S.kp_next[(long)gr * 2 + c] = bn;
+            const int* dl = p.fan_dst + fano[r];
+            for (int dd = 0; dd < fanc[r]; ++dd) S.kp_next[(long)dl[dd] * 2 + c] = bn;   // (the sample's other masked tokens)
+          }
         }
         __syncthreads();
         if (kp_sine) {   // sine embedding of b_next -> the operand buffer of the next stage (positional_encoding.py; sincos_kernel)
@@ -440,6 +452,24 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
       ++i;
     }
     stamp();   // stage done (K loop + epilogues)
+    if (p.fan_cnt && store_out) {
+      // Row compaction: the masked token rows that were not computed equal their sample's representative row.  Its freshly stored
+      // output row (this workgroup's own stores: visible to the whole workgroup behind the barrier) is copied to them by all 512
+      // threads - ~60 rows per representative, about one representative per slab.  (Round 4 did this with a bcast_rows launch behind
+      // every chain: 27 launches per step on the head's dependent lanes.)
+      __syncthreads();
+      const int q4 = S.N >> 2;
+      for (int r = 0; r < CH_BM; ++r) {
+        const int cnt = fanc[r];
+        if (cnt == 0) continue;   // (workgroup-uniform)
+        const float* src = S.out + (long)rowm[r] * S.ldo;
+        const int* dl = p.fan_dst + fano[r];
+        for (int q = tid; q < cnt * q4; q += 512) {
+          const int dd = q / q4, c = (q - dd * q4) << 2;
+          *(f32x4*)(S.out + (long)dl[dd] * S.ldo + c) = *(const f32x4*)(src + c);
+        }
+      }
+    }
   }
 }
 
@@ -476,6 +506,7 @@ ChDev ch_dev[64];
 int run_chain(const ChainP& p, hipStream_t st) {
   EC_REQUIRE(p.rows > 0 && p.n_stages >= 1 && p.n_stages <= CH_MAX_STAGES, -1, "chain: bad stage count");
   EC_REQUIRE(p.split == 1 || p.split == 2, -1, "chain: split");
+  EC_REQUIRE(!p.fan_cnt || (p.rowmap && p.fan_off && p.fan_dst && p.split == 1), -1, "chain: row fan-out needs a row map and one workgroup per slab");
   EC_REQUIRE(p.lds_bytes >= CH_RED && p.lds_bytes <= 160 * 1024, -1, "chain: LDS layout does not fit");
   for (int s = 0; s < p.n_stages; ++s) {
     const ChainStage& S = p.st[s];

@@ -11,7 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
-
+#include <functional>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -87,9 +87,11 @@ struct ec_model {
   bool cur_h1 = false;       // build time: the Lin being made belongs to that set
   bool head_chain = false;   // ... and the row-wise stretches of every head layer as row-chain launches (ec_chain.hip); EC_CHAIN=0: off
   // Row compaction of the token-row chains (round 4; ec_ops.h rowplan): the chains compute the valid keypoint tokens and one
-  // representative masked token per sample, bcast_rows fills in the other masked rows.  EC_COMPACT=0: every row is computed as before.
-  struct RowPlan { int* plan = nullptr; int* rowmap = nullptr; int* csrc = nullptr; int* cdst = nullptr; int max_pairs = 0; };
+  // representative masked token per sample, whose output rows the kernel also writes to the sample's other masked rows.  EC_COMPACT=0: every row is computed.
+  struct RowPlan { int* plan = nullptr; int* rowmap = nullptr; int* fan_off = nullptr; int* fan_cnt = nullptr; int* cdst = nullptr; };
   RowPlan plan_dec, plan_skel;   // bs samples (decoder, keypoint branches) / S * bs samples (skeleton head)
+  const RowPlan* skel_plan = nullptr;   // the plan the skeleton head of the call being enqueued reads (build_row_plans): plan_dec when one
+                                        // plan over the same samples serves both (S == 1, both built from the same mask), else plan_skel
   // Measured (profiles/r04_compact_ab.txt, cfg2, interleaved): +1.5 % pairs/s through ec_forward_pipelined (5384 / 5385 / 5398 -> 5481 /
   // 5464 / 5466: a deferred head costs the backbone beside it CU time), -0.7 % through ec_forward (4927 -> 4883 / 4901: there the head's
   // LATENCY counts, a chain workgroup takes as long as before and every chain now drags a copy launch behind it).  So: pipelined
@@ -97,6 +99,8 @@ struct ec_model {
   // On ViT-S/14 @224, where the head is as long as the backbone, it is worth +4-5 % (11 170 -> 11 610-11 710 pairs/s).
   int compact_mode = 0;
   bool compact = false;          // ... for the call being enqueued
+  bool episode_call = false;     // ... which is an episode-cache call: the support lane's samples (new episodes) are not the query lane's, so
+                                 // the skeleton head builds a plan of its own (plan_skel) and the query lane builds the decoder's from the gathered masks
   // the support half of the head (pooling + SkeletonPredictor) has no query input: it runs on a side stream, concurrently
   // with input_proj / encoder / proposal generator on the caller's stream (both are small-grid, latency-bound kernels)
   hipStream_t side = nullptr;
@@ -465,12 +469,16 @@ static int ln(const float* x, long ldx, void* y, long ldy, int y16, const Norm& 
 // The images may come from several tensors of n_each images (query batch + S support batches): they are
 // gathered by the im2col step so that the whole ViT runs ONCE over n = n_src * n_each images (one large-M GEMM
 // per layer instead of 1+S smaller ones).
-static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_each, float* feat_out, hipStream_t st) {
+// The sources may hold different numbers of images (counts[s]; the streaming episode path: a batch of queries + the support images of
+// the episodes that start in this call); a source with no image is skipped.
+static int run_backbone(ec_model* m, const float* const* imgs, const int* counts, int n_src, float* feat_out, hipStream_t st) {
   const int C = m->C, T = m->T, HW = m->HW;
   const bool h16 = m->bb16;
   const int hfmt = h16 ? (m->bbf16 ? 2 : 1) : 0;   // 16-bit storage format: 0 fp32, 1 bf16, 2 fp16
   const int nh = m->cfg.num_heads;
-  const int n = n_src * n_each;
+  int n = 0;
+  for (int s = 0; s < n_src; ++s) n += counts[s];
+  EC_REQUIRE(n > 0 && n <= m->n_img_max, EC_ERR_ARG, "backbone: image count outside 1..(1+max_shots)*max_batch");
   const long M = (long)n * T;
   // fp16 backbone: the patch embedding in SPLIT precision (round 3).  The image patches and the patch weights rounded to fp16 carry 38 %
   // of the error variance of the backbone's features (oracle/precision_sites.py) - every later block inherits it through the residual
@@ -478,8 +486,9 @@ static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_
   // computes the products to ~2^-22.  EC_PATCH_X3=0: single fp16 operands as before.
   const bool px3 = m->patch_w16x3 != nullptr;
   const int Kpe = px3 ? 3 * m->Kp : m->Kp;
-  for (int s = 0; s < n_src; ++s)
-    RUN(im2col14(imgs[s], (char*)m->bb_h + (size_t)s * n_each * T * Kpe * (h16 ? 2 : 4), px3 ? 3 : hfmt, n_each, m->H, m->W, m->gh, m->gw, m->Kp, st));
+  for (int s = 0, at = 0; s < n_src; at += counts[s], ++s)
+    if (counts[s] > 0)
+      RUN(im2col14(imgs[s], (char*)m->bb_h + (size_t)at * T * Kpe * (h16 ? 2 : 4), px3 ? 3 : hfmt, counts[s], m->H, m->W, m->gh, m->gw, m->Kp, st));
   {  // patch embedding: ONE GEMM over all n*T token rows (the zero cls rows produce bias + pos[0], overwritten below);
      // epilogue adds the conv bias and the positional table row m % T
     GemmP p;
@@ -549,6 +558,10 @@ static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_
   }
   RUN(ln(m->bb_x, C, feat_out ? feat_out : m->feat, C, 0, m->bnorm, (int)M, C, 1e-6f, st, T, pend, C, pend2, false, hfmt));
   return 0;
+}
+static int run_backbone(ec_model* m, const float* const* imgs, int n_src, int n_each, float* feat_out, hipStream_t st) {
+  std::vector<int> counts(n_src, n_each);
+  return run_backbone(m, imgs, counts.data(), n_src, feat_out, st);
 }
 
 // One TransformerDecoderLayer (encoder_decoder.py:584-651) on nb = batch entries.
@@ -680,26 +693,8 @@ struct ChainBuild {
     p.split = (!plan && may_split && p.n_stages > 1 && ((rows + CH_BM - 1) / CH_BM) * 2 <= 256) ? 2 : 1;
     if (!plan) return run_chain(p, st);
     p.rowmap = plan->rowmap; p.n_active = plan->plan;
-    RUN(run_chain(p, st));
-    // every global output of the chain: the masked rows that were not computed equal their sample's representative row
-    BcastP t;
-    auto flush = [&]() -> int {
-      const int rc = bcast_rows(t, plan->plan, plan->csrc, plan->cdst, std::min(plan->max_pairs, rows), st);
-      t = BcastP();
-      return rc;
-    };
-    for (int i = 0; i < p.n_stages; ++i) {
-      const ChainStage& S = p.st[i];
-      if (S.out) {
-        t.ptr[t.n] = S.out; t.ld[t.n] = S.ldo; t.ncols[t.n] = S.N; ++t.n;
-        if (t.n == 4) RUN(flush());
-      }
-      if (S.kp_next) {
-        t.ptr[t.n] = S.kp_next; t.ld[t.n] = 2; t.ncols[t.n] = 2; ++t.n;
-        if (t.n == 4) RUN(flush());
-      }
-    }
-    return flush();
+    p.fan_off = plan->fan_off; p.fan_cnt = plan->fan_cnt; p.fan_dst = plan->cdst;   // (the masked rows that are not computed: written in-kernel)
+    return run_chain(p, st);
   }
 };
 static void chain_lin(ChainStage& S, const Lin& W) { S.W = W.wc; S.bias = W.b; S.N = W.N; S.K = W.K; S.k1 = W.K; S.h1 = W.h1 ? 1 : 0; }
@@ -916,13 +911,44 @@ struct SupportState {
 // the skeleton head's over S * bs (shot-major token rows; one shot: the same plan).
 static int build_row_plans(ec_model* m, const float* mask, int bs, int S, hipStream_t st, bool dec = true, bool skel = true) {
   if (!m->compact) return 0;
-  if (dec || S == 1) RUN(rowplan(mask, bs, bs, m->K, m->plan_dec.plan, m->plan_dec.rowmap, m->plan_dec.csrc, m->plan_dec.cdst, st));
-  if (skel && S > 1) RUN(rowplan(mask, bs, S * bs, m->K, m->plan_skel.plan, m->plan_skel.rowmap, m->plan_skel.csrc, m->plan_skel.cdst, st));
+  if (dec) RUN(rowplan(mask, bs, bs, m->K, m->plan_dec.plan, m->plan_dec.rowmap, m->plan_dec.fan_off, m->plan_dec.fan_cnt, m->plan_dec.cdst, st));
+  if (skel) {
+    // (chosen by the RUNTIME S: a model built for max_shots > 1 and called with one shot reads the decoder's plan - round 4 skipped
+    //  both branches in that case and the skeleton head ran on a stale plan)
+    if (S == 1 && dec) m->skel_plan = &m->plan_dec;
+    else {
+      RUN(rowplan(mask, bs, S * bs, m->K, m->plan_skel.plan, m->plan_skel.rowmap, m->plan_skel.fan_off, m->plan_skel.fan_cnt, m->plan_skel.cdst, st));
+      m->skel_plan = &m->plan_skel;
+    }
+  }
   return 0;
 }
 
+// Markov-bias MLP of every decoder layer (bias_attn.py:188-191): depends on attn_adj only, so it rides with the support side (or, with
+// the episode cache, behind the gather of the queries' Markov stacks).  out: [dec_layers][bs, nhead, K, K].
+static int decoder_bias_all(ec_model* m, const float* attn_adj, float* out, int bs, hipStream_t st) {
+  const int K = m->K, hops1 = m->cfg.max_hops + 1;
+  const int nl = (int)m->dec.size();
+  const size_t per = (size_t)bs * m->cfg.nhead * K * K;
+  if (nl <= 4) {   // all layers in one launch when the fused shape applies
+    const float *w1[4], *b1[4], *w2[4], *b2[4];
+    for (int li = 0; li < nl; ++li) { w1[li] = m->dec[li].m_w1; b1[li] = m->dec[li].m_b1; w2[li] = m->dec[li].m_w2; b2[li] = m->dec[li].m_b2; }
+    const int rc = bias_mlp_layers(attn_adj, w1, b1, w2, b2, nl, out, (long)per, hops1, m->cfg.max_hops + m->cfg.nhead, m->cfg.nhead, bs, K, st);
+    if (rc < 0) return rc;
+    if (rc == 1) return 0;
+  }
+  for (int li = 0; li < nl; ++li) {
+    const DecLayer& Ld = m->dec[li];
+    RUN(bias_mlp(attn_adj, Ld.m_w1, Ld.m_b1, Ld.m_w2, Ld.m_b2, out + li * per, hops1, m->cfg.max_hops + m->cfg.nhead, m->cfg.nhead, bs, K, st));
+  }
+  return 0;
+}
+
+typedef std::function<int(hipStream_t)> StreamHook;   // extra work of the episode-cache paths at a fixed point of a lane
+
 static int run_head_support(ec_model* m, const float* const* fs, const float* const* target_s, const float* mask_s, int bs, int S,
-                            hipStream_t st, const SupportState& ss, hipEvent_t ev_sk = nullptr, int part = 0) {
+                            hipStream_t st, const SupportState& ss, hipEvent_t ev_sk = nullptr, int part = 0,
+                            const StreamHook& on_sk = nullptr) {
   const int C = m->C, d = m->d, K = m->K, HW = m->HW, gh = m->gh, gw = m->gw;
   const int Fs = m->cfg.skel_ffn_dim, hops1 = m->cfg.max_hops + 1;
   const int Mk = bs * K, Mi = bs * HW;
@@ -938,7 +964,7 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
   const int nsk = (int)m->skel.size();
   if (part == 1) {
     RUN(adj_build(m->d_edges, m->d_off, mask_s, ss.valid, ss.kmask, ss.kmask_fixed, m->binary, m->adj_r1, bs, K, st));
-    RUN(build_row_plans(m, mask_s, bs, S, st));
+    RUN(build_row_plans(m, mask_s, bs, S, st, !m->episode_call, true));
     for (int s = 0; s < S; ++s)
       RUN(pool_taps(target_s[s], mask_s, 1.f / (float)S, m->tap_n + (long)s * Mk, m->tap_i + (long)s * Mk * HW, m->tap_w + (long)s * Mk * HW,
                     bs, K, m->cfg.heatmap_size, gh, gw, st));
@@ -951,7 +977,7 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
       // adjacency from the skeleton edges + key masks (skeleton.py:58-75): needs only the edges and the keypoint mask, so with the helper
       // lane it runs there FIRST, beside the pooling chain, instead of between query_proj and the first layer on the critical lane
       RUN(adj_build(m->d_edges, m->d_off, mask_s, ss.valid, ss.kmask, ss.kmask_fixed, m->binary, m->adj_r1, bs, K, s2));
-      RUN(build_row_plans(m, mask_s, bs, S, s2));
+      RUN(build_row_plans(m, mask_s, bs, S, s2, !m->episode_call, true));
       EC_HIP(hipEventRecord(ev_adjb, s2));
     }
   }
@@ -987,8 +1013,9 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
   else if (ov2) EC_HIP(hipStreamWaitEvent(st, ev_adjb, 0));
   else {
     RUN(adj_build(m->d_edges, m->d_off, mask_s, ss.valid, ss.kmask, ss.kmask_fixed, m->binary, m->adj_r1, bs, K, st));
-    RUN(build_row_plans(m, mask_s, bs, S, st));
+    RUN(build_row_plans(m, mask_s, bs, S, st, !m->episode_call, true));
   }
+  if (on_sk) RUN(on_sk(st));                      // (streaming episodes: the tokens and masks go to their cache slots first)
   if (ev_sk) EC_HIP(hipEventRecord(ev_sk, st));   // support tokens + key masks are ready: the encoder may start
 
   // (3) skeleton head (skeleton.py:58-161).  Two lanes: the token path of every layer (self-attention, token->image cross
@@ -1006,7 +1033,7 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
     io.x_final = &sx; io.ldx_final = &sx_ld;
     io.adj1 = m->adj_r1; io.valid = ss.valid; io.kmask_fixed = ss.kmask_fixed; io.bias = nullptr;
     io.nb = nb; io.bs = bs;
-    io.plan = m->compact ? &m->plan_skel : nullptr;
+    io.plan = m->compact ? m->skel_plan : nullptr;
     io.update_mem = false;                       // done below, on s2
     io.kv_pre = m->s_kv; io.ld_kv_pre = 2 * m->E; io.kv16 = kv16_on(m, m->skel[i].ca_kv);
     if (ov2) {
@@ -1068,31 +1095,17 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
       RUN(mm(attn_adj + 2 * hop, A1, attn_adj + 3 * hop));
     }
   }
-  bool bias_done = false;
-  if (ss.dec_bias) {   // all decoder layers' Markov-bias MLPs in one launch when the fused shape applies
-    const float *w1[4], *b1[4], *w2[4], *b2[4];
-    const int nl = (int)m->dec.size();
-    if (nl <= 4) {
-      for (int li = 0; li < nl; ++li) { w1[li] = m->dec[li].m_w1; b1[li] = m->dec[li].m_b1; w2[li] = m->dec[li].m_w2; b2[li] = m->dec[li].m_b2; }
-      const int rc = bias_mlp_layers(attn_adj, w1, b1, w2, b2, nl, ss.dec_bias, (long)bs * m->cfg.nhead * K * K, hops1,
-                                     m->cfg.max_hops + m->cfg.nhead, m->cfg.nhead, bs, K, st);
-      if (rc < 0) return rc;
-      bias_done = rc == 1;
-    }
-  }
-  if (ss.dec_bias && !bias_done)   // Markov-bias MLP of every decoder layer: depends on attn_adj only, so it rides with the support side
-    for (size_t li = 0; li < m->dec.size(); ++li) {
-      const DecLayer& Ld = m->dec[li];
-      RUN(bias_mlp(attn_adj, Ld.m_w1, Ld.m_b1, Ld.m_w2, Ld.m_b2, ss.dec_bias + li * (size_t)bs * m->cfg.nhead * K * K, hops1,
-                   m->cfg.max_hops + m->cfg.nhead, m->cfg.nhead, bs, K, st));
-    }
+  if (ss.dec_bias) RUN(decoder_bias_all(m, attn_adj, ss.dec_bias, bs, st));
   RUN(tl_mark(m, "S.end", st));
   return 0;
 }
 
 // Query half of TwoStageHead.forward (head.py:169-173, 202-222): input_proj, encoder, proposal generator, decoder, kpt branches.
+// after_sk / before_dec (episode cache): run on the query lane once it has waited for wait_sk / wait_adj - they gather the cached
+// support tokens + masks, and the adjacency stack (+ the decoder's Markov bias), of every query's episode into `ss`.
 static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, const ec_outputs* out, const SupportState& ss,
-                          hipEvent_t wait_sk = nullptr, hipEvent_t wait_adj = nullptr) {
+                          hipEvent_t wait_sk = nullptr, hipEvent_t wait_adj = nullptr, const StreamHook& after_sk = nullptr,
+                          const StreamHook& before_dec = nullptr) {
   const int C = m->C, d = m->d, E = m->E, K = m->K, HW = m->HW, L = m->L, nh = m->cfg.nhead;
   const int Fd = m->cfg.ffn_dim, hops1 = m->cfg.max_hops + 1;
   const int Mk = bs * K;
@@ -1172,6 +1185,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
   if (m->dq_active && m->ev_feat_read_q) EC_HIP(hipEventRecord(m->ev_feat_read_q, st));
   RUN(tl_mark(m, "Q.inproj", st));
   if (wait_sk) EC_HIP(hipStreamWaitEvent(st, wait_sk, 0));
+  if (after_sk) RUN(after_sk(st));
   RUN(copy3d(m->e_x + (long)HW * d, d, (long)L * d, ss.sk, d, (long)K * d, bs, K, d, st));
 
   // (4) encoder (encoder_decoder.py:276-310, 461-483) over [bs, L = HW + K, d]
@@ -1285,6 +1299,11 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
   RUN(copy3d(m->d_qin, 2 * d, (long)K * 2 * d, kp, d, s_tok, bs, K, d, st));
   // adjacency / Markov stack from the support side: first needed by layer 0's self-attention kernel (bias, key mask) - its input
   // projection runs before the wait.  Without the precomputed bias stack the bias MLP itself reads attn_adj: wait here.
+  if (before_dec) {   // (the hook fills ss.adj1 / attn_adj / dec_bias on THIS stream: nothing left to wait for further down)
+    if (wait_adj) EC_HIP(hipStreamWaitEvent(st, wait_adj, 0));
+    RUN(before_dec(st));
+    wait_adj = nullptr;
+  }
   if (wait_adj && !ss.dec_bias) EC_HIP(hipStreamWaitEvent(st, wait_adj, 0));
   RUN(tl_mark(m, "Q.adjwait", st));
   float* dx = m->d_qin;                       // token state: left half of d_qin, ping-ponging with d_tmp under two-workgroup chains
@@ -1416,9 +1435,10 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
 }  // namespace ec
 struct ec_support {
   ec_model* m = nullptr;
-  int cap = 0, n = 0, S = 0;
-  ec::SupportState ss;
-  int32_t* d_idx = nullptr;
+  int cap = 0;
+  ec::SupportState ss;    // `cap` slots: one cached episode each (attn_adj: [hops+1][cap][K][K])
+  ec::SupportState stg;   // staging of the episodes a call encodes, in run_head_support's dense layout; scattered into their slots
+  std::vector<char> filled;
   std::vector<void*> owned;
 };
 namespace ec {
@@ -1815,14 +1835,13 @@ int ec_finalize(ec_handle m) {
   WS(d_att, Mk * E); WS(d_tmp, Mk * d); WS(d_qc, Mk * E); WS(d_kv, Mi * 2 * E * m->cfg.dec_layers); WS(d_y, Mk * 2 * Fd); WS(d_z, Mk * Fd);
   WS(d_hs, (size_t)m->cfg.dec_layers * Mk * d); WS(d_pts, (size_t)(m->cfg.dec_layers + 1) * Mk * 2); WS(d_k1, Mk * d); WS(d_k2, Mk * d); WS(d_k3, Mk * d); WS(d_k4, Mk * d);
 #undef WS
-  m->compact_mode = (m->head_chain && K <= 128) ? (getenv("EC_COMPACT") ? atoi(getenv("EC_COMPACT")) : 1) : 0;
+  m->compact_mode = (m->head_chain && K <= 128) ? (getenv("EC_COMPACT") ? atoi(getenv("EC_COMPACT")) : 2) : 0;
   if (m->compact_mode) {
     for (int which = 0; which < 2; ++which) {
       ec_model::RowPlan& pl = which ? m->plan_skel : m->plan_dec;
       const size_t rows = (which ? (size_t)S : 1) * Mk;
-      if (which && S == 1) { pl = m->plan_dec; break; }   // one shot: the skeleton head's token rows are the decoder's
-      if ((rc = dalloc(m, &pl.plan, 4)) || (rc = dalloc(m, &pl.rowmap, rows)) || (rc = dalloc(m, &pl.csrc, rows)) || (rc = dalloc(m, &pl.cdst, rows))) return rc;
-      pl.max_pairs = (int)rows;
+      if ((rc = dalloc(m, &pl.plan, 4)) || (rc = dalloc(m, &pl.rowmap, rows)) || (rc = dalloc(m, &pl.fan_off, rows)) || (rc = dalloc(m, &pl.fan_cnt, rows)) ||
+          (rc = dalloc(m, &pl.cdst, rows))) return rc;
       EC_HIP(hipMemset(pl.plan, 0, 4 * sizeof(int)));
     }
   }
@@ -1965,20 +1984,25 @@ int ec_pipeline_flush(ec_handle m, void* stream) {
 // (head.py:196-200).  ec_support_encode runs it once per episode, ec_forward_cached runs only the query side.
 int ec_support_create(ec_handle m, int max_episodes, ec_support_t* out) {
   EC_REQUIRE(m && m->finalized && out, EC_ERR_STATE, "model not finalized");
-  EC_REQUIRE(max_episodes > 0 && max_episodes <= m->cfg.max_batch, EC_ERR_ARG, "max_episodes must be within 1..max_batch");
+  EC_REQUIRE(max_episodes > 0, EC_ERR_ARG, "max_episodes must be positive");
   ec_support* c = new ec_support();
   c->m = m; c->cap = max_episodes;
-  const size_t n = max_episodes, K = m->K, d = m->d, KK = K * K;
+  c->filled.assign(max_episodes, 0);
+  const size_t K = m->K, d = m->d, KK = K * K, hops1 = m->cfg.max_hops + 1;
   auto al = [&](void** p, size_t bytes) -> int {
     EC_HIP(hipMalloc(p, bytes));
     c->owned.push_back(*p);
     return 0;
   };
   int rc = 0;
-  if ((rc = al((void**)&c->ss.sk, n * K * d * 4)) || (rc = al((void**)&c->ss.valid, n * K * 4)) || (rc = al((void**)&c->ss.kmask, n * K)) ||
-      (rc = al((void**)&c->ss.kmask_fixed, n * K)) || (rc = al((void**)&c->ss.adj1, n * KK * 4)) ||
-      (rc = al((void**)&c->ss.adj_out, n * 2 * KK * 4)) || (rc = al((void**)&c->ss.attn_adj, (m->cfg.max_hops + 1) * n * KK * 4)) ||
-      (rc = al((void**)&c->d_idx, (size_t)m->cfg.max_batch * 4))) {
+  for (int which = 0; which < 2 && !rc; ++which) {
+    SupportState& t = which ? c->stg : c->ss;
+    const size_t n = which ? (size_t)std::min(max_episodes, m->cfg.max_batch) : (size_t)max_episodes;   // (a call encodes <= max_batch episodes)
+    (rc = al((void**)&t.sk, n * K * d * 4)) || (rc = al((void**)&t.valid, n * K * 4)) || (rc = al((void**)&t.kmask, n * K)) ||
+        (rc = al((void**)&t.kmask_fixed, n * K)) || (rc = al((void**)&t.adj1, n * KK * 4)) || (rc = al((void**)&t.adj_out, n * 2 * KK * 4)) ||
+        (rc = al((void**)&t.attn_adj, hops1 * n * KK * 4));
+  }
+  if (rc) {
     for (void* p : c->owned) (void)hipFree(p);
     delete c;
     return rc;
@@ -1994,51 +2018,173 @@ int ec_support_destroy(ec_support_t c) {
   return EC_OK;
 }
 
+// One call of the episode cache, in its general form (ec_forward_episodes): n_new episodes are encoded - their support images ride in
+// the SAME backbone pass as the bs query images, so no small-M pass exists - and stored in their cache slots; the query side of the
+// head then runs for the bs queries against the slots slot_q[b] (which may have been filled by this very call).  bs = 0: encode only
+// (ec_support_encode); n_new = 0: queries only (ec_forward_cached).
+static int episodes_impl(ec_handle m, ec_support_t c, const float* const* img_s, const float* const* target_s, const float* mask_s,
+                         const int32_t* edges, const int32_t* off, const int32_t* slots, int n_new, int S, const float* img_q,
+                         const int32_t* slot_q, int bs, void* stream, const ec_outputs* out, bool pipelined) {
+  EC_REQUIRE(m && m->finalized && c && c->m == m, EC_ERR_STATE, "bad handle");
+  EC_REQUIRE(n_new >= 0 && bs >= 0 && n_new + bs > 0, EC_ERR_ARG, "nothing to do: no new episode and no query");
+  if (n_new > 0) {
+    EC_REQUIRE(img_s && target_s && mask_s && slots && off, EC_ERR_ARG, "null input");
+    EC_REQUIRE(n_new <= c->cap && n_new <= m->cfg.max_batch && S > 0 && S <= m->cfg.max_shots, EC_ERR_ARG, "n_episodes / S exceed the configured maxima");
+    for (int i = 0; i < n_new; ++i) {
+      EC_REQUIRE(slots[i] >= 0 && slots[i] < c->cap, EC_ERR_ARG, "episode slot out of range");
+      for (int j = 0; j < i; ++j) EC_REQUIRE(slots[j] != slots[i], EC_ERR_ARG, "two new episodes share a cache slot");
+    }
+  } else {
+    S = 0;
+  }
+  if (bs > 0) {
+    RUN(check_head_args(m, bs, 1, out));
+    EC_REQUIRE(img_q && slot_q, EC_ERR_ARG, "null input");
+    for (int b = 0; b < bs; ++b) {
+      EC_REQUIRE(slot_q[b] >= 0 && slot_q[b] < c->cap, EC_ERR_ARG, "episode index out of range");
+      bool ok = c->filled[slot_q[b]] != 0;
+      for (int i = 0; i < n_new && !ok; ++i) ok = slots[i] == slot_q[b];
+      EC_REQUIRE(ok, EC_ERR_STATE, "support cache slot is empty: encode the episode first (ec_support_encode / ec_forward_episodes)");
+      // (a slot that was filled earlier AND is re-encoded by this call serves its NEW episode: the scatter precedes the gather)
+    }
+  }
+  EC_REQUIRE(bs + S * n_new <= m->n_img_max, EC_ERR_ARG, "queries + support images of the new episodes exceed (1 + max_shots) * max_batch");
+  hipStream_t st = (hipStream_t)stream;
+  pipelined = pipelined && bs > 0;
+  struct Scope { ec_model* m; ~Scope() { m->dq_active = false; m->compact = false; m->episode_call = false; } } scope{m};
+  m->dq_active = pipelined;
+  m->episode_call = true;
+  m->compact = m->compact_mode == 2 || (m->compact_mode == 1 && pipelined);
+  const bool full = pipelined && m->pipe_full && m->overlap && m->dq;
+  const int C = m->C, K = m->K, HW = m->HW, hops1 = m->cfg.max_hops + 1;
+  const long KK = (long)K * K;
+  const size_t per_img = (size_t)HW * C;
+
+  const float* srcs[1 + 16];
+  int counts[1 + 16];
+  EC_REQUIRE(S <= 16, EC_ERR_ARG, "more than 16 shots");
+  srcs[0] = img_q; counts[0] = bs;
+  std::vector<const float*> fsp(S);
+  for (int s = 0; s < S; ++s) {
+    srcs[1 + s] = img_s[s]; counts[1 + s] = n_new;
+    fsp[s] = m->feat + ((size_t)bs + (size_t)s * n_new) * per_img;
+  }
+
+  // ---- cache traffic (ec_ops.h rows_xfer; the slot numbers travel as kernel arguments)
+  const SupportState &cs = c->ss, &sg = c->stg;
+  SupportState ws;
+  if (bs > 0) {
+    ws = workspace_support(m, out);
+    ws.dec_bias = m->d_bias_all;   // recomputed from the gathered Markov stacks (before_dec below) rather than cached: 8 x the stack's bytes
+  }
+  const int32_t *slots_v = slots, *slot_q_v = slot_q;
+  auto scatter_a = [&](hipStream_t s2) -> int {   // support tokens + masks of the new episodes -> their slots
+    XferP x;
+    x.add(cs.sk, sg.sk, (long)K * m->d * 4); x.add(cs.valid, sg.valid, (long)K * 4);
+    x.add(cs.kmask, sg.kmask, K); x.add(cs.kmask_fixed, sg.kmask_fixed, K);
+    return rows_xfer(x, slots_v, n_new, true, s2);
+  };
+  auto scatter_b = [&](hipStream_t s2) -> int {   // adjacency + Markov stack
+    XferP x;
+    x.add(cs.adj1, sg.adj1, KK * 4); x.add(cs.adj_out, sg.adj_out, 2 * KK * 4);
+    x.add(cs.attn_adj, sg.attn_adj, KK * 4, hops1, (long)c->cap * KK * 4, (long)n_new * KK * 4);
+    return rows_xfer(x, slots_v, n_new, true, s2);
+  };
+  auto gather_a = [&](hipStream_t s2) -> int {    // every query's episode -> the head workspace
+    XferP x;
+    x.add(ws.sk, cs.sk, (long)K * m->d * 4); x.add(ws.valid, cs.valid, (long)K * 4);
+    x.add(ws.kmask, cs.kmask, K); x.add(ws.kmask_fixed, cs.kmask_fixed, K);
+    RUN(rows_xfer(x, slot_q_v, bs, false, s2));
+    return build_row_plans(m, ws.valid, bs, 1, s2, true, false);   // the queries' masks: valid[b] = 1 / 0 from their episodes
+  };
+  auto gather_b = [&](hipStream_t s2) -> int {
+    XferP x;
+    x.add(ws.adj1, cs.adj1, KK * 4); x.add(ws.adj_out, cs.adj_out, 2 * KK * 4);
+    x.add(ws.attn_adj, cs.attn_adj, KK * 4, hops1, (long)bs * KK * 4, (long)c->cap * KK * 4);
+    RUN(rows_xfer(x, slot_q_v, bs, false, s2));
+    return decoder_bias_all(m, ws.attn_adj, ws.dec_bias, bs, s2);
+  };
+  auto mark_filled = [&]() { for (int i = 0; i < n_new; ++i) c->filled[slots[i]] = 1; };
+
+  if (full) {
+    // Same lanes as a FULL pipelined ec_forward (run_head / run_head_pre): only the backbone on the caller's stream; what reads the
+    // caller's heatmaps / masks beside it on the support lane; the whole head - support lane of the new episodes, query lane of the bs
+    // queries - on the library's streams beside the NEXT call's backbone.
+    if (n_new > 0) RUN(upload_edges(m, edges, off, n_new, m->side));
+    EC_HIP(hipEventRecord(m->ev_call, st));
+    EC_HIP(hipStreamWaitEvent(m->side, m->ev_call, 0));
+    if (m->dq_pending) EC_HIP(hipStreamWaitEvent(m->side, m->ev_dq_done, 0));   // (also: the previous call's gathers have read the slots)
+    if (n_new > 0) RUN(join_on_error(m, run_head_support(m, nullptr, target_s, mask_s, n_new, S, m->side, sg, nullptr, 1)));
+    EC_HIP(hipEventRecord(m->ev_inputs, m->side));
+    if (m->timeline_defer) RUN(tl_mark(m, "BB", st));
+    RUN(run_backbone(m, srcs, counts, 1 + S, m->feat, st));
+    if (m->timeline_defer) RUN(tl_mark(m, "BBend", st));
+    RUN(tl_mark(m, "head", st));
+    EC_HIP(hipEventRecord(m->ev_fork, st));
+    EC_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+    EC_HIP(hipStreamWaitEvent(m->dq, m->ev_fork, 0));
+    if (m->dq_pending) EC_HIP(hipStreamWaitEvent(m->dq, m->ev_dq_done, 0));
+    if (n_new > 0) {
+      RUN(join_on_error(m, run_head_support(m, fsp.data(), target_s, mask_s, n_new, S, m->side, sg, m->ev_sk, 2, scatter_a)));
+      RUN(join_on_error(m, scatter_b(m->side)));
+      EC_HIP(hipEventRecord(m->ev_join, m->side));
+    }
+    mark_filled();
+    RUN(join_on_error(m, run_head_query(m, m->feat, bs, m->dq, out, ws, n_new > 0 ? m->ev_sk : nullptr, n_new > 0 ? m->ev_join : nullptr,
+                                        gather_a, gather_b)));
+    EC_HIP(hipStreamWaitEvent(st, m->ev_inputs, 0));
+    m->feat_read_pending = true;
+    return tl_dump(m);
+  }
+
+  RUN(wait_pending_decoder(m, st));
+  if (n_new > 0) RUN(upload_edges(m, edges, off, n_new, st));
+  RUN(run_backbone(m, srcs, counts, 1 + S, m->feat, st));
+  if (bs == 0) RUN(tl_mark(m, "support-only", st));
+  else RUN(tl_mark(m, "head", st));
+  if (m->overlap && n_new > 0 && bs > 0) {
+    EC_HIP(hipEventRecord(m->ev_fork, st));
+    EC_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+    RUN(join_on_error(m, run_head_support(m, fsp.data(), target_s, mask_s, n_new, S, m->side, sg, m->ev_sk, 0, scatter_a)));
+    RUN(join_on_error(m, scatter_b(m->side)));
+    EC_HIP(hipEventRecord(m->ev_join, m->side));
+    mark_filled();
+    RUN(join_on_error(m, run_head_query(m, m->feat, bs, st, out, ws, m->ev_sk, m->ev_join, gather_a, gather_b)));
+    if (m->dq_active) EC_HIP(hipStreamWaitEvent(st, m->ev_feat_read, 0));   // (see run_head)
+    return tl_dump(m);
+  }
+  if (n_new > 0) {
+    RUN(join_on_error(m, run_head_support(m, fsp.data(), target_s, mask_s, n_new, S, st, sg, nullptr, 0, scatter_a)));
+    RUN(join_on_error(m, scatter_b(st)));
+    mark_filled();
+  }
+  if (bs > 0) RUN(join_on_error(m, run_head_query(m, m->feat, bs, st, out, ws, nullptr, nullptr, gather_a, gather_b)));
+  return tl_dump(m);
+}
+
 int ec_support_encode(ec_handle m, ec_support_t c, const float* const* img_s, const float* const* target_s, const float* mask_s,
                       const int32_t* edges, const int32_t* off, int n_episodes, int S, void* stream) {
   EC_REQUIRE(m && m->finalized && c && c->m == m, EC_ERR_STATE, "bad handle");
-  EC_REQUIRE(img_s && target_s && mask_s, EC_ERR_ARG, "null input");
-  EC_REQUIRE(n_episodes > 0 && n_episodes <= c->cap && S > 0 && S <= m->cfg.max_shots, EC_ERR_ARG, "n_episodes / S exceed the configured maxima");
-  hipStream_t st = (hipStream_t)stream;
-  struct CScope { ec_model* m; ~CScope() { m->compact = false; } } cscope{m};
-  m->compact = m->compact_mode == 2;
-  RUN(wait_pending_decoder(m, st));
-  RUN(upload_edges(m, edges, off, n_episodes, st));
-  const size_t per = (size_t)n_episodes * m->HW * m->C;
-  std::vector<const float*> fsp(S);
-  for (int s = 0; s < S; ++s) fsp[s] = m->feat + s * per;
-  RUN(run_backbone(m, img_s, S, n_episodes, m->feat, st));
-  c->n = n_episodes; c->S = S;
-  RUN(tl_mark(m, "support-only", st));
-  RUN(join_on_error(m, run_head_support(m, fsp.data(), target_s, mask_s, n_episodes, S, st, c->ss)));
-  return tl_dump(m);
+  EC_REQUIRE(n_episodes > 0 && n_episodes <= c->cap, EC_ERR_ARG, "n_episodes / S exceed the configured maxima");
+  std::vector<int32_t> slots(n_episodes);
+  for (int i = 0; i < n_episodes; ++i) slots[i] = i;
+  const std::vector<char> before = c->filled;
+  std::fill(c->filled.begin(), c->filled.end(), 0);   // the cache then holds exactly these episodes, slots 0 .. n_episodes - 1
+  const int rc = episodes_impl(m, c, img_s, target_s, mask_s, edges, off, slots.data(), n_episodes, S, nullptr, nullptr, 0, stream, nullptr, false);
+  if (rc) c->filled = before;
+  return rc;
 }
 
 int ec_forward_cached(ec_handle m, ec_support_t c, const float* img_q, const int32_t* episode_of_query, int bs, void* stream,
                       const ec_outputs* out) {
-  RUN(check_head_args(m, bs, 1, out));
-  EC_REQUIRE(c && c->m == m && c->n > 0, EC_ERR_STATE, "support cache is empty: call ec_support_encode first");
-  EC_REQUIRE(img_q && episode_of_query, EC_ERR_ARG, "null input");
-  for (int b = 0; b < bs; ++b)
-    EC_REQUIRE(episode_of_query[b] >= 0 && episode_of_query[b] < c->n, EC_ERR_ARG, "episode index out of range");
-  hipStream_t st = (hipStream_t)stream;
-  struct CScope { ec_model* m; ~CScope() { m->compact = false; } } cscope{m};
-  m->compact = m->compact_mode == 2;
-  RUN(wait_pending_decoder(m, st));
-  EC_HIP(hipMemcpyAsync(c->d_idx, episode_of_query, (size_t)bs * 4, hipMemcpyHostToDevice, st));
-  RUN(run_backbone(m, &img_q, 1, bs, m->feat, st));
-  SupportState ws = workspace_support(m, out);
-  ws.dec_bias = nullptr;   // the bias MLP is recomputed from the gathered Markov stack (cheap) instead of being cached
-  const long K = m->K, KK = K * K;
-  RUN(gather_rows(ws.sk, c->ss.sk, c->d_idx, K * m->d, bs, 1, 0, 0, st));
-  RUN(gather_rows(ws.valid, c->ss.valid, c->d_idx, K, bs, 1, 0, 0, st));
-  RUN(gather_bytes(ws.kmask, c->ss.kmask, c->d_idx, K, bs, st));
-  RUN(gather_bytes(ws.kmask_fixed, c->ss.kmask_fixed, c->d_idx, K, bs, st));
-  RUN(gather_rows(ws.adj1, c->ss.adj1, c->d_idx, KK, bs, 1, 0, 0, st));
-  RUN(gather_rows(ws.adj_out, c->ss.adj_out, c->d_idx, 2 * KK, bs, 1, 0, 0, st));
-  RUN(gather_rows(ws.attn_adj, c->ss.attn_adj, c->d_idx, KK, bs, m->cfg.max_hops + 1, (long)c->n * KK, (long)bs * KK, st));
-  RUN(build_row_plans(m, ws.valid, bs, 1, st, true, false));   // the queries' masks: valid[b] = 1 / 0 gathered from their episodes
-  return join_on_error(m, run_head_query(m, m->feat, bs, st, out, ws));
+  EC_REQUIRE(bs > 0, EC_ERR_ARG, "bs / S exceed the configured maxima");
+  return episodes_impl(m, c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, img_q, episode_of_query, bs, stream, out, false);
+}
+
+int ec_forward_episodes(ec_handle m, ec_support_t c, const float* const* img_s, const float* const* target_s, const float* mask_s,
+                        const int32_t* edges, const int32_t* off, const int32_t* slots, int n_new, int S, const float* img_q,
+                        const int32_t* slot_of_query, int bs, void* stream, const ec_outputs* out, int pipelined) {
+  return episodes_impl(m, c, img_s, target_s, mask_s, edges, off, slots, n_new, S, img_q, slot_of_query, bs, stream, out, pipelined != 0);
 }
 
 // ---- on-device input pipeline ---------------------------------------------------------------

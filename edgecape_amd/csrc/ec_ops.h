@@ -28,11 +28,22 @@ int add_table(float* x, long ldx, const float* table, long ldt, int period, int 
 int copy2d(float* dst, long ldd, const float* src, long lds, int rows, int cols, hipStream_t st);
 // dst[b][r][c] = src[b][r][c] for b < batch with batch strides
 int copy3d(float* dst, long ldd, long sd, const float* src, long lds, long ss, int batch, int rows, int cols, hipStream_t st);
-int gather_bytes(uint8_t* dst, const uint8_t* src, const int32_t* idx_dev, int row, int n_rows, hipStream_t st);
 int mean_over(float* dst, const float* src, long stride, int n, long count, hipStream_t st);
-// dst[o][b][0..row) = src[o][idx[b]][0..row) for b < n_rows, o < n_outer (outer strides in floats)
-int gather_rows(float* dst, const float* src, const int32_t* idx_dev, long row, int n_rows, int n_outer, long src_os, long dst_os,
-                hipStream_t st);
+// Indexed row transfer (support-side episode cache <-> per-call buffers): for r < n_rows and every outer slice o of every segment,
+//   idx_is_dst = false (gather):  dst[o][r]      = src[o][idx[r]]
+//   idx_is_dst = true (scatter):  dst[o][idx[r]] = src[o][r]
+// rows of row_bytes bytes, outer strides in bytes.  The indices are host values and travel as kernel arguments.
+constexpr int XFER_MAX_ROWS = 256;
+struct XferSeg { void* dst = nullptr; const void* src = nullptr; long row_bytes = 0; int n_outer = 1; long dst_os = 0, src_os = 0; int align = 1; };
+struct XferP {
+  XferSeg seg[8]; int n_seg = 0; int idx_is_dst = 0;
+  int idx[XFER_MAX_ROWS];
+  void add(void* dst, const void* src, long row_bytes, int n_outer = 1, long dst_os = 0, long src_os = 0) {
+    XferSeg& S = seg[n_seg++];
+    S.dst = dst; S.src = src; S.row_bytes = row_bytes; S.n_outer = n_outer; S.dst_os = dst_os; S.src_os = src_os;
+  }
+};
+int rows_xfer(XferP p, const int* idx_host, int n_rows, bool idx_is_dst, hipStream_t st);
 int f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t st, int f16 = 0);   // f16: IEEE fp16 instead of bf16
 // src [B][L][E] fp32 -> dst [B][E][Lp] bf16 (columns >= L zeroed); test helper for the bf16 attention kernel
 int transpose_pad_bf16(const float* src, bf16_t* dst, int B, int L, int E, int Lp, hipStream_t st);
@@ -81,13 +92,12 @@ int adj_build(const int32_t* edges, const int32_t* offsets, const float* mask_s,
 // adjacency rows / columns and attention keys of masked tokens are zeroed), so a row-wise kernel only has to compute the valid tokens
 // and ONE masked token per sample.  For `ns` samples of K tokens, sample i using the mask row i % bs of mask_s [bs, K]:
 //   plan[0] = n_active, plan[1] = n_copy, rowmap [ns*K]: token rows to compute (sample-major, valid tokens in order, then the
-//   representative = the first masked token), copy_src / copy_dst [ns*K]: for every other masked token dst the row src it equals.
+//   representative = the first masked token); copy_dst [ns*K]: the other masked token rows, sample-major; fan_off / fan_cnt [ns*K], indexed
+//   like rowmap: the range of copy_dst that equals this computed row (count 0 for a valid token) - the chain kernel writes a
+//   representative's output rows to them itself (ChainP::fan_*).
 // A sample WITHOUT a valid token keeps token 0 as a row of its own: its key 0 is un-masked (encoder_decoder.py:359-360, skeleton.py:98-99)
 // and sees a different attention bias than the other masked tokens do.
-int rowplan(const float* mask_s, int bs, int ns, int K, int* plan, int* rowmap, int* copy_src, int* copy_dst, hipStream_t st);
-// dst rows <- src rows of up to 4 fp32 tensors (row pitch ld[t] floats, ncols[t] % 4 == 0 or ncols == 2), pair list of a rowplan
-struct BcastP { float* ptr[4] = {nullptr, nullptr, nullptr, nullptr}; long ld[4] = {0, 0, 0, 0}; int ncols[4] = {0, 0, 0, 0}; int n = 0; };
-int bcast_rows(const BcastP& t, const int* plan, const int* copy_src, const int* copy_dst, int max_pairs, hipStream_t st);
+int rowplan(const float* mask_s, int bs, int ns, int K, int* plan, int* rowmap, int* fan_off, int* fan_cnt, int* copy_dst, hipStream_t st);
 int rownorm(const float* x, float* y, int rows, int cols, hipStream_t st);
 // skeleton.py:134-161 — combine cosine similarity with the prior, soft-normalise, Markov matrix
 int adj_combine(const float* P, const float* binary, const float* valid, const float* zc_w, const float* zc_b,

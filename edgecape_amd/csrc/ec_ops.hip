@@ -99,17 +99,24 @@ __global__ void copy3d_kernel(float* dst, long ldd, long sd, const float* src, l
   *(f32x4*)(dst + b * sd + (long)r * ldd + c) = *(const f32x4*)(src + b * ss + (long)r * lds + c);
 }
 
-// dst[o][b][i] = src[o][idx[b]][i]  (support-side episode cache -> per-query workspace)
-__global__ void gather_rows_kernel(float* dst, const float* src, const int32_t* idx, long row, long src_os, long dst_os) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= row) return;
-  const int b = blockIdx.y, o = blockIdx.z;
-  dst[o * dst_os + (long)b * row + i] = src[o * src_os + (long)idx[b] * row + i];
-}
-
-__global__ void gather_bytes_kernel(uint8_t* dst, const uint8_t* src, const int32_t* idx, int row) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < row) dst[(long)blockIdx.y * row + i] = src[(long)idx[blockIdx.y] * row + i];
+// Indexed row transfer between the support-side episode cache and the per-call buffers (ec_ops.h XferP): workgroup (r, y) moves row r
+// of outer slice y (segments laid end to end along y) with the widest access the segment's alignment allows.
+__global__ __launch_bounds__(256) void rows_xfer_kernel(XferP p) {
+  const int r = blockIdx.x;
+  int y = blockIdx.y, sg = 0;
+  while (y >= p.seg[sg].n_outer) { y -= p.seg[sg].n_outer; ++sg; }
+  const XferSeg& S = p.seg[sg];
+  const long dr = p.idx_is_dst ? p.idx[r] : r, sr = p.idx_is_dst ? r : p.idx[r];
+  char* dst = (char*)S.dst + (long)y * S.dst_os + dr * S.row_bytes;
+  const char* src = (const char*)S.src + (long)y * S.src_os + sr * S.row_bytes;
+  const long nb = S.row_bytes;
+  if (S.align >= 16) {
+    for (long i = (long)threadIdx.x * 16; i < nb; i += 256 * 16) *(f32x4*)(dst + i) = *(const f32x4*)(src + i);
+  } else if (S.align >= 4) {
+    for (long i = (long)threadIdx.x * 4; i < nb; i += 256 * 4) *(unsigned*)(dst + i) = *(const unsigned*)(src + i);
+  } else {
+    for (long i = threadIdx.x; i < nb; i += 256) dst[i] = src[i];
+  }
 }
 
 __global__ void mean_over_kernel(float* dst, const float* src, long stride, int n, long count) {
@@ -439,8 +446,8 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const int32_t* edges, co
 // bits); a serial prefix over the samples by thread 0 (ns <= a few hundred: sub-microsecond against the ~5 us the launch costs);
 // pass 2: every wave writes its samples' entries.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void rowplan_kernel(const float* mask_s, int bs, int ns, int K, int* plan, int* rowmap, int* copy_src,
-                                                       int* copy_dst) {
+__global__ __launch_bounds__(1024) void rowplan_kernel(const float* mask_s, int bs, int ns, int K, int* plan, int* rowmap, int* fan_off,
+                                                       int* fan_cnt, int* copy_dst) {
   extern __shared__ int pl_lds[];        // [ns] active offsets, [ns] copy offsets
   int* a_off = pl_lds;
   int* c_off = pl_lds + ns;
@@ -489,28 +496,10 @@ __global__ __launch_bounds__(1024) void rowplan_kernel(const float* mask_s, int 
       const unsigned long long v = half ? v1 : v0, mk = half ? m1 : m0;
       const int vrank = (half ? __popcll(v0) : 0) + __popcll(v & below);
       const int mrank = (half ? __popcll(m0) : 0) + __popcll(mk & below);
-      if ((v >> lane) & 1ull) rowmap[ao + vrank] = (int)(base + k);
-      else if (k == rep) rowmap[ao + nv] = (int)(base + k);
-      else {                                  // masked, not the representative: mrank >= 1
-        copy_dst[co + mrank - 1] = (int)(base + k);
-        copy_src[co + mrank - 1] = (int)(base + rep);
-      }
+      if ((v >> lane) & 1ull) { rowmap[ao + vrank] = (int)(base + k); fan_cnt[ao + vrank] = 0; fan_off[ao + vrank] = 0; }
+      else if (k == rep) { rowmap[ao + nv] = (int)(base + k); fan_off[ao + nv] = co; fan_cnt[ao + nv] = K - nv - 1; }
+      else copy_dst[co + mrank - 1] = (int)(base + k);   // masked, not the representative (mrank >= 1): a copy of row `rep`
     }
-  }
-}
-
-// bcast_rows (ec_ops.h): 64 threads per (dst, src) pair, 4 pairs per block; blocks past plan[1] leave at once
-__global__ __launch_bounds__(256) void bcast_rows_kernel(BcastP t, const int* plan, const int* copy_src, const int* copy_dst) {
-  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (pair >= plan[1]) return;
-  const long src = copy_src[pair], dst = copy_dst[pair];
-  for (int i = 0; i < t.n; ++i) {
-    float* base = t.ptr[i];
-    if (t.ncols[i] & 3) {
-      if (lane < t.ncols[i]) base[dst * t.ld[i] + lane] = base[src * t.ld[i] + lane];
-      continue;
-    }
-    for (int c = lane * 4; c < t.ncols[i]; c += 256) *(f32x4*)(base + dst * t.ld[i] + c) = *(const f32x4*)(base + src * t.ld[i] + c);
   }
 }
 
@@ -913,11 +902,29 @@ __global__ __launch_bounds__(256) void msra_target_kernel(const float* joints, c
   if (threadIdx.x == 0) weight[jk] = w;
 }
 
-int gather_rows(float* dst, const float* src, const int32_t* idx_dev, long row, int n_rows, int n_outer, long src_os, long dst_os,
-                hipStream_t st) {
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(row, 256), n_rows, n_outer), dim3(256), 0, st, dst, src, idx_dev, row, src_os,
-                     dst_os);
-  EC_LAUNCH_CHECK();
+int rows_xfer(XferP p, const int* idx_host, int n_rows, bool idx_is_dst, hipStream_t st) {
+  EC_REQUIRE(p.n_seg > 0 && p.n_seg <= 8 && n_rows >= 0 && idx_host, -1, "rows_xfer: bad arguments");
+  int ny = 0;
+  for (int i = 0; i < p.n_seg; ++i) {
+    XferSeg& S = p.seg[i];
+    EC_REQUIRE(S.dst && S.src && S.row_bytes > 0 && S.n_outer > 0, -1, "rows_xfer: bad segment");
+    const uintptr_t bits = (uintptr_t)S.dst | (uintptr_t)S.src | (uintptr_t)S.row_bytes | (uintptr_t)S.dst_os | (uintptr_t)S.src_os;
+    S.align = (bits % 16 == 0) ? 16 : (bits % 4 == 0) ? 4 : 1;
+    ny += S.n_outer;
+  }
+  p.idx_is_dst = idx_is_dst ? 1 : 0;
+  for (int r0 = 0; r0 < n_rows; r0 += XFER_MAX_ROWS) {   // the row indices travel as kernel arguments: no staging buffer, no copy
+    const int n = std::min(XFER_MAX_ROWS, n_rows - r0);
+    XferP q = p;
+    for (int i = 0; i < n; ++i) q.idx[i] = idx_host[r0 + i];
+    for (int i = 0; i < q.n_seg; ++i) {   // this chunk's identity side starts at row r0
+      XferSeg& S = q.seg[i];
+      if (idx_is_dst) S.src = (const char*)S.src + (long)r0 * S.row_bytes;
+      else S.dst = (char*)S.dst + (long)r0 * S.row_bytes;
+    }
+    hipLaunchKernelGGL(rows_xfer_kernel, dim3(n, ny), dim3(256), 0, st, q);
+    EC_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -936,12 +943,6 @@ int preprocess_affine_cv2(const PreprocBatchCv2& pb, int n, float* out, int H, h
 int msra_targets(const float* joints, const float* visible, float* target, float* weight, int n_kpts_total, const MsraP& mp,
                  hipStream_t st) {
   hipLaunchKernelGGL(msra_target_kernel, dim3(n_kpts_total), dim3(256), 0, st, joints, visible, target, weight, mp);
-  EC_LAUNCH_CHECK();
-  return 0;
-}
-
-int gather_bytes(uint8_t* dst, const uint8_t* src, const int32_t* idx_dev, int row, int n_rows, hipStream_t st) {
-  hipLaunchKernelGGL(gather_bytes_kernel, dim3(cdiv(row, 128), n_rows), dim3(128), 0, st, dst, src, idx_dev, row);
   EC_LAUNCH_CHECK();
   return 0;
 }
@@ -1038,18 +1039,9 @@ int adj_build(const int32_t* edges, const int32_t* offsets, const float* mask_s,
   return 0;
 }
 
-int rowplan(const float* mask_s, int bs, int ns, int K, int* plan, int* rowmap, int* copy_src, int* copy_dst, hipStream_t st) {
+int rowplan(const float* mask_s, int bs, int ns, int K, int* plan, int* rowmap, int* fan_off, int* fan_cnt, int* copy_dst, hipStream_t st) {
   EC_REQUIRE(K >= 1 && K <= 128 && ns >= 1 && ns <= 8192 && bs >= 1, -1, "rowplan: K <= 128, samples <= 8192");
-  hipLaunchKernelGGL(rowplan_kernel, dim3(1), dim3(1024), (size_t)ns * 2 * sizeof(int), st, mask_s, bs, ns, K, plan, rowmap, copy_src, copy_dst);
-  EC_LAUNCH_CHECK();
-  return 0;
-}
-
-int bcast_rows(const BcastP& t, const int* plan, const int* copy_src, const int* copy_dst, int max_pairs, hipStream_t st) {
-  if (t.n == 0 || max_pairs <= 0) return 0;
-  EC_REQUIRE(t.n <= 4, -1, "bcast_rows: at most 4 tensors");
-  for (int i = 0; i < t.n; ++i) EC_REQUIRE((t.ncols[i] % 4 == 0 && t.ld[i] % 4 == 0) || t.ncols[i] <= 64, -1, "bcast_rows: column count");
-  hipLaunchKernelGGL(bcast_rows_kernel, dim3(cdiv(max_pairs, 4)), dim3(256), 0, st, t, plan, copy_src, copy_dst);
+  hipLaunchKernelGGL(rowplan_kernel, dim3(1), dim3(1024), (size_t)ns * 2 * sizeof(int), st, mask_s, bs, ns, K, plan, rowmap, fan_off, fan_cnt, copy_dst);
   EC_LAUNCH_CHECK();
   return 0;
 }

@@ -238,7 +238,7 @@ class HipEngine:
         ms = self._dev(mask_s).reshape(n, self.K)
         edges, off = self._edges(skeletons, n)
         if cache is None:
-            cache = SupportCache(self, self.max_batch)
+            cache = SupportCache(self, max(self.max_batch, n))
         _lib.check(self.lib.ec_support_encode(self.h, cache.h, self._ptr_array(is_), self._ptr_array(ts), ms.data_ptr(),
                                               edges.ctypes.data, off.ctypes.data, n, S, _lib.current_stream()))
         cache.n_episodes = n
@@ -253,6 +253,55 @@ class HipEngine:
         o, eo = self._outputs(bs)
         _lib.check(self.lib.ec_forward_cached(self.h, cache.h, iq.data_ptr(), ep.ctypes.data, bs, _lib.current_stream(), C.byref(eo)))
         o["_keep"] = (iq,)
+        return o
+
+    def support_cache(self, max_episodes):
+        """An empty episode cache of max_episodes slots for support_encode / forward_cached / forward_episodes."""
+        return SupportCache(self, max_episodes)
+
+    def prepare_episode_call(self, img_q, slot_of_query, new=None):
+        """Arguments of one ec_forward_episodes call, made resident / packed once (the timed loops re-issue prepared calls):
+        `new` = dict(img_s, target_s, mask_s, skeletons, slots), lists over shots of [n_new, ...], or None; img_q [bs,3,H,W] or None."""
+        keep = []
+        if new is not None:
+            is_ = [self._dev(x) for x in new["img_s"]]
+            ts = [self._dev(t) for t in new["target_s"]]
+            n, S = is_[0].shape[0], len(is_)
+            ms = self._dev(new["mask_s"]).reshape(n, self.K)
+            edges, off = self._edges(new["skeletons"], n)
+            slots = np.ascontiguousarray(np.asarray(new["slots"], np.int32).reshape(n))
+            pi, pt = self._ptr_array(is_), self._ptr_array(ts)
+            keep += [is_, ts, ms, edges, off, slots, pi, pt]
+            a_new = (pi, pt, ms.data_ptr(), edges.ctypes.data, off.ctypes.data, slots.ctypes.data, n, S)
+            top = int(slots.max()) + 1
+        else:
+            a_new, top = (None, None, None, None, None, None, 0, 0), 0
+        if img_q is not None:
+            iq = self._dev(img_q)
+            bs = iq.shape[0]
+            sq = np.ascontiguousarray(np.asarray(slot_of_query, np.int32).reshape(bs))
+            keep += [iq, sq]
+            a_q = (iq.data_ptr(), sq.ctypes.data, bs)
+        else:
+            a_q = (None, None, 0)
+        return dict(args=a_new + a_q, bs=a_q[2], top=top, keep=keep)
+
+    def forward_episodes(self, cache, img_q=None, slot_of_query=None, new=None, outputs=None, pipelined=False, prepared=None):
+        """ec_forward_episodes (include/edgecape_hip.h): encode the episodes that start in this call into their cache slots and run
+        the query side for the call's queries, query b against slot slot_of_query[b]; support and query images share ONE backbone
+        pass.  Arguments as prepare_episode_call (or its result as `prepared`).  pipelined: ec_forward_pipelined's completion rule
+        (pipeline_flush); `outputs` as for forward_pipelined (default: a fresh set)."""
+        p = prepared if prepared is not None else self.prepare_episode_call(img_q, slot_of_query, new)
+        if p["bs"] > 0:
+            o, eo = outputs if outputs is not None else self._outputs(p["bs"])
+        else:
+            o, eo = {}, None
+        _lib.check(self.lib.ec_forward_episodes(self.h, cache.h, *p["args"], _lib.current_stream(),
+                                                C.byref(eo) if eo is not None else None, 1 if pipelined else 0))
+        cache.n_episodes = max(cache.n_episodes, p["top"])
+        if outputs is None and p["bs"] > 0:
+            o["_keep"] = p["keep"]
+        cache._keep = p["keep"]
         return o
 
     def debug(self, name):

@@ -35,3 +35,34 @@ def group_episodes(paired_samples):
     new[1:] = (sup[1:] != sup[:-1]).any(axis=1)
     ep = np.cumsum(new).astype(np.int32) - 1
     return sup[new], ep
+
+
+def stream_schedule(episode_of_pair, batch, capacity):
+    """Cut the reference's pair order (episode_of_pair from group_episodes: non-decreasing episode ids) into the calls of
+    `ec_forward_episodes` (include/edgecape_hip.h): every call takes the next `batch` pairs' queries and ENCODES the episodes whose
+    first query lies in it; an episode occupies a cache slot from that call until the call holding its last query has been issued.
+    Returns a list of dicts: `queries` (pair indices of the call), `slot_of_query` (int32), `new_episodes` (episode ids to encode in
+    this call), `new_slots` (int32, their cache slots).  `capacity` slots must cover the episodes alive across one call boundary
+    (ValueError otherwise): ceil(batch / queries-per-episode) + 1 always does."""
+    ep = np.asarray(episode_of_pair, np.int64)
+    if ep.size and (np.diff(ep) < 0).any():
+        raise ValueError("episode_of_pair must be non-decreasing (the reference's sequential pair order)")
+    last = {}
+    for i, e in enumerate(ep):
+        last[int(e)] = i
+    free = list(range(capacity - 1, -1, -1))
+    slot_of, calls = {}, []
+    for q0 in range(0, len(ep), batch):
+        idx = np.arange(q0, min(q0 + batch, len(ep)))
+        new = []
+        for e in dict.fromkeys(int(x) for x in ep[idx]):
+            if e not in slot_of:
+                if not free:
+                    raise ValueError(f"capacity {capacity} too small for batch {batch}: more episodes alive than cache slots")
+                slot_of[e] = free.pop()
+                new.append(e)
+        calls.append(dict(queries=idx, slot_of_query=np.array([slot_of[int(e)] for e in ep[idx]], np.int32),
+                          new_episodes=new, new_slots=np.array([slot_of[e] for e in new], np.int32)))
+        for e in [e for e in slot_of if last[e] < q0 + batch]:      # their last query is in this call: the slot is free for the next one
+            free.append(slot_of.pop(e))
+    return calls

@@ -60,8 +60,8 @@ enum ec_precision {
                      single-pass fp16 MFMAs (fp32 data rounded to fp16 operands, fp32 accumulate) in the Linear layers AND the
                      attentions of the skeleton head (skeleton.py:58-161) and of the decoder layers (encoder_decoder.py:584-651),
                      whose image K|V are also stored as fp16 - all of which only move the output continuously: with the fp16 backbone,
-                     max |d kpt| on flip-free samples 1.65e-4 (cfg2) / 1.87e-4 (ViT-S/14 @ 224) over 512 disjoint pairs each, 13 argmax
-                     flips of ~20 000 valid keypoints on either (profiles/r04_conformance_*.json) */
+                     max |d kpt| on flip-free samples 2.0e-4 (cfg2) / 2.4e-4 (ViT-S/14 @ 224) over 512 disjoint pairs each, 12 / 11 argmax
+                     flips of ~20 000 valid keypoints (profiles/r04_conformance_*.json) */
 };
 enum ec_dtype { EC_DT_F32 = 0, EC_DT_F16 = 1, EC_DT_BF16 = 2, EC_DT_F64 = 3 };
 enum ec_layout { EC_LAYOUT_TOKENS = 0, EC_LAYOUT_NCHW = 1 };
@@ -104,7 +104,7 @@ typedef struct ec_outputs {
 const char* ec_last_error(void);
 /* ABI version of the library (EC_ABI_VERSION of the header it was built from): bumped whenever a struct layout, an enum value, the set of entry points
    or a signature changes, so a binding can refuse a stale prebuilt library instead of calling it with mismatched layouts. */
-#define EC_ABI_VERSION 4
+#define EC_ABI_VERSION 5
 int ec_version(void);
 /* sizeof(ec_config) / sizeof(ec_outputs) as the library was compiled: a binding compares them with its own mirrors. */
 int ec_abi_sizes(int* config_bytes, int* outputs_bytes);
@@ -164,13 +164,34 @@ int ec_pipeline_flush(ec_handle h, void* stream);
  * decoder, kpt branches) for a batch of queries, query b using episode episode_of_query[b].  Results are identical to
  * ec_forward on the expanded (support, query) pairs. */
 typedef struct ec_support* ec_support_t;
-int ec_support_create(ec_handle h, int max_episodes, ec_support_t* out);   /* max_episodes <= max_batch */
+/* A cache of max_episodes SLOTS, one episode each (state per slot: support tokens [K,d], masks, adj [2,K,K], Markov stack
+ * [max_hops+1,K,K]: ~0.4 MB at K = 100). */
+int ec_support_create(ec_handle h, int max_episodes, ec_support_t* out);
 int ec_support_destroy(ec_support_t s);
+/* Encode n_episodes (<= max_batch) episodes into slots 0 .. n_episodes-1; the other slots become empty. */
 int ec_support_encode(ec_handle h, ec_support_t s, const float* const* img_s_dev, const float* const* target_s_dev,
                       const float* mask_s_dev, const int32_t* edges, const int32_t* edge_offsets, int n_episodes, int S,
                       void* stream);
+/* Query side for bs queries, query b against the episode in slot episode_of_query[b] (host array). */
 int ec_forward_cached(ec_handle h, ec_support_t s, const float* img_q_dev, const int32_t* episode_of_query, int bs,
                       void* stream, const ec_outputs* out);
+/* Streaming form (ABI 5): the reference's evaluation order - every episode followed by its 15 queries, test_dataset.py:86-99 -
+ * cut into calls of bs queries.  A call ENCODES the n_new episodes that start in it (arguments as ec_support_encode, plus
+ * new_slots: host [n_new], the cache slot each one is written to - distinct, < max_episodes; a slot is free again once the last
+ * query of its old episode has been passed to a call) AND runs the query side for bs queries, query b against slot
+ * slot_of_query[b] (host [bs]; a slot filled by an earlier call or by this one).  The support images of the new episodes ride in
+ * the SAME backbone pass as the queries (one pass over bs + n_new * S images: no small, latency-bound support pass), with
+ * bs + n_new * S <= (1 + max_shots) * max_batch, bs <= max_batch, n_new <= max_batch.  n_new = 0 (queries only) and bs = 0
+ * (encode only; out may be NULL) are allowed.  Results are identical to ec_support_encode + ec_forward_cached, i.e. to ec_forward
+ * on the expanded pairs.
+ * pipelined = 0: complete when `stream` has passed the call (ec_forward's rule).  pipelined != 0: ec_forward_pipelined's rule -
+ * only the backbone runs on `stream`; the whole head (support lane of the new episodes, query lane of the queries) runs on the
+ * library's streams beside the NEXT call's backbone; outputs are complete after ec_pipeline_flush, and consecutive calls must not
+ * share output buffers. */
+int ec_forward_episodes(ec_handle h, ec_support_t s, const float* const* img_s_dev, const float* const* target_s_dev,
+                        const float* mask_s_dev, const int32_t* edges, const int32_t* edge_offsets, const int32_t* new_slots,
+                        int n_new, int S, const float* img_q_dev, const int32_t* slot_of_query, int bs, void* stream,
+                        const ec_outputs* out, int pipelined);
 
 /* ---- on-device input pipeline (no model handle needed) -----------------------------------
  * ec_preprocess_images = TopDownAffineFewShot (cv2.warpAffine INTER_LINEAR, constant-0 border;

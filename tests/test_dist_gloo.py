@@ -199,6 +199,19 @@ class _FakeEngine:
     def pipeline_flush(self, stream=None):
         self.flushed = getattr(self, "flushed", 0) + 1
 
+    # episode-cache entry points (bench.episode_mode)
+    def support_cache(self, max_episodes):
+        return dict(cap=max_episodes)
+
+    def prepare_episode_call(self, img_q, slot_of_query, new=None):
+        assert new is None or len(new["slots"]) == new["img_s"][0].shape[0]
+        return dict(bs=img_q.shape[0], new=0 if new is None else len(new["slots"]))
+
+    def forward_episodes(self, cache, prepared=None, outputs=None, pipelined=False):
+        assert pipelined and outputs is not None and prepared["new"] <= cache["cap"]
+        self.episode_calls = getattr(self, "episode_calls", 0) + 1
+        return outputs[0]
+
 
 def _worker_bench(rank, world, port, q):
     sys.path.insert(0, ROOT)
@@ -209,7 +222,8 @@ def _worker_bench(rank, world, port, q):
     import edgecape_amd.engine as engine
     engine.HipEngine = _FakeEngine
     import bench
-    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "3", "--warmup", "1", "--batch", "4", "--image-size", "56", "--arch", "dinov2_vits14"]
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "3", "--warmup", "1", "--batch", "4", "--image-size", "56", "--arch", "dinov2_vits14",
+                "--sustained-seconds", "0.05"]
     buf = io.StringIO()
     with redirect_stdout(buf):
         res = bench.main()
@@ -219,7 +233,8 @@ def _worker_bench(rank, world, port, q):
 
 def test_world2_bench_main_runs_its_distributed_branches():
     """bench.py main() itself with WORLD_SIZE = 2 on gloo and a stand-in engine: the N > 1 branches (per-rank shard by global pair
-    index, timed region with the counter all-reduce, max over ranks, result assembled and printed by rank 0 only, CPU legs skipped)
+    index, timed region with the counter all-reduce, max over ranks, result assembled and printed by rank 0 only, CPU legs skipped,
+    the `sustained` and episode-protocol legs with their own timed regions on every rank)
     execute here before an 8-GPU driver run does it for the first time.  Contract: apis/test.py:154-198 + the bench contract."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -238,7 +253,12 @@ def test_world2_bench_main_runs_its_distributed_branches():
     assert res0["config"]["global_batch"] == 8 and res0["config"]["parallelism"].startswith("dp2")
     assert res0["value"] > 0 and abs(res0["value"] - 2 * 4 * 3 / (res0["ms_per_step"] * 3e-3)) / res0["value"] < 0.01   # whole-job aggregate
     assert res0["roofline"]["launches_timed"] == 3 and res0["roofline"]["avg_launch_ms"] == 1.0     # sampled: one QKV launch per step
-    assert "cpu_baseline" not in res0 and "episode_cached" not in res0 and "bf16_mode" not in res0   # rank-0-only legs are N = 1 only
+    assert "cpu_baseline" not in res0 and "bf16_mode" not in res0 and "conforming_mode" not in res0   # rank-0-only legs are N = 1 only
+    # the legs every rank takes part in (their own timed regions with the same barriers / max over ranks): whole-job aggregates
+    su, epi = res0["sustained"], res0["episode_cached"]
+    assert su["steps"] >= 3 and su["value"] > 0 and abs(su["value"] - 2 * 4 * su["steps"] / su["seconds"]) / su["value"] < 0.01
+    assert epi["pairs"] == 32 * 15 and epi["queries_per_call"] == 7 and epi["calls_per_pass"] == -(-480 // 7)
+    assert abs(epi["value"] - 2 * 480 * epi["passes_timed"] / epi["seconds"]) / epi["value"] < 0.01
     assert res0["pipelined"] is True and "unpipelined" not in res0
     assert set(res0["pck_vs_synthetic_gt"]) >= {"PCK@0.2"}
 

@@ -386,3 +386,113 @@ def test_forward_pipelined_bit_equal(arch, H, bs, S, nb):
     for o, r in ((o0, ref[0]), (o1, ref[1]), (o2, ref[2])):
         for k in keys:
             assert torch.equal(o[0][k], r[k]), k
+
+
+def _episode_stream_data(n_ep, qpe, S, H):
+    """n_ep episodes of qpe queries each, in the reference's pair order (test_dataset.py:86-99): supports from one synthetic set,
+    queries from another; returns (sup batch, mask [n_ep,K,1], skeletons, query images [n_ep*qpe,3,H,H], episode_of_pair)."""
+    sup = synth.make_pairs(n_ep, S, H, seed=300, fixed_n_kp=False)
+    qry = synth.make_pairs(n_ep * qpe, 1, H, seed=400)
+    mask = sup["target_weight_s"][0].copy()
+    for tw in sup["target_weight_s"]:
+        mask = mask * tw
+    skels = [m["sample_skeleton"][0] for m in sup["img_metas"]]
+    return sup, mask, skels, qry["img_q"], np.repeat(np.arange(n_ep, dtype=np.int32), qpe)
+
+
+def _run_episode_stream(eng, cache, calls, sup, mask, skels, img_q, pipelined):
+    keys = ("output_kpts", "initial_proposals", "similarity_map", "adj", "attn_adj", "out_points")
+    res = []
+    for c in calls:
+        new = None
+        if len(c["new_episodes"]):
+            e = np.asarray(c["new_episodes"])
+            new = dict(img_s=[x[e] for x in sup["img_s"]], target_s=[x[e] for x in sup["target_s"]], mask_s=mask[e],
+                       skeletons=[skels[i] for i in e], slots=c["new_slots"])
+        o = eng.forward_episodes(cache, img_q[c["queries"]], c["slot_of_query"], new=new, pipelined=pipelined)   # (own output set per call)
+        res.append(o)
+    if pipelined:
+        eng.pipeline_flush()
+    torch.cuda.synchronize()
+    return [{k: o[k].cpu().numpy() for k in keys} for o in res]
+
+
+@pytest.mark.parametrize("shots,precision", [(1, "fp32"), (5, "fp32"), (1, "fp16"), (3, "fp16")])
+def test_forward_episodes_stream(shots, precision):
+    """f1, streaming form (ec_forward_episodes): 5 episodes x 5 queries in the reference's pair order, cut into calls of 6 queries
+    with a 3-slot cache (slots are re-used; calls with two, one and NO new episode occur; the supports of the new episodes ride in
+    the queries' backbone pass).  (a) every call equals ec_forward on its expanded (support set, query) pairs - which the oracle and
+    the golden fixtures pin - to 1e-6 (fp32) / the precision gates' bound (fp16 / mixed: the backbone batch composition differs, the
+    arithmetic per image does not); (b) the same stream through the PIPELINED form, head of call i beside the backbone of call
+    i + 1, row compaction on, is bit-equal to the plain one; (c) and so is ec_support_encode + ec_forward_cached."""
+    from edgecape_amd.engine import HipEngine, SupportCache
+    from edgecape_amd.episodes import stream_schedule
+    arch, H, n_ep, qpe, bs = "dinov2_vits14", 224, 5, 5, 6
+    sd = synth.make_weights(arch, seed=61)
+    sup, mask, skels, img_q, ep = _episode_stream_data(n_ep, qpe, shots, H)
+    eng = HipEngine(sd, arch=arch, image_size=H, max_batch=bs, max_shots=shots, backbone_precision=precision,
+                    head_precision="mixed" if precision == "fp16" else "fp32")
+    calls = stream_schedule(ep, bs, 3)
+    assert [len(c["new_episodes"]) for c in calls] == [2, 1, 1, 1, 0]
+    plain = _run_episode_stream(eng, SupportCache(eng, 3), calls, sup, mask, skels, img_q, False)
+    piped = _run_episode_stream(eng, SupportCache(eng, 3), calls, sup, mask, skels, img_q, True)
+    for i, c in enumerate(calls):
+        e = ep[c["queries"]]
+        ref = eng.forward(img_q[c["queries"]], [x[e] for x in sup["img_s"]], [x[e] for x in sup["target_s"]], mask[e], [skels[j] for j in e])
+        torch.cuda.synchronize()
+        for k, got in plain[i].items():
+            d = float(np.abs(got - ref[k].cpu().numpy()).max())
+            # fp16 / mixed: the skeleton head's image projections switch kernels with the number of support images in the call (the
+            # 8-phase 16-bit GEMM from 1024 rows on, ec_model.hip project_image_kv) - same precision class, not the same bits
+            tol = 1e-6 if precision == "fp32" else {"output_kpts": 5e-4, "out_points": 5e-4, "adj": 1e-3, "attn_adj": 1e-3}.get(k, 1e-6)
+            assert d < tol, (i, k, d)
+            assert np.array_equal(got, piped[i][k]), (i, k, float(np.abs(got - piped[i][k]).max()))
+    # (c) the two-call form on the same queries: all episodes encoded at once, then the queries of call 1 (episodes 1 and 2)
+    cache = eng.support_encode(sup["img_s"], sup["target_s"], mask, skels)
+    got = eng.forward_cached(img_q[calls[1]["queries"]], cache, ep[calls[1]["queries"]])
+    torch.cuda.synchronize()
+    for k in plain[1]:
+        d = float(np.abs(got[k].cpu().numpy() - plain[1][k]).max())
+        tol = 1e-6 if precision == "fp32" else {"output_kpts": 5e-4, "out_points": 5e-4, "adj": 1e-3, "attn_adj": 1e-3}.get(k, 1e-6)
+        assert d < tol, (k, d)
+    # error behaviour: an empty slot, a slot number past the cache, two new episodes in one slot
+    c2 = SupportCache(eng, 3)
+    with pytest.raises(Exception, match="empty"):
+        eng.forward_episodes(c2, img_q[:2], np.array([0, 0], np.int32))
+    with pytest.raises(Exception, match="out of range"):
+        eng.forward_episodes(c2, img_q[:2], np.array([0, 3], np.int32))
+    with pytest.raises(Exception, match="share a cache slot"):
+        eng.forward_episodes(c2, None, None, new=dict(img_s=[x[:2] for x in sup["img_s"]], target_s=[x[:2] for x in sup["target_s"]],
+                                                      mask_s=mask[:2], skeletons=skels[:2], slots=[1, 1]))
+    torch.cuda.synchronize()
+
+
+def test_one_shot_call_on_a_multi_shot_model_pipelined():
+    """a model built for max_shots = 3 and called with S = 1 through ec_forward_pipelined (row compaction on by
+    default there) ran its skeleton head on the row plan of an EARLIER S = 3 call - or on an empty one.  A 3-shot call, then a 1-shot
+    call with a different batch mask, both pipelined: the 1-shot outputs must be bit-equal to plain ec_forward (no compaction)."""
+    from edgecape_amd.engine import HipEngine
+    arch, H, bs = "dinov2_vits14", 224, 4
+    eng = HipEngine(synth.make_weights(arch, seed=9), arch=arch, image_size=H, max_batch=bs, max_shots=3, backbone_precision="fp16",
+                    head_precision="mixed")
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    prepared = []
+    for S, seed in ((3, 50), (1, 77)):
+        b = synth.make_pairs(bs, S, H, seed=seed, fixed_n_kp=False)
+        mask = b["target_weight_s"][0].copy()
+        for tw in b["target_weight_s"]:
+            mask = mask * tw
+        e, o = eng._edges([m["sample_skeleton"][0] for m in b["img_metas"]], bs)
+        prepared.append((dev(b["img_q"]), [dev(x) for x in b["img_s"]], [dev(x) for x in b["target_s"]], dev(mask.reshape(bs, -1)), e, o))
+    keys = ("output_kpts", "initial_proposals", "similarity_map", "adj", "attn_adj", "out_points")
+    ref = eng._outputs(bs)
+    eng.forward_resident(*prepared[1], ref)
+    torch.cuda.synchronize()
+    o3, o1 = eng._outputs(bs), eng._outputs(bs)
+    eng.forward_pipelined(*prepared[0], o3)
+    eng.forward_pipelined(*prepared[1], o1)
+    eng.pipeline_flush()
+    torch.cuda.synchronize()
+    for k in keys:
+        assert torch.isfinite(o1[0][k]).all(), k
+        assert torch.equal(o1[0][k], ref[0][k]), (k, float((o1[0][k] - ref[0][k]).abs().max()))

@@ -25,7 +25,8 @@ a = ap.parse_args()
 per_seed, pooled = T.conformance_at_scale(a.batches, tuple(int(x) for x in a.seeds.split(",")), a.backbone, a.head, a.config, outliers=a.outliers)
 c = T.CFG[a.config]
 rec = dict(config=f"{a.config}: {c['S']}-shot, batch {c['bs']}, {c['H']}x{c['H']}, {c['arch']}; {a.batches} disjoint batches per weight seed" + ("; weights with planted activation outliers" if a.outliers else ""), backbone=a.backbone, head=a.head, oracle="oracle/edgecape_oracle.py (fp32 CPU)",
-           tolerance="1e-3 abs on output_kpts of valid keypoints", per_weight_seed=per_seed, pooled=pooled)
+           tolerance="1e-3 abs on output_kpts of valid keypoints", per_weight_seed=per_seed, pooled=pooled,
+           library_source_hash=__import__("edgecape_amd.build", fromlist=["source_hash"]).source_hash())   # bench.py quotes the record only for this library
 print(json.dumps(rec, indent=1))
 if a.out:
     with open(a.out, "w") as f:
