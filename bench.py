@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--cpu-runs", type=int, default=5, help="timed CPU forwards per batch size (after 2 warm-ups)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-episode", action="store_true", help="skip the episode-protocol measurement (ec_forward_episodes)")
+    ap.add_argument("--episode-images", type=int, default=0,
+                    help="backbone images per call of the episode leg (queries + support images of the episodes that start in it); "
+                         "0 = as many as a headline step, (1 + shots) * batch")
     ap.add_argument("--sustained-seconds", type=float, default=5.0,
                     help="length of the `sustained` leg: pipelined steps for about this long in the same process (0: skip).  `value` stays the "
                          "K timed steps of the contract - a 0.1 s burst; this leg says what the path holds once the clock has settled")
@@ -331,7 +334,7 @@ def episode_mode(args, sd, synth, bs, S, H, arch, apis, rank=0, world=1, n_ep=32
     import torch
     from edgecape_amd.engine import HipEngine
     from edgecape_amd.episodes import stream_schedule
-    n_img = (1 + S) * bs
+    n_img = args.episode_images or (1 + S) * bs
     q = max(1, n_img * qpe // (qpe + S))
     cap = (q + qpe - 1) // qpe + 2
     eng = HipEngine(sd, arch=arch, image_size=H, max_batch=q, max_shots=S, backbone_precision=args.precision, head_precision=args.head_precision)

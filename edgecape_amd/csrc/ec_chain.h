@@ -58,12 +58,12 @@ struct ChainP {
   // *n_active leave at once.
   const int* rowmap = nullptr;
   const int* n_active = nullptr;
-  // ... and every global output row of a representative is copied, inside the kernel, to the token rows of its sample's other masked
-  // tokens (round 5; round 4: a bcast_rows launch behind every chain): active index i fans out to fan_cnt[i] rows fan_dst[fan_off[i] ..]
-  // (0 for valid tokens), so every token row of every output is (re)written by every launch, as without compaction.
-  const int* fan_off = nullptr;
-  const int* fan_cnt = nullptr;
-  const int* fan_dst = nullptr;
+  // ... and every global output row of a representative is also written, inside the kernel, to the token rows of its sample's other
+  // masked tokens (round 5; round 4: a bcast_rows launch behind every chain): active index i fans out to the rows fan_base[i] + k for
+  // every set bit k of the two 64-bit words fan_bits[2 i], fan_bits[2 i + 1] (zero for valid tokens), so every token row of every
+  // output is (re)written by every launch, as without compaction.
+  const int* fan_base = nullptr;
+  const unsigned long long* fan_bits = nullptr;
   int trace_stage = -1;        // TRACE: stage whose K loop / epilogue is stamped finely into trace[64..127]
   unsigned* trace = nullptr;   // EC_CHAIN_TRACE=1 (debug instantiation): s_memtime stamps of one mid-grid workgroup's wave 0
 };

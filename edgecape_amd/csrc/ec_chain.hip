@@ -93,14 +93,23 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
   if (row0 >= n_rows) return;                       // whole workgroup, before any barrier
   int* const rowm = (int*)(smem + 3072);            // [32] (CH_RED = 4096: LayerNorm partials 0..2047, keypoint tail ..2303)
   auto map_row = [&](int i) { const int c = min(i, n_rows - 1); return p.rowmap ? p.rowmap[c] : c; };
-  // Fan-out of the representative rows (ChainP::fan_*): slab row r is written to fanc[r] further token rows fan_dst[fano[r] ..]
-  int* const fano = (int*)(smem + 3200);            // [32]
-  int* const fanc = (int*)(smem + 3328);            // [32]
-  if (tid < CH_BM) {
-    rowm[tid] = map_row(row0 + tid);
-    const bool on = p.fan_cnt != nullptr && row0 + tid < n_rows;
-    fano[tid] = on ? p.fan_off[row0 + tid] : 0;
-    fanc[tid] = on ? p.fan_cnt[row0 + tid] : 0;
+  // Fan-out of the representative rows (ChainP::fan_*): slab row r is also written to the token rows fbase[r] + k of the set bits k
+  // of fbits[r] (two 64-bit words: K <= 128); frep: bit r set <=> slab row r has such rows (wave 0's ballot)
+  int* const fbase = (int*)(smem + 3200);                                     // [32]
+  unsigned long long* const fbits = (unsigned long long*)(smem + 3328);       // [32][2]
+  unsigned* const frep = (unsigned*)(smem + 3840);
+  if (tid < 64) {
+    unsigned long long b0 = 0ull, b1 = 0ull;
+    if (tid < CH_BM) {
+      rowm[tid] = map_row(row0 + tid);
+      const bool on = p.fan_bits != nullptr && row0 + tid < n_rows;
+      if (on) { b0 = p.fan_bits[(long)(row0 + tid) * 2]; b1 = p.fan_bits[(long)(row0 + tid) * 2 + 1]; }
+      fbase[tid] = on ? p.fan_base[row0 + tid] : 0;
+      fbits[tid * 2] = b0;
+      fbits[tid * 2 + 1] = b1;
+    }
+    const unsigned long long any = __ballot((b0 | b1) != 0ull);
+    if (tid == 0) *frep = (unsigned)any;
   }
   int grow_l[2];
 #pragma unroll
@@ -321,13 +330,18 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
           const float z = dl + logf(fmaxf(x, 1e-3f) / fmaxf(1.f - x, 1e-3f));
           const float bn = 1.f / (1.f + expf(-z));
           coord[r * 2 + c] = bn;
-          if (row0 + r < n_rows && part == 0) {
-            S.kp_next[(long)gr * 2 + c] = bn;
-            const int* dl = p.fan_dst + fano[r];
-            for (int dd = 0; dd < fanc[r]; ++dd) S.kp_next[(long)dl[dd] * 2 + c] = bn;   // (the sample's other masked tokens)
-          }
+          if (row0 + r < n_rows && part == 0) S.kp_next[(long)gr * 2 + c] = bn;
         }
         __syncthreads();
+        if (p.fan_bits && part == 0 && tid < 256) {
+          // (row compaction) the sample's other masked tokens take the representative's point: thread (k, coordinate) per representative
+          const int k = tid >> 1, cc = tid & 1;
+          for (unsigned rm = __builtin_amdgcn_readfirstlane(*frep); rm; rm &= rm - 1u) {
+            const int r = __builtin_ctz(rm);
+            const unsigned long long w = fbits[r * 2 + (k >> 6)];
+            if ((w >> (k & 63)) & 1ull) S.kp_next[(long)(fbase[r] + k) * 2 + cc] = coord[r * 2 + cc];
+          }
+        }
         if (kp_sine) {   // sine embedding of b_next -> the operand buffer of the next stage (positional_encoding.py; sincos_kernel)
           for (int qd = tid; qd < CH_BM * 64; qd += 512) {
             const int r = qd >> 6, c = (qd & 63) << 2;           // 4 consecutive features of row r
@@ -452,21 +466,37 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainP p) {
       ++i;
     }
     stamp();   // stage done (K loop + epilogues)
-    if (p.fan_cnt && store_out) {
+    if (p.fan_bits && store_out) {
       // Row compaction: the masked token rows that were not computed equal their sample's representative row.  Its freshly stored
-      // output row (this workgroup's own stores: visible to the whole workgroup behind the barrier) is copied to them by all 512
-      // threads - ~60 rows per representative, about one representative per slab.  (Round 4 did this with a bcast_rows launch behind
-      // every chain: 27 launches per step on the head's dependent lanes.)
+      // output row (this workgroup's own stores: visible to the whole workgroup behind the barrier) is copied to them.  Thread t holds
+      // the 16-byte chunk t % (N/4) of the row in registers; the 512 / (N/4) thread groups deal the sample's K tokens out between them
+      // (token k to group k % G); a group is whole waves (N % 256 == 0), so "is token k masked" is a scalar bit test on the sample's mask
+      // words and a wave only issues the stores that exist - nothing is read from memory between them.
+      // (Round 4 did this with a bcast_rows launch behind every chain: 27 launches per step on the head's dependent lanes.  In-kernel
+      //  forms that read a destination list from memory, or walked the mask bits with per-lane arithmetic, cost 15-30 us per chain.)
       __syncthreads();
-      const int q4 = S.N >> 2;
-      for (int r = 0; r < CH_BM; ++r) {
-        const int cnt = fanc[r];
-        if (cnt == 0) continue;   // (workgroup-uniform)
-        const float* src = S.out + (long)rowm[r] * S.ldo;
-        const int* dl = p.fan_dst + fano[r];
-        for (int q = tid; q < cnt * q4; q += 512) {
-          const int dd = q / q4, c = (q - dd * q4) << 2;
-          *(f32x4*)(S.out + (long)dl[dd] * S.ldo + c) = *(const f32x4*)(src + c);
+      const int q4 = S.N >> 2;                          // host: N % 256 == 0, N <= 2048
+      const int G = 512 / q4;
+      const int c = tid % q4, g = __builtin_amdgcn_readfirstlane(tid / q4);
+      // two workgroups per slab: a dealt-out stage's 256-column passes alternate between the parts, and each part copies the columns
+      // it computed itself (a wave's 64 chunks are one pass's 256 columns)
+      const bool cols_mine = shared || __builtin_amdgcn_readfirstlane(((c >> 6) % p.split) == part);
+      if (g < G && cols_mine) {
+        for (unsigned rm = __builtin_amdgcn_readfirstlane(*frep); rm; rm &= rm - 1u) {
+          const int r = __builtin_ctz(rm);
+          const unsigned long long w0 = fbits[r * 2], w1 = fbits[r * 2 + 1];   // (LDS broadcast reads: the same value in every lane)
+          // (readfirstlane returns a signed int: without the casts the low word is sign-extended over the high one)
+          const unsigned long long b0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(w0 >> 32)) << 32) |
+                                        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)w0);
+          const unsigned long long b1 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(w1 >> 32)) << 32) |
+                                        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)w1);
+          const int base = __builtin_amdgcn_readfirstlane(fbase[r]);
+          const f32x4 v = *(const f32x4*)(S.out + (long)__builtin_amdgcn_readfirstlane(rowm[r]) * S.ldo + c * 4);
+          float* const dst0 = S.out + (long)base * S.ldo + c * 4;
+          for (int k = g; k < 128; k += G) {
+            const unsigned long long w = k < 64 ? b0 : b1;
+            if ((w >> (k & 63)) & 1ull) *(f32x4*)(dst0 + (long)k * S.ldo) = v;
+          }
         }
       }
     }
@@ -506,7 +536,7 @@ ChDev ch_dev[64];
 int run_chain(const ChainP& p, hipStream_t st) {
   EC_REQUIRE(p.rows > 0 && p.n_stages >= 1 && p.n_stages <= CH_MAX_STAGES, -1, "chain: bad stage count");
   EC_REQUIRE(p.split == 1 || p.split == 2, -1, "chain: split");
-  EC_REQUIRE(!p.fan_cnt || (p.rowmap && p.fan_off && p.fan_dst && p.split == 1), -1, "chain: row fan-out needs a row map and one workgroup per slab");
+  EC_REQUIRE(!p.fan_bits || (p.rowmap && p.fan_base), -1, "chain: row fan-out needs a row map");
   EC_REQUIRE(p.lds_bytes >= CH_RED && p.lds_bytes <= 160 * 1024, -1, "chain: LDS layout does not fit");
   for (int s = 0; s < p.n_stages; ++s) {
     const ChainStage& S = p.st[s];
@@ -522,6 +552,7 @@ int run_chain(const ChainP& p, hipStream_t st) {
     EC_REQUIRE(!S.post_table || S.post_period > 0, -1, "chain: post-table period");
     EC_REQUIRE(!S.kp_w || (S.N == 256 && !S.ln_w && S.kp_b && S.kp_prev && S.kp_next && (!S.kp_dim_t || S.s_off >= 0)), -1, "chain: keypoint tail needs N = 256, no LayerNorm");
     EC_REQUIRE((S.h1 != 0) == (p.h1 != 0), -1, "chain: stages packed for different arithmetic");
+    EC_REQUIRE(!p.fan_bits || !S.out || (S.N <= 2048 && S.N % 256 == 0), -1, "chain: row fan-out needs N % 256 == 0, N <= 2048");
     EC_REQUIRE(p.split == 1 || !(S.s_off >= 0 || S.keep || S.ln_w) || !S.resid || !S.out || S.resid != S.out, -1,
                "chain: split chains need out != resid in the stages both workgroups compute");
   }

@@ -88,7 +88,7 @@ struct ec_model {
   bool head_chain = false;   // ... and the row-wise stretches of every head layer as row-chain launches (ec_chain.hip); EC_CHAIN=0: off
   // Row compaction of the token-row chains (round 4; ec_ops.h rowplan): the chains compute the valid keypoint tokens and one
   // representative masked token per sample, whose output rows the kernel also writes to the sample's other masked rows.  EC_COMPACT=0: every row is computed.
-  struct RowPlan { int* plan = nullptr; int* rowmap = nullptr; int* fan_off = nullptr; int* fan_cnt = nullptr; int* cdst = nullptr; };
+  struct RowPlan { int* plan = nullptr; int* rowmap = nullptr; int* fan_base = nullptr; unsigned long long* fan_bits = nullptr; bool split = false; };
   RowPlan plan_dec, plan_skel;   // bs samples (decoder, keypoint branches) / S * bs samples (skeleton head)
   const RowPlan* skel_plan = nullptr;   // the plan the skeleton head of the call being enqueued reads (build_row_plans): plan_dec when one
                                         // plan over the same samples serves both (S == 1, both built from the same mask), else plan_skel
@@ -690,10 +690,12 @@ struct ChainBuild {
     // (not under a row plan: two workgroups per slab buy latency with duplicated work - both compute the stages that later stages read.
     //  Measured with compaction on, two / one workgroup per slab / no compaction, pipelined, interleaved (profiles/r04_compact_split_ab.txt):
     //  cfg2 5645 / 5645 / 5545 pairs/s, ViT-S/14 @224 11 610 / 11 710 / 11 170 - one per slab is never worse)
-    p.split = (!plan && may_split && p.n_stages > 1 && ((rows + CH_BM - 1) / CH_BM) * 2 <= 256) ? 2 : 1;
+    // (r04: under a plan one workgroup per slab was never worse for PIPELINED calls - 5645 / 5645 pairs/s on cfg2, 11 610 / 11 710 on ViT-S
+    //  @224, profiles/r04_compact_split_ab.txt; plain calls, where the head's latency counts, keep two: RowPlan::split)
+    p.split = ((!plan || plan->split) && may_split && p.n_stages > 1 && ((rows + CH_BM - 1) / CH_BM) * 2 <= 256) ? 2 : 1;
     if (!plan) return run_chain(p, st);
     p.rowmap = plan->rowmap; p.n_active = plan->plan;
-    p.fan_off = plan->fan_off; p.fan_cnt = plan->fan_cnt; p.fan_dst = plan->cdst;   // (the masked rows that are not computed: written in-kernel)
+    p.fan_base = plan->fan_base; p.fan_bits = plan->fan_bits;   // (the masked rows that are not computed: written in-kernel)
     return run_chain(p, st);
   }
 };
@@ -911,13 +913,14 @@ struct SupportState {
 // the skeleton head's over S * bs (shot-major token rows; one shot: the same plan).
 static int build_row_plans(ec_model* m, const float* mask, int bs, int S, hipStream_t st, bool dec = true, bool skel = true) {
   if (!m->compact) return 0;
-  if (dec) RUN(rowplan(mask, bs, bs, m->K, m->plan_dec.plan, m->plan_dec.rowmap, m->plan_dec.fan_off, m->plan_dec.fan_cnt, m->plan_dec.cdst, st));
+  m->plan_dec.split = m->plan_skel.split = !m->dq_active;   // two workgroups per slab where the head's latency counts (plain calls)
+  if (dec) RUN(rowplan(mask, bs, bs, m->K, m->plan_dec.plan, m->plan_dec.rowmap, m->plan_dec.fan_base, m->plan_dec.fan_bits, st));
   if (skel) {
     // (chosen by the RUNTIME S: a model built for max_shots > 1 and called with one shot reads the decoder's plan - round 4 skipped
     //  both branches in that case and the skeleton head ran on a stale plan)
     if (S == 1 && dec) m->skel_plan = &m->plan_dec;
     else {
-      RUN(rowplan(mask, bs, S * bs, m->K, m->plan_skel.plan, m->plan_skel.rowmap, m->plan_skel.fan_off, m->plan_skel.fan_cnt, m->plan_skel.cdst, st));
+      RUN(rowplan(mask, bs, S * bs, m->K, m->plan_skel.plan, m->plan_skel.rowmap, m->plan_skel.fan_base, m->plan_skel.fan_bits, st));
       m->skel_plan = &m->plan_skel;
     }
   }
@@ -1840,8 +1843,7 @@ int ec_finalize(ec_handle m) {
     for (int which = 0; which < 2; ++which) {
       ec_model::RowPlan& pl = which ? m->plan_skel : m->plan_dec;
       const size_t rows = (which ? (size_t)S : 1) * Mk;
-      if ((rc = dalloc(m, &pl.plan, 4)) || (rc = dalloc(m, &pl.rowmap, rows)) || (rc = dalloc(m, &pl.fan_off, rows)) || (rc = dalloc(m, &pl.fan_cnt, rows)) ||
-          (rc = dalloc(m, &pl.cdst, rows))) return rc;
+      if ((rc = dalloc(m, &pl.plan, 4)) || (rc = dalloc(m, &pl.rowmap, rows)) || (rc = dalloc(m, &pl.fan_base, rows)) || (rc = dalloc(m, &pl.fan_bits, 2 * rows))) return rc;
       EC_HIP(hipMemset(pl.plan, 0, 4 * sizeof(int)));
     }
   }
@@ -2140,6 +2142,7 @@ static int episodes_impl(ec_handle m, ec_support_t c, const float* const* img_s,
   RUN(wait_pending_decoder(m, st));
   if (n_new > 0) RUN(upload_edges(m, edges, off, n_new, st));
   RUN(run_backbone(m, srcs, counts, 1 + S, m->feat, st));
+  if (bs > 0) m->taps["feature_q"] = {m->feat, (long)((size_t)bs * per_img)};
   if (bs == 0) RUN(tl_mark(m, "support-only", st));
   else RUN(tl_mark(m, "head", st));
   if (m->overlap && n_new > 0 && bs > 0) {

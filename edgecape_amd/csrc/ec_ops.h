@@ -92,12 +92,12 @@ int adj_build(const int32_t* edges, const int32_t* offsets, const float* mask_s,
 // adjacency rows / columns and attention keys of masked tokens are zeroed), so a row-wise kernel only has to compute the valid tokens
 // and ONE masked token per sample.  For `ns` samples of K tokens, sample i using the mask row i % bs of mask_s [bs, K]:
 //   plan[0] = n_active, plan[1] = n_copy, rowmap [ns*K]: token rows to compute (sample-major, valid tokens in order, then the
-//   representative = the first masked token); copy_dst [ns*K]: the other masked token rows, sample-major; fan_off / fan_cnt [ns*K], indexed
-//   like rowmap: the range of copy_dst that equals this computed row (count 0 for a valid token) - the chain kernel writes a
-//   representative's output rows to them itself (ChainP::fan_*).
+//   representative = the first masked token); fan_base [ns*K] / fan_bits [ns*K][2], indexed like rowmap: a representative's rows are
+//   also those of its sample's other masked tokens, rows fan_base + k for every set bit k of the two 64-bit words (zero words for a
+//   valid token) - the chain kernel writes them itself (ChainP::fan_*).
 // A sample WITHOUT a valid token keeps token 0 as a row of its own: its key 0 is un-masked (encoder_decoder.py:359-360, skeleton.py:98-99)
 // and sees a different attention bias than the other masked tokens do.
-int rowplan(const float* mask_s, int bs, int ns, int K, int* plan, int* rowmap, int* fan_off, int* fan_cnt, int* copy_dst, hipStream_t st);
+int rowplan(const float* mask_s, int bs, int ns, int K, int* plan, int* rowmap, int* fan_base, unsigned long long* fan_bits, hipStream_t st);
 int rownorm(const float* x, float* y, int rows, int cols, hipStream_t st);
 // skeleton.py:134-161 — combine cosine similarity with the prior, soft-normalise, Markov matrix
 int adj_combine(const float* P, const float* binary, const float* valid, const float* zc_w, const float* zc_b,

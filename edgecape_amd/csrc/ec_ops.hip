@@ -446,8 +446,8 @@ __global__ __launch_bounds__(256) void adj_build_kernel(const int32_t* edges, co
 // bits); a serial prefix over the samples by thread 0 (ns <= a few hundred: sub-microsecond against the ~5 us the launch costs);
 // pass 2: every wave writes its samples' entries.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void rowplan_kernel(const float* mask_s, int bs, int ns, int K, int* plan, int* rowmap, int* fan_off,
-                                                       int* fan_cnt, int* copy_dst) {
+__global__ __launch_bounds__(1024) void rowplan_kernel(const float* mask_s, int bs, int ns, int K, int* plan, int* rowmap, int* fan_base,
+                                                       unsigned long long* fan_bits) {
   extern __shared__ int pl_lds[];        // [ns] active offsets, [ns] copy offsets
   int* a_off = pl_lds;
   int* c_off = pl_lds + ns;
@@ -496,9 +496,13 @@ __global__ __launch_bounds__(1024) void rowplan_kernel(const float* mask_s, int 
       const unsigned long long v = half ? v1 : v0, mk = half ? m1 : m0;
       const int vrank = (half ? __popcll(v0) : 0) + __popcll(v & below);
       const int mrank = (half ? __popcll(m0) : 0) + __popcll(mk & below);
-      if ((v >> lane) & 1ull) { rowmap[ao + vrank] = (int)(base + k); fan_cnt[ao + vrank] = 0; fan_off[ao + vrank] = 0; }
-      else if (k == rep) { rowmap[ao + nv] = (int)(base + k); fan_off[ao + nv] = co; fan_cnt[ao + nv] = K - nv - 1; }
-      else copy_dst[co + mrank - 1] = (int)(base + k);   // masked, not the representative (mrank >= 1): a copy of row `rep`
+      if ((v >> lane) & 1ull) {
+        rowmap[ao + vrank] = (int)(base + k); fan_base[ao + vrank] = 0; fan_bits[2 * (ao + vrank)] = 0ull; fan_bits[2 * (ao + vrank) + 1] = 0ull;
+      } else if (k == rep) {   // the representative: its rows are also the sample's other masked tokens' (bit k of the two words)
+        rowmap[ao + nv] = (int)(base + k); fan_base[ao + nv] = (int)base;
+        fan_bits[2 * (ao + nv)] = rep < 64 ? m0 & ~(1ull << rep) : m0;
+        fan_bits[2 * (ao + nv) + 1] = rep >= 64 ? m1 & ~(1ull << (rep - 64)) : m1;
+      }
     }
   }
 }
@@ -1039,9 +1043,9 @@ int adj_build(const int32_t* edges, const int32_t* offsets, const float* mask_s,
   return 0;
 }
 
-int rowplan(const float* mask_s, int bs, int ns, int K, int* plan, int* rowmap, int* fan_off, int* fan_cnt, int* copy_dst, hipStream_t st) {
+int rowplan(const float* mask_s, int bs, int ns, int K, int* plan, int* rowmap, int* fan_base, unsigned long long* fan_bits, hipStream_t st) {
   EC_REQUIRE(K >= 1 && K <= 128 && ns >= 1 && ns <= 8192 && bs >= 1, -1, "rowplan: K <= 128, samples <= 8192");
-  hipLaunchKernelGGL(rowplan_kernel, dim3(1), dim3(1024), (size_t)ns * 2 * sizeof(int), st, mask_s, bs, ns, K, plan, rowmap, fan_off, fan_cnt, copy_dst);
+  hipLaunchKernelGGL(rowplan_kernel, dim3(1), dim3(1024), (size_t)ns * 2 * sizeof(int), st, mask_s, bs, ns, K, plan, rowmap, fan_base, fan_bits);
   EC_LAUNCH_CHECK();
   return 0;
 }

@@ -5,11 +5,17 @@ import sqlite3
 import sys
 
 
-def main(path, head_only=False):
+def main(path, head_only=False, which=-1):
+    """which: -1 the last step (the last two im2col launches open it: query + support sources); k < -1: the step |k| - 1 steps before
+    the end of the trace (e.g. the last HEADLINE step when an episode leg follows it)."""
     db = sqlite3.connect(path)
     rows = db.execute("select name,start,end,grid_x,grid_y,grid_z,workgroup_x,stream_id from kernels order by start").fetchall()
     idx = [i for i, r in enumerate(rows) if "im2col" in r[0]]
-    step = rows[idx[-2]:]
+    # a step opens with its im2col launches (one per image source, back to back on the caller's stream): group consecutive ones
+    starts = [i for j, i in enumerate(idx) if j == 0 or not all("im2col" in rows[x][0] or rows[x][7] != rows[i][7] for x in range(idx[j - 1], i))]
+    first = starts[which]
+    last = starts[which + 1] if which < -1 else len(rows)
+    step = rows[first:last]
     t0 = step[0][1]
     agg = {}
     tot = 0
@@ -30,4 +36,4 @@ def main(path, head_only=False):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else False)
+    main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 and float(sys.argv[2]) > 0 else False, int(sys.argv[3]) if len(sys.argv) > 3 else -1)
