@@ -27,7 +27,7 @@ class EcConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "embed_dim", "depth", "num_heads", "image_size", "patch", "num_kpts", "d_model", "nhead", "enc_layers",
         "dec_layers", "skel_layers", "ffn_dim", "skel_ffn_dim", "max_hops", "heatmap_size", "max_shots", "max_batch",
-        "backbone_precision", "head_precision", "image_width")]
+        "backbone_precision", "head_precision", "image_width", "gt_skeleton", "no_attn_bias")]
 
 
 class EcOutputs(C.Structure):

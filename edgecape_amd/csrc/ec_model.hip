@@ -79,6 +79,8 @@ struct ec_model {
   int H = 0, W = 0;                                                       // input height / width (ec_config::image_size / image_width)
   int Kp = 640;  // padded im2col width (588 -> 640: multiple of 128 bytes for fp32 and bf16)
   bool finalized = false;
+  bool gt_skel = false;      // SkeletonPredictor(learn_skeleton=False): the ground-truth adjacency, no skeleton layers, no Markov stack (skeleton.py:70-74)
+  bool markov_bias = true;   // the decoder layers' self-attention adds the Markov-bias MLP (attn_bias=True AND a stack exists)
   bool bb16 = false;         // backbone GEMM operands / activations are 16-bit ...
   bool bbf16 = false;        // ... in IEEE fp16 (EC_F16) instead of bf16 (EC_BF16)
   bool bb_split = false;     // EC_BF16X3 backbone: fp32 activations, every MFMA operand split hi+lo bf16 (3 MFMAs per product)
@@ -93,9 +95,12 @@ struct ec_model {
   const RowPlan* skel_plan = nullptr;   // the plan the skeleton head of the call being enqueued reads (build_row_plans): plan_dec when one
                                         // plan over the same samples serves both (S == 1, both built from the same mask), else plan_skel
   // Measured (profiles/r04_compact_ab.txt, cfg2, interleaved): +1.5 % pairs/s through ec_forward_pipelined (5384 / 5385 / 5398 -> 5481 /
-  // 5464 / 5466: a deferred head costs the backbone beside it CU time), -0.7 % through ec_forward (4927 -> 4883 / 4901: there the head's
-  // LATENCY counts, a chain workgroup takes as long as before and every chain now drags a copy launch behind it).  So: pipelined
-  // calls only (compact_mode 1, default); EC_COMPACT=2: every call, EC_COMPACT=0: never.  Results are bit-identical either way.
+  // 5464 / 5466: a deferred head costs the backbone beside it CU time), -0.7 % through ec_forward with round 4's copy launch behind every
+  // chain.  Round 5 (the fan-out inside the chain kernel, two workgroups per slab under a plan for plain calls; profiles/r05_compact_ab.txt,
+  // interleaved): pipelined 5415 / 5413 with compaction in every call vs 5434 / (5192) pipelined-only - the same; ec_forward 4815 / 4858 vs
+  // 4899 / 4890 - still -1 %: there the head's LATENCY counts, a chain workgroup takes as long as before (it is bound by its weight
+  // stream) and the fan-out adds its tail to each of the 27 chains on the critical lanes.  So: pipelined calls only (compact_mode 1,
+  // default); EC_COMPACT=2: every call, EC_COMPACT=0: never.  Results are bit-identical either way.
   // On ViT-S/14 @224, where the head is as long as the backbone, it is worth +4-5 % (11 170 -> 11 610-11 710 pairs/s).
   int compact_mode = 0;
   bool compact = false;          // ... for the call being enqueued
@@ -345,8 +350,10 @@ static std::vector<float> sine_table(int gh, int gw, int nf, std::vector<float>*
 }
 
 // Build the derived weights of one TransformerDecoderLayer (encoder_decoder.py:527-651).
+// biased: a main-decoder layer (q / k / v_proj keys - engine.normalize_state_dict splits a fused in_proj into them -, query = [x | qpe]);
+// markov: ... whose self-attention adds the Markov-bias MLP of the hop stack (bias_attn.py:188-191)
 static int build_dec_layer(ec_model* m, const std::string& P, bool biased, bool two_way, const std::vector<float>& pos_img,
-                           DecLayer* L) {
+                           DecLayer* L, bool markov = true) {
   const int d = m->d, E = 2 * m->d, HW = m->HW;
   int rc;
   if (biased) {
@@ -356,9 +363,11 @@ static int build_dec_layer(ec_model* m, const std::string& P, bool biased, bool 
     for (const Tensor* t : {q, k, v}) W.insert(W.end(), t->host.begin(), t->host.end());
     for (const Tensor* t : {qb, kb, vb}) b.insert(b.end(), t->host.begin(), t->host.end());
     if ((rc = make_lin_host(m, W, b, 3 * d, d, &L->sa_in))) return rc;
-    GET(w1, P + "self_attn.markov_structural_mlp.0.weight"); GET(b1, P + "self_attn.markov_structural_mlp.0.bias");
-    GET(w2, P + "self_attn.markov_structural_mlp.3.weight"); GET(b2, P + "self_attn.markov_structural_mlp.3.bias");
-    L->m_w1 = w1->dev; L->m_b1 = b1->dev; L->m_w2 = w2->dev; L->m_b2 = b2->dev;
+    if (markov) {
+      GET(w1, P + "self_attn.markov_structural_mlp.0.weight"); GET(b1, P + "self_attn.markov_structural_mlp.0.bias");
+      GET(w2, P + "self_attn.markov_structural_mlp.3.weight"); GET(b2, P + "self_attn.markov_structural_mlp.3.bias");
+      L->m_w1 = w1->dev; L->m_b1 = b1->dev; L->m_w2 = w2->dev; L->m_b2 = b2->dev;
+    }
   } else {
     if ((rc = make_lin(m, P + "self_attn.in_proj_weight", P + "self_attn.in_proj_bias", &L->sa_in, false))) return rc;
   }
@@ -959,6 +968,30 @@ static int run_head_support(ec_model* m, const float* const* fs, const float* co
   float* attn_adj = ss.attn_adj;
   EC_REQUIRE(hops1 <= 5, EC_ERR_ARG, "max_hops > 4 not supported");   // all argument checks happen before the first fork
 
+  if (m->gt_skel && part != 1) {
+    // SkeletonPredictor(learn_skeleton=False) (skeleton.py:70-74): adj = normalize_adj of the skeleton edges - the row-normalised binary
+    // adjacency adj_build already makes for refine_features (x / (n + 1e-8) and nan_to_num(x / n) are the same fp32 numbers for the
+    // integer row sums n of a binary matrix) - no SkeletonPredictor layers, no Markov stack (attn_adj = None)
+    for (int s = 0; s < S; ++s) {
+      if (part == 2)
+        RUN(pool_apply(m->tap_n + (long)s * Mk, m->tap_i + (long)s * Mk * HW, m->tap_w + (long)s * Mk * HW, fs[s], m->pooled,
+                       s == 0 ? 0.f : 1.f, bs, K, m->cfg.heatmap_size, gh, gw, C, st));
+      else
+        RUN(pool_gather(target_s[s], mask_s, 1.f / (float)S, fs[s], m->pooled, s == 0 ? 0.f : 1.f, bs, K, m->cfg.heatmap_size, gh, gw, C, st));
+    }
+    if (m->ev_feat_read_p) EC_HIP(hipEventRecord(m->ev_feat_read_p, st));
+    if (m->ev_feat_read) EC_HIP(hipEventRecord(m->ev_feat_read, st));
+    RUN(linear(m->pooled, C, false, m->query_proj, ss.sk, d, false, Mk, ACT_NONE, st));
+    m->taps["support_keypoints"] = {ss.sk, (long)Mk * d};
+    if (part == 0) {
+      RUN(adj_build(m->d_edges, m->d_off, mask_s, ss.valid, ss.kmask, ss.kmask_fixed, m->binary, m->adj_r1, bs, K, st));
+      RUN(build_row_plans(m, mask_s, bs, S, st, !m->episode_call, false));
+    }
+    if (on_sk) RUN(on_sk(st));
+    if (ev_sk) EC_HIP(hipEventRecord(ev_sk, st));
+    RUN(adj_gt(m->adj_r1, ss.valid, adj_out, ss.adj1, bs, K, st));
+    return tl_mark(m, "S.end", st);
+  }
   // image lane of the skeleton head (see (3)): forked first so image_project overlaps the pooling chain
   const bool ov2 = m->overlap_dec && m->side2 != nullptr;
   hipStream_t s2 = ov2 ? m->side2 : st;
@@ -1322,7 +1355,8 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     const DecLayer& Ld = m->dec[li];
     float* bi = pts + (long)li * Mk * 2;
     float* lbias = m->d_bias;
-    if (ss.dec_bias) lbias = ss.dec_bias + li * (size_t)bs * nh * K * K;
+    if (!m->markov_bias) lbias = nullptr;   // (attn_bias=False / no Markov stack: plain self-attention with the key-padding mask)
+    else if (ss.dec_bias) lbias = ss.dec_bias + li * (size_t)bs * nh * K * K;
     else RUN(bias_mlp(attn_adj, Ld.m_w1, Ld.m_b1, Ld.m_w2, Ld.m_b2, m->d_bias, hops1, m->cfg.max_hops + nh, nh, bs, K, st));
     LayerIO io;
     io.x = dx; io.ldx = dx_ld; io.mem = mem; io.s_mem = s_tok;
@@ -1451,7 +1485,7 @@ static SupportState workspace_support(ec_model* m, const ec_outputs* out) {
   ss.sk = m->sk; ss.valid = m->valid; ss.kmask = m->kmask; ss.kmask_fixed = m->kmask_fixed; ss.adj1 = m->adj1;
   ss.adj_out = out->adj_dev;
   ss.attn_adj = out->attn_adj_dev ? out->attn_adj_dev : m->attn_adj;
-  ss.dec_bias = m->d_bias_all;
+  ss.dec_bias = m->markov_bias ? m->d_bias_all : nullptr;
   return ss;
 }
 
@@ -1722,26 +1756,28 @@ int ec_finalize(ec_handle m) {
   }
   if ((rc = make_lin(m, hp + "input_proj.weight", hp + "input_proj.bias", &m->input_proj, false))) return rc;
   if ((rc = make_lin(m, hp + "query_proj.weight", hp + "query_proj.bias", &m->query_proj, false))) return rc;
-  m->cur_h1 = m->head_mixed;   // the skeleton head's image projection, its two-way layers and the decoder layers: single-pass fp16
-  rc = make_lin(m, hp + "skeleton_head.image_project.weight", hp + "skeleton_head.image_project.bias", &m->image_project, false);
-  m->cur_h1 = false;
-  if (rc) return rc;
+  m->gt_skel = m->cfg.gt_skeleton != 0;
+  m->markov_bias = !m->gt_skel && m->cfg.no_attn_bias == 0;
   EC_REQUIRE(m->input_proj.K == C && m->query_proj.K == C, EC_ERR_ARG, "head in_channels must equal backbone width");
-  EC_REQUIRE(m->image_project.K == C && m->cfg.skel_ffn_dim == C, EC_ERR_ARG,
-             "skeleton_head.dim_feedforward must equal the backbone width (skeleton.py:40,92)");
-  {
+  if (!m->gt_skel) {   // (learn_skeleton=False never runs refine_features / predict_skeleton: their weights need not be there)
+    m->cur_h1 = m->head_mixed;   // the skeleton head's image projection, its two-way layers and the decoder layers: single-pass fp16
+    rc = make_lin(m, hp + "skeleton_head.image_project.weight", hp + "skeleton_head.image_project.bias", &m->image_project, false);
+    m->cur_h1 = false;
+    if (rc) return rc;
+    EC_REQUIRE(m->image_project.K == C && m->cfg.skel_ffn_dim == C, EC_ERR_ARG,
+               "skeleton_head.dim_feedforward must equal the backbone width (skeleton.py:40,92)");
     GET(zw, hp + "skeleton_head.zero_conv.weight"); GET(zb, hp + "skeleton_head.zero_conv.bias");
     m->zc_w = zw->dev; m->zc_b = zb->dev;
   }
   m->cur_h1 = m->head_mixed;
   struct H1Off { ec_model* m; ~H1Off() { m->cur_h1 = false; } } h1_off{m};   // (every early return below leaves the flag cleared)
-  m->skel.resize(m->cfg.skel_layers);
-  for (int i = 0; i < m->cfg.skel_layers; ++i)
+  m->skel.resize(m->gt_skel ? 0 : m->cfg.skel_layers);
+  for (int i = 0; i < (int)m->skel.size(); ++i)
     if ((rc = build_dec_layer(m, hp + "skeleton_head.skeleton_predictor." + std::to_string(i) + ".", false, true, pos_img, &m->skel[i])))
       return rc;
   m->dec.resize(m->cfg.dec_layers);
   for (int i = 0; i < m->cfg.dec_layers; ++i)
-    if ((rc = build_dec_layer(m, hp + "transformer.decoder.layers." + std::to_string(i) + ".", true, false, pos_img, &m->dec[i])))
+    if ((rc = build_dec_layer(m, hp + "transformer.decoder.layers." + std::to_string(i) + ".", true, false, pos_img, &m->dec[i], m->markov_bias)))
       return rc;
   {  // stack the decoder layers' K|V projections: W [nL*2E, d], table [HW, nL*2E]
     const int nL = m->cfg.dec_layers;
@@ -1838,7 +1874,7 @@ int ec_finalize(ec_handle m) {
   WS(d_att, Mk * E); WS(d_tmp, Mk * d); WS(d_qc, Mk * E); WS(d_kv, Mi * 2 * E * m->cfg.dec_layers); WS(d_y, Mk * 2 * Fd); WS(d_z, Mk * Fd);
   WS(d_hs, (size_t)m->cfg.dec_layers * Mk * d); WS(d_pts, (size_t)(m->cfg.dec_layers + 1) * Mk * 2); WS(d_k1, Mk * d); WS(d_k2, Mk * d); WS(d_k3, Mk * d); WS(d_k4, Mk * d);
 #undef WS
-  m->compact_mode = (m->head_chain && K <= 128) ? (getenv("EC_COMPACT") ? atoi(getenv("EC_COMPACT")) : 2) : 0;
+  m->compact_mode = (m->head_chain && K <= 128) ? (getenv("EC_COMPACT") ? atoi(getenv("EC_COMPACT")) : 1) : 0;
   if (m->compact_mode) {
     for (int which = 0; which < 2; ++which) {
       ec_model::RowPlan& pl = which ? m->plan_skel : m->plan_dec;
@@ -2077,7 +2113,7 @@ static int episodes_impl(ec_handle m, ec_support_t c, const float* const* img_s,
   SupportState ws;
   if (bs > 0) {
     ws = workspace_support(m, out);
-    ws.dec_bias = m->d_bias_all;   // recomputed from the gathered Markov stacks (before_dec below) rather than cached: 8 x the stack's bytes
+    // (the decoder's Markov bias is recomputed from the gathered stacks - before_dec below - rather than cached: 8 x the stack's bytes)
   }
   const int32_t *slots_v = slots, *slot_q_v = slot_q;
   auto scatter_a = [&](hipStream_t s2) -> int {   // support tokens + masks of the new episodes -> their slots
@@ -2104,7 +2140,7 @@ static int episodes_impl(ec_handle m, ec_support_t c, const float* const* img_s,
     x.add(ws.adj1, cs.adj1, KK * 4); x.add(ws.adj_out, cs.adj_out, 2 * KK * 4);
     x.add(ws.attn_adj, cs.attn_adj, KK * 4, hops1, (long)bs * KK * 4, (long)c->cap * KK * 4);
     RUN(rows_xfer(x, slot_q_v, bs, false, s2));
-    return decoder_bias_all(m, ws.attn_adj, ws.dec_bias, bs, s2);
+    return m->markov_bias ? decoder_bias_all(m, ws.attn_adj, ws.dec_bias, bs, s2) : 0;
   };
   auto mark_filled = [&]() { for (int i = 0; i < n_new; ++i) c->filled[slots[i]] = 1; };
 

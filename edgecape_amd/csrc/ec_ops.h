@@ -98,6 +98,8 @@ int adj_build(const int32_t* edges, const int32_t* offsets, const float* mask_s,
 // A sample WITHOUT a valid token keeps token 0 as a row of its own: its key 0 is un-masked (encoder_decoder.py:359-360, skeleton.py:98-99)
 // and sees a different attention bias than the other masked tokens do.
 int rowplan(const float* mask_s, int bs, int ns, int K, int* plan, int* rowmap, int* fan_base, unsigned long long* fan_bits, hipStream_t st);
+// skeleton.py:70-74 (learn_skeleton=False): adj_out [bs,2,K,K] = stack(diag(valid), adj_r1), adj1 = adj_r1
+int adj_gt(const float* adj_r1, const float* valid, float* adj_out, float* adj1, int bs, int K, hipStream_t st);
 int rownorm(const float* x, float* y, int rows, int cols, hipStream_t st);
 // skeleton.py:134-161 — combine cosine similarity with the prior, soft-normalise, Markov matrix
 int adj_combine(const float* P, const float* binary, const float* valid, const float* zc_w, const float* zc_b,

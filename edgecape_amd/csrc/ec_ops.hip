@@ -507,6 +507,18 @@ __global__ __launch_bounds__(1024) void rowplan_kernel(const float* mask_s, int 
   }
 }
 
+// SkeletonPredictor(learn_skeleton=False): adj = stack(diag(valid), normalised ground-truth adjacency) (skeleton.py:70-74, 187-194)
+__global__ __launch_bounds__(256) void adj_gt_kernel(const float* adj_r1, const float* valid, float* adj_out, float* adj1, int K) {
+  const int b = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= K * K) return;
+  const int i = idx / K, j = idx - i * K;
+  const long KK = (long)K * K;
+  const float a = adj_r1[b * KK + idx];
+  adj1[b * KK + idx] = a;
+  adj_out[b * 2 * KK + KK + idx] = a;
+  adj_out[b * 2 * KK + idx] = i == j ? valid[(long)b * K + i] : 0.f;
+}
+
 __global__ __launch_bounds__(256) void rownorm_kernel(const float* x, float* y, int rows, int cols) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1046,6 +1058,12 @@ int adj_build(const int32_t* edges, const int32_t* offsets, const float* mask_s,
 int rowplan(const float* mask_s, int bs, int ns, int K, int* plan, int* rowmap, int* fan_base, unsigned long long* fan_bits, hipStream_t st) {
   EC_REQUIRE(K >= 1 && K <= 128 && ns >= 1 && ns <= 8192 && bs >= 1, -1, "rowplan: K <= 128, samples <= 8192");
   hipLaunchKernelGGL(rowplan_kernel, dim3(1), dim3(1024), (size_t)ns * 2 * sizeof(int), st, mask_s, bs, ns, K, plan, rowmap, fan_base, fan_bits);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
+int adj_gt(const float* adj_r1, const float* valid, float* adj_out, float* adj1, int bs, int K, hipStream_t st) {
+  hipLaunchKernelGGL(adj_gt_kernel, dim3(cdiv((long)K * K, 256), bs), dim3(256), 0, st, adj_r1, valid, adj_out, adj1, K);
   EC_LAUNCH_CHECK();
   return 0;
 }

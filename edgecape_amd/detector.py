@@ -96,7 +96,8 @@ class EdgeCape:
                         skel_ffn_dim=self.keypoint_head_module.skeleton_head.dim_feedforward,
                         backbone_precision=self.backbone_precision, head_precision=self.head_precision,
                         enc_layers=th.num_encoder_layers, dec_layers=th.num_decoder_layers,
-                        skel_layers=self.keypoint_head_module.skeleton_head.num_layers, max_hops=th.max_hops)
+                        skel_layers=self.keypoint_head_module.skeleton_head.num_layers, max_hops=th.max_hops if th.attn_bias else 4,
+                        learn_skeleton=self.keypoint_head_module.skeleton_head.learn_skeleton, attn_bias=th.attn_bias)
         self._engines[(image_size, mb, shots, K)] = eng
         return eng
 

@@ -80,7 +80,7 @@ class SupportCache:
 class HipEngine:
     def __init__(self, state_dict, arch="dinov2_vits14", image_size=224, max_batch=2, max_shots=1, num_kpts=100,
                  ffn_dim=384, skel_ffn_dim=None, backbone_precision="fp32", head_precision="fp32", heatmap_size=64,
-                 d_model=256, nhead=8, enc_layers=3, dec_layers=3, skel_layers=3, max_hops=4):
+                 d_model=256, nhead=8, enc_layers=3, dec_layers=3, skel_layers=3, max_hops=4, learn_skeleton=True, attn_bias=True):
         if not torch.cuda.is_available():
             raise _lib.EdgeCapeHipError("no MI355X / HIP device visible: the EdgeCape hot path has no CPU fallback")
         self.lib = _lib.load()
@@ -100,7 +100,9 @@ class HipEngine:
                             num_kpts=num_kpts, d_model=d_model, nhead=nhead, enc_layers=enc_layers, dec_layers=dec_layers,
                             skel_layers=skel_layers, ffn_dim=ffn_dim, skel_ffn_dim=skel_ffn_dim or a["C"], max_hops=max_hops,
                             heatmap_size=heatmap_size, max_shots=max_shots, max_batch=max_batch,
-                            backbone_precision=prec[backbone_precision], head_precision=prec[head_precision])
+                            backbone_precision=prec[backbone_precision], head_precision=prec[head_precision],
+                            gt_skeleton=0 if learn_skeleton else 1, no_attn_bias=0 if attn_bias else 1)
+        self.learn_skeleton, self.attn_bias = bool(learn_skeleton), bool(attn_bias)
         self.backbone_precision, self.head_precision = backbone_precision, head_precision
         h = C.c_void_p()
         _lib.check(self.lib.ec_create(C.byref(cfg), C.byref(h)))

@@ -43,8 +43,9 @@ class TwoStageSupportRefineTransformer:
         if d_model != 256 or nhead != 8: unsupported.append("d_model/nhead != 256/8")
         if normalize_before: unsupported.append("normalize_before=True")
         if not return_intermediate_dec: unsupported.append("return_intermediate_dec=False")
-        if not (attn_bias and use_bias_attn_module): unsupported.append("attn_bias / use_bias_attn_module = False")
-        if max_hops != 4: unsupported.append("max_hops != 4")
+        # attn_bias=False (stage-1 / stage-2 models of run.py:44-88): the decoder layers' self-attention adds no Markov bias - plain
+        # nn.MultiheadAttention, or BiasedMultiheadAttention(bias_attn=False) with use_bias_attn_module (encoder_decoder.py:551-560)
+        if attn_bias and max_hops != 4: unsupported.append("max_hops != 4")
         if similarity_proj_dim != 256 or dynamic_proj_dim > 128: unsupported.append("proposal generator dims")
         if unsupported:
             raise NotImplementedError("HIP path implements the shipped test configs only: " + ", ".join(unsupported))
@@ -59,8 +60,9 @@ class SkeletonPredictor:
                  mask_res=False, use_zero_conv=True, max_hops=4, two_way_attn=True, gcn_norm=False):
         self.d_model, self.nhead, self.num_layers, self.dim_feedforward = d_model, nhead, num_layers, dim_feedforward
         self.learn_skeleton, self.max_hop = learn_skeleton, max_hop
-        if not (learn_skeleton and adj_normalization and use_zero_conv and two_way_attn) or mask_res or gcn_norm \
-                or activation != "relu" or normalize_before:
+        # learn_skeleton=False (skeleton.py:70-74): the normalised ground-truth adjacency, none of the layers below runs
+        if learn_skeleton and (not (adj_normalization and use_zero_conv and two_way_attn) or mask_res or gcn_norm
+                               or activation != "relu" or normalize_before):
             raise NotImplementedError("HIP path implements SkeletonPredictor(learn_skeleton=True) with default flags only")
 
     def init_weights(self):

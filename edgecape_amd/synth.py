@@ -375,3 +375,15 @@ def make_head_inputs(bs, shots, C, g, seed, n_kps, skeletons="auto", K=100, imag
         else:
             skel.append(list(skeletons[i]))
     return dict(feature_q=feature_q, feature_s=feature_s, target_s=target_s, mask_s=mask_s, skeleton=skel)
+
+
+def as_stage_checkpoint(sd):
+    """The keys a checkpoint of an EARLIER training stage of the reference carries (run.py:44-88: decoder self-attention =
+    nn.MultiheadAttention): every decoder self_attn.{q,k,v}_proj fused into in_proj_{weight,bias}, no markov_structural_mlp."""
+    out = {k: v for k, v in sd.items() if "markov_structural_mlp" not in k}
+    for k in list(out):
+        if ".transformer.decoder.layers." in k and k.endswith("self_attn.q_proj.weight"):
+            base = k[:-len("q_proj.weight")]
+            for kind, fused in (("weight", "in_proj_weight"), ("bias", "in_proj_bias")):
+                out[base + fused] = np.concatenate([out.pop(base + f"{n}_proj.{kind}") for n in "qkv"], 0)
+    return out

@@ -90,6 +90,12 @@ typedef struct ec_config {
   int32_t head_precision;     /* EC_F32, EC_BF16X3 or EC_MIXED: GEMM operand handling in the head (LayerNorm / softmax statistics stay fp32) */
   int32_t image_width;        /* input WIDTH; 0 = square (image_size).  The reference takes any img.shape[-2:] (EdgeCape.py:143); token
                                  grid columns gw = image_width / patch.  (ABI version 4) */
+  /* (ABI version 5) the model variants of the reference's three training stages (run.py:44-101); 0 / 0 = the shipped test configs */
+  int32_t gt_skeleton;        /* 1: SkeletonPredictor(learn_skeleton=False): adj = the normalised ground-truth adjacency of the skeleton
+                                 edges, no SkeletonPredictor layers, no Markov stack (skeleton.py:70-74; attn_adj_dev is not written) */
+  int32_t no_attn_bias;       /* 1: the decoder layers' self-attention adds no Markov bias (transformer attn_bias=False: nn.MultiheadAttention,
+                                 encoder_decoder.py:551-560, 605-612 - its fused in_proj keys are loaded as q / k / v_proj; implied by
+                                 gt_skeleton: bias_attn.py:188 skips the bias when there is no stack) */
 } ec_config;
 
 typedef struct ec_outputs {

@@ -388,8 +388,10 @@ def token_mlp(w, x):
     return F.linear(x, w("mlp.6.weight"), w("mlp.6.bias"))
 
 
-def decoder(w, kpt_w, support, mem, pos_cat, kp_mask, initial_proposals, adj, attn_adj, nhead=8, taps=None):
-    """TransformerDecoder.forward (:330-425)."""
+def decoder(w, kpt_w, support, mem, pos_cat, kp_mask, initial_proposals, adj, attn_adj, nhead=8, taps=None, attn_bias=True):
+    """TransformerDecoder.forward (:330-425).  attn_bias=False: the layers' self-attention is nn.MultiheadAttention (fused in_proj keys,
+    encoder_decoder.py:551-560, 605-612: the stage-1 / stage-2 models of run.py:44-88); with BiasedMultiheadAttention and attn_adj = None
+    (learn_skeleton=False) no bias is added either (bias_attn.py:188)."""
     d = support.shape[-1]
     x = support
     bi = initial_proposals
@@ -403,8 +405,13 @@ def decoder(w, kpt_w, support, mem, pos_cat, kp_mask, initial_proposals, adj, at
         rp = w.sub("ref_point_head.")
         qpe = F.linear(F.gelu(F.linear(qpe, rp("layers.0.weight"), rp("layers.0.bias"))),
                        rp("layers.1.weight"), rp("layers.1.bias"))
-        x, mem = decoder_layer(w.sub(f"layers.{li}."), x, mem, m, mem_mask, pos_cat, qpe, adj, attn_adj,
-                               nhead, biased=True, two_way=False)
+        lw = w.sub(f"layers.{li}.")
+        if attn_bias and attn_adj is not None:
+            x, mem = decoder_layer(lw, x, mem, m, mem_mask, pos_cat, qpe, adj, attn_adj, nhead, biased=True, two_way=False)
+        elif attn_bias:   # BiasedMultiheadAttention without a Markov stack: q/k/v_proj keys, no bias term
+            x, mem = decoder_layer(_FusedView(lw), x, mem, m, mem_mask, pos_cat, qpe, adj, None, nhead, biased=False, two_way=False)
+        else:
+            x, mem = decoder_layer(lw, x, mem, m, mem_mask, pos_cat, qpe, adj, None, nhead, biased=False, two_way=False)
         inter.append(F.layer_norm(x, (d,), w("norm.weight"), w("norm.bias")))
         delta = token_mlp(kpt_w[li], x.transpose(0, 1))
         bi = (inverse_sigmoid(bi) + delta).sigmoid()
@@ -415,7 +422,33 @@ def decoder(w, kpt_w, support, mem, pos_cat, kp_mask, initial_proposals, adj, at
 # --------------------------------------------------------------------------------------
 # Head: EdgeCape/models/keypoint_heads/head.py:161-222
 # --------------------------------------------------------------------------------------
-def head_forward(sd, feature_q, feature_s, target_s, mask_s, skeleton, prefix="keypoint_head_module.", taps=None):
+class _FusedView:
+    """A decoder layer's weights with self_attn.{q,k,v}_proj presented as the fused in_proj_{weight,bias} that mha_fused reads."""
+
+    def __init__(self, w):
+        self.w = w
+
+    def __call__(self, name):
+        return self.w(name)
+
+    def sub(self, p):
+        inner = self.w.sub(p)
+        if p != "self_attn.":
+            return inner
+
+        def get(name):
+            if name == "in_proj_weight":
+                return torch.cat([inner("q_proj.weight"), inner("k_proj.weight"), inner("v_proj.weight")], 0)
+            if name == "in_proj_bias":
+                return torch.cat([inner("q_proj.bias"), inner("k_proj.bias"), inner("v_proj.bias")], 0)
+            return inner(name)
+        return get
+
+
+def head_forward(sd, feature_q, feature_s, target_s, mask_s, skeleton, prefix="keypoint_head_module.", taps=None,
+                 learn_skeleton=True, attn_bias=True):
+    """learn_skeleton=False: SkeletonPredictor returns the normalised ground-truth adjacency and no Markov stack (skeleton.py:73-74);
+    attn_bias: see decoder()."""
     w = W(sd, prefix)
     feature_q, mask_s = _t(feature_q), _t(mask_s)
     feature_s = [_t(f) for f in feature_s]
@@ -437,7 +470,11 @@ def head_forward(sd, feature_q, feature_s, target_s, mask_s, skeleton, prefix="k
     K = sk.shape[1]
     if taps is not None:
         taps["support_keypoints"] = sk.clone()
-    adj, attn_adj, unnorm = skeleton_head(w.sub("skeleton_head."), skeleton, sk, feature_s, kp_mask, pos_img, taps=taps)
+    if learn_skeleton:
+        adj, attn_adj, unnorm = skeleton_head(w.sub("skeleton_head."), skeleton, sk, feature_s, kp_mask, pos_img, taps=taps)
+    else:
+        adj = adj_from_edges(skeleton, K, kp_mask)
+        attn_adj, unnorm = None, adj[:, 1] > 0
     # TwoStageSupportRefineTransformer.forward (encoder_decoder.py:183-260)
     tw = w.sub("transformer.")
     src = fq.flatten(2).permute(2, 0, 1)
@@ -447,7 +484,7 @@ def head_forward(sd, feature_q, feature_s, target_s, mask_s, skeleton, prefix="k
         taps["enc_img"], taps["enc_kp"] = mem.clone(), kp.clone()
     prop_loss, sim, prop = proposal_generator(tw.sub("proposal_generator."), mem, kp, h, wd)
     kpt_w = [w.sub(f"kpt_branch.{i}.") for i in range(3)]
-    hs, points = decoder(tw.sub("decoder."), kpt_w, kp, mem, pos_cat, kp_mask, prop, adj, attn_adj, taps=taps)
+    hs, points = decoder(tw.sub("decoder."), kpt_w, kp, mem, pos_cat, kp_mask, prop, adj, attn_adj, taps=taps, attn_bias=attn_bias)
     hs = hs.transpose(1, 2)  # [3, bs, K, d]
     outs = []
     for i in range(3):
@@ -504,7 +541,7 @@ def decode(img_metas, output, img_size):
     return dict(preds=all_preds, boxes=all_boxes, image_paths=paths, bbox_ids=ids)
 
 
-def forward_test(sd, batch, heads, taps=None, pos_table=None):
+def forward_test(sd, batch, heads, taps=None, pos_table=None, learn_skeleton=True, attn_bias=True):
     """EdgeCape.forward_test (EdgeCape.py:131-163) on a `synth.make_pairs`-style batch."""
     with torch.no_grad():
         img_q = _t(batch["img_q"])
@@ -514,7 +551,7 @@ def forward_test(sd, batch, heads, taps=None, pos_table=None):
         fq = dinov2_features(sd, img_q, heads, taps=taps, pos_table=pos_table)
         fs = [dinov2_features(sd, im, heads, pos_table=pos_table) for im in batch["img_s"]]
         skeleton = [m["sample_skeleton"][0] for m in batch["img_metas"]]
-        out = head_forward(sd, fq, fs, batch["target_s"], mask_s, skeleton, taps=taps)
+        out = head_forward(sd, fq, fs, batch["target_s"], mask_s, skeleton, taps=taps, learn_skeleton=learn_skeleton, attn_bias=attn_bias)
         out["feature_q"], out["feature_s"] = fq, fs
     H, Wd = img_q.shape[-2:]
     res = decode(batch["img_metas"], out["output_kpts"][-1].numpy(), [Wd, H])

@@ -51,6 +51,28 @@ def test_head_matches_reference(name):
     assert sim_err <= 1e-5 * max(1.0, scale), f"{name}: similarity_map err {sim_err} (scale {scale})"
 
 
+@pytest.mark.parametrize("name", ["head_stage1_c384_g16", "head_stage2_c384_g16_s2"])
+def test_head_variants_match_reference(name):
+    """The reference head of training stages 1 and 2 (run.py:44-88; built by oracle/make_golden.py --round5 from
+    configs/train/1shot_split1.py): SkeletonPredictor(learn_skeleton=False) -> the normalised ground-truth adjacency, and decoder
+    layers whose self-attention is nn.MultiheadAttention without the Markov bias (encoder_decoder.py:551-560, 605-612)."""
+    gold, meta = load_golden(name)
+    sd = synth.as_stage_checkpoint(synth.make_head_weights(C=meta["C"], seed=meta["weight_seed"]))
+    inp = synth.make_head_inputs(len(meta["n_kps"]), meta["shots"], meta["C"], meta["g"], meta["input_seed"], meta["n_kps"], meta["skeletons"])
+    with torch.no_grad():
+        out = orc.head_forward(sd, inp["feature_q"], inp["feature_s"], inp["target_s"], inp["mask_s"], inp["skeleton"],
+                               learn_skeleton=meta["learn_skeleton"], attn_bias=meta["attn_bias"])
+    for k in ("adj", "initial_proposals", "out_points", "output_kpts"):
+        err = np.abs(out[k].numpy() - gold[k]).max()
+        assert err <= (3e-5 if k == "initial_proposals" else TOL), f"{name}:{k} max abs err {err}"
+    assert np.abs(out["similarity_map"].numpy() - gold["similarity_map"]).max() <= 1e-5 * max(1.0, np.abs(gold["similarity_map"]).max())
+    assert (out["attn_adj"] is None) == (not meta["learn_skeleton"])
+    if not meta["learn_skeleton"]:      # ground-truth adjacency: rows of valid keypoints sum to one (or are empty), padded rows / columns zero
+        for b, nk in enumerate(meta["n_kps"]):
+            rs = gold["adj"][b, 1].sum(-1)
+            assert np.all((np.abs(rs[:nk] - 1) < 1e-6) | (rs[:nk] == 0)) and np.all(gold["adj"][b, 1][nk:] == 0)
+
+
 @pytest.mark.parametrize("name", HEAD)
 def test_structural_invariants(name):
     """invariants derivable from the reference alone."""

@@ -37,18 +37,27 @@ def test_reference_config_builds_unchanged(path):
 
 
 @pytest.mark.parametrize("path", TRAIN, ids=[os.path.relpath(p, REF) for p in TRAIN])
-def test_train_configs_parse_and_are_refused_cleanly(path):
-    """Training is out of scope: the train configs still parse; the stage-1 variants (no bias attention) are refused
-    with a clear error instead of being silently mis-evaluated."""
+def test_train_configs_build_their_inference_model(path):
+    """Training is out of scope, evaluating a checkpoint of any training stage is not: the train configs describe the
+    stage-1 model of run.py:44-101 (SkeletonPredictor(learn_skeleton=False), decoder self-attention without the Markov bias) and
+    build unchanged (round 5; rounds 1-4 refused them); train() itself is refused."""
     from edgecape_amd import Config, build_posenet
     cfg = Config.fromfile(path)
     assert cfg.model.type == "EdgeCape" and "optimizer" in cfg
-    th = cfg.model.keypoint_head.transformer
-    if th.get("attn_bias", False) and th.get("use_bias_attn_module", False):
-        build_posenet(cfg.model)
-    else:
-        with pytest.raises(NotImplementedError):
-            build_posenet(cfg.model)
+    model = build_posenet(cfg.model)
+    th, sk = model.keypoint_head_module.transformer, model.keypoint_head_module.skeleton_head
+    assert th.attn_bias is False and sk.learn_skeleton is False                 # what the engine is then built with (detector._engine)
+    with pytest.raises(NotImplementedError):
+        model.train()
+    # the later stages as run.py derives them from the same file (run.py:67-72, 93-96)
+    cfg.merge_from_dict({"model.keypoint_head.skeleton_head.learn_skeleton": True, "model.keypoint_head.learn_skeleton": True,
+                         "model.keypoint_head.masked_supervision": True})
+    m2 = build_posenet(cfg.model)
+    assert m2.keypoint_head_module.skeleton_head.learn_skeleton is True and m2.keypoint_head_module.transformer.attn_bias is False
+    cfg.merge_from_dict({"model.keypoint_head.transformer.use_bias_attn_module": True, "model.keypoint_head.transformer.attn_bias": True,
+                         "model.keypoint_head.transformer.max_hops": 4, "model.keypoint_head.model_freeze": "skeleton"})
+    m3 = build_posenet(cfg.model)
+    assert m3.keypoint_head_module.transformer.attn_bias is True
 
 
 def test_unknown_registry_name_raises():
