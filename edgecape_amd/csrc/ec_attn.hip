@@ -218,14 +218,15 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnP p) {
   // and every one of them pulled that head's K / V through its own L2 (FETCH_SIZE: exactly 7/3 of the Q|K|V bytes at three query
   // blocks, profiles/r04_qkv_gemm_pmc_kernels.csv).  1-D launch; id L -> xcd = L % 8, slot = L / 8; the nqb query blocks of an item
   // take consecutive slots of ONE xcd: item = (slot / nqb) * 8 + xcd, query block = slot % nqb.  Bijective on the first
-  // (items / 8) * 8 * nqb ids; the at most seven items left over keep the plain order.
+  // (items / 8) * 8 * nqb ids; the at most seven items left over keep the plain order.  Measured (cfg2: 3 query blocks x 12 heads x 64
+  // images, T = 325; profiles/r05_attn_xcd_ab.txt, the plain order behind a switch that is gone again): FETCH_SIZE x 2 223.7 -> 95.9 MB
+  // per launch (2.33 x -> 1.00 x the Q|K|V bytes), 48.9 -> 46.0 us in the model trace (47.1 -> 44.7 us in the counter runs): the re-read is
+  // gone and the time moved by 6 % - what binds is the vector pipe (32 v_exp_f32 per lane and key tile at quarter rate, see below).
   int item, qb;
   {
     const int nqb = (p.Lq + 127) >> 7, NI = p.H * p.B, L = blockIdx.x;
     const int Gm = (NI >> 3) * 8 * nqb;
-    if (p.plain_map) {
-      item = L / nqb; qb = L - item * nqb;
-    } else if (L < Gm) {
+    if (L < Gm) {
       const int slot = L >> 3, grp = slot / nqb;
       item = grp * 8 + (L & 7); qb = slot - grp * nqb;
     } else {
@@ -775,11 +776,8 @@ int attention(const AttnP& p, hipStream_t st) {
       return 0;
     }
     EC_REQUIRE((long)p.Lk * p.ldk * 2 < (1l << 31) && (long)p.Lk * p.ldv * 2 < (1l << 31), -1, "attention(bf16): K / V rows of one head beyond 2 GiB");
-    static const bool plain = getenv("EC_ATTN_PLAIN") && atoi(getenv("EC_ATTN_PLAIN")) != 0;   // A/B switch of the round-5 measurement
-    AttnP q = p;
-    q.plain_map = plain ? 1 : 0;
-    if (p.f16) hipLaunchKernelGGL((attn_bf16_kernel<false, true>), dim3(grid.x * grid.y * grid.z), dim3(256), A16_LDS, st, q);
-    else hipLaunchKernelGGL((attn_bf16_kernel<false, false>), dim3(grid.x * grid.y * grid.z), dim3(256), A16_LDS, st, q);
+    if (p.f16) hipLaunchKernelGGL((attn_bf16_kernel<false, true>), dim3(grid.x * grid.y * grid.z), dim3(256), A16_LDS, st, p);
+    else hipLaunchKernelGGL((attn_bf16_kernel<false, false>), dim3(grid.x * grid.y * grid.z), dim3(256), A16_LDS, st, p);
     EC_LAUNCH_CHECK();
     return 0;
   }

@@ -253,7 +253,6 @@ struct AttnP {
   int split = 0;                                // fp32 data, bf16x3 MFMAs (head throughput mode)
   int one = 0;                                  // split mode only: ONE fp16 MFMA per product instead of three bf16 ones (mixed head, see ec_attn.hip)
   int kv16 = 0;                                 // split mode only: K and V are IEEE fp16 (ldk / ldv / sK / sV in fp16 elements), Q and O fp32
-  int plain_map = 0;                            // 16-bit kernel: plain (query block, head, image) workgroup order instead of the XCD-aware one (A/B only)
 };
 int attention(const AttnP& p, hipStream_t st);
 

@@ -82,6 +82,8 @@ enum { G8_GENERIC = 0, G8_BIAS_BF16 = 1, G8_SCALE_BF16 = 2, G8_GELU_BF16 = 3, G8
 // Cost per element: 5 (3) v_fma + v_exp + v_max + v_fma = 7 (5) full-rate and ONE quarter-rate instruction; the old form was 8 (6)
 // full-rate and TWO quarter-rate ones (v_exp + v_rcp = 16 of its ~34 cycles; measured and rejected in round 3: a degree-2 polynomial,
 // packed-fp16 polynomials - both kept the two transcendentals).  |x| and -|x| are source modifiers, NaN goes through the last fma.
+// The limits hold for FINITE x; an infinite accumulator (an fp32 overflow, or an infinite activation) comes out as NaN for either
+// sign: q = -inf, 2^q = 0 and -|x| * 0 = NaN (the exact GELU would give +inf / -0).  Pinned by test_linear_h16_fp16_nan_in_nan_out.
 template <bool F16>
 __device__ __forceinline__ float gelu_fast8(float x) {
   const float a = fabsf(x);
@@ -669,7 +671,17 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
     // ---- epilogue at the end of the tile.  Both groups run it concurrently: group 0 passes the tile's last barrier first.
     if (it < 9) stamp(2 + 3 * it);
     if (wr == 0) G8_BAR();
-    if constexpr (F16) fp16_ovfl_mode<1>();   // fp16 outputs saturate at +-65504 in the conversion itself (pack4_h_ovfl; ec_common.h)
+    if constexpr (F16) {
+      // fp16 outputs saturate at +-65504 in the conversion itself (pack4_h_ovfl; ec_common.h).  The mode bit is not confined to
+      // conversions (see fp16_ovfl_mode), so it must not flip under MFMAs still in flight: group 1 has no barrier between the tile's
+      // last MFMA block (phase 3: acc[4..7][0..1]) and this point - a VALU read of that block's last accumulator waits for it (the matrix
+      // pipe retires in order), and the scheduling barriers keep the conversions of the pieces behind the switch
+      G8_SB();
+      asm volatile("v_mov_b32 %0, %0" : "+v"(acc[7][1][3]));
+      G8_SB();
+      fp16_ovfl_mode<1>();
+      G8_SB();
+    }
     if constexpr (KIND == G8_GENERIC) {
       g8_epilogue_generic<F16>(p, acc, m0, n0, wr, wc, lane);
 #pragma unroll
@@ -681,7 +693,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
       const int m0s = (LAB & 1024) ? 0 : m0;
       pieces(0, m0s, n0, it & 1); pieces(2, m0s, n0, it & 1); pieces(4, m0s, n0, it & 1); pieces(6, m0s, n0, it & 1);
     }
-    if constexpr (F16) fp16_ovfl_mode<0>();
+    if constexpr (F16) { G8_SB(); fp16_ovfl_mode<0>(); G8_SB(); }
     if (it < 9) stamp(3 + 3 * it);
     if (wr == 1) G8_BAR();
   }

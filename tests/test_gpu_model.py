@@ -438,8 +438,8 @@ def test_support_cache_matches_pairwise_forward(shots):
 
 # Switches of different subsystems share a run (each alternative path is still exercised; a failing pair is bisected by hand): the
 # matrix is ~30 s of GPU-box time per entry.
-@pytest.mark.parametrize("switch", ["EC_CHAIN=0 EC_G8_DYN=1", "EC_OVERLAP=0 EC_DEC_PRE=0", "EC_OVERLAP=1 EC_G8_TAB=0",
-                                    "EC_KPT_CHAIN=0 EC_PATCH_X3=0 EC_ENC_CHAIN=0 EC_G8_DYN=0", "EC_GEMM8_OFF=1 EC_COMPACT=2", "EC_PIPE_FULL=0 EC_COMPACT=0"])
+@pytest.mark.parametrize("switch", ["EC_CHAIN=0 EC_G8_DYN=1 EC_G8_TAB=0", "EC_OVERLAP=0 EC_DEC_PRE=0 EC_COMPACT=2",
+                                    "EC_OVERLAP=1 EC_PIPE_FULL=0 EC_COMPACT=0 EC_PATCH_X3=0", "EC_KPT_CHAIN=0 EC_ENC_CHAIN=0 EC_G8_DYN=0 EC_GEMM8_OFF=1"])
 def test_runtime_switch_matrix(switch):
     """Every A/B switch that keeps an alternative code path alive in the shipped library (README "Runtime switches") through the
     reference-generated golden vectors of the head and the detector + the cfg2 precision gate: a switch is read once per process, so
@@ -449,7 +449,8 @@ def test_runtime_switch_matrix(switch):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, **dict(kv.split("=") for kv in switch.split()))
-    sel = "reference_golden or (headline_mode_fp16_mixed_head and cfg2) or (forward_pipelined_bit_equal and 224-4) or support_cache_matches"
+    sel = ("reference_golden or (headline_mode_fp16_mixed_head and cfg2) or (forward_pipelined_bit_equal and 224-4) or support_cache_matches "
+           "or (episodes_stream and fp16)")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_model.py"), os.path.join(here, "test_gpu_precision_modes.py"),
                         os.path.join(here, "test_gpu_next_rows.py"), "-q", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -320,6 +320,7 @@ def test_linear_h16_fp16_nan_in_nan_out(lib, kind):
     A = torch.randn(M, K, generator=g)
     A[77, 5] = float("nan")
     A[1500, 200] = float("nan")
+    A[300, 7] = float("inf")          #  an infinite activation: one infinite product per output, the accumulator is +-inf
     W = torch.randn(N, K, generator=g)
     b = torch.randn(N, generator=g)
     gam = (torch.rand(N, generator=g) + 0.5) if kind == "scale" else None
@@ -329,8 +330,12 @@ def test_linear_h16_fp16_nan_in_nan_out(lib, kind):
     torch.cuda.synchronize()
     got = buf.view(M, N)
     nan_rows = torch.isnan(got).all(dim=1).nonzero().flatten().tolist()
-    assert nan_rows == [77, 1500], nan_rows
-    assert int(torch.isnan(got).any(dim=1).sum().item()) == 2
+    # an infinite activation becomes NaN where the operands are rounded to fp16 (sat_h16: finite -> clamp, NaN / +-inf -> NaN, ec_common.h),
+    # so its row is NaN in every output kind; an accumulator that overflows to +-inf inside the GEMM keeps the infinity through the
+    # bias / LayerScale epilogues and becomes NaN in the GELU one (gelu_fast8: -|x| * 2^(-inf) = inf * 0)
+    assert nan_rows == [77, 300, 1500], nan_rows
+    assert int(torch.isnan(got).any(dim=1).sum().item()) == 3
+    assert bool(torch.isfinite(got[[0, 299, 301, M - 1]]).all())
 
 
 @pytest.mark.parametrize("prec", [1, 3])
