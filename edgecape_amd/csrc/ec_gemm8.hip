@@ -770,6 +770,10 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
     if (p.N > 16384) kind = G8_GENERIC; else q.bias = ds.zeros;
   }
   if (ntiles <= grid || grid < 8 || p.K < 256 || (kind != G8_BIAS_BF16 && kind != G8_GELU_BF16)) q.sched = nullptr;   // one tile per workgroup: nothing to deal out (K >= 256: the hand-over spans three K-tiles)
+  // (round 5 experiment, A/B only) the multi-round GEMMs of a PIPELINED call - the ones that take their tiles from the dynamic schedule -
+  // on ncu - R workgroups: R CUs stay free for the previous call's head, which otherwise holds whole CUs the persistent workgroups need
+  static const int reserve = getenv("EC_G8_RESERVE") ? atoi(getenv("EC_G8_RESERVE")) : 0;
+  if (q.sched && reserve > 0 && grid == ds.ncu && grid - reserve >= 64) grid -= reserve;
   hipLaunchKernelGGL(table[p.h_f16 ? 1 : 0][kind][p.tag], dim3((unsigned)grid), dim3(512), G8_LDS, st, q);
   EC_LAUNCH_CHECK();
   return 1;

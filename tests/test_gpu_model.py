@@ -436,22 +436,47 @@ def test_support_cache_matches_pairwise_forward(shots):
         eng.forward_cached(qry["img_q"], cache, np.full(8, 3, np.int32))     # episode index out of range
 
 
-# Switches of different subsystems share a run (each alternative path is still exercised; a failing pair is bisected by hand): the
-# matrix is ~30 s of GPU-box time per entry.
-@pytest.mark.parametrize("switch", ["EC_CHAIN=0 EC_G8_DYN=1 EC_G8_TAB=0", "EC_OVERLAP=0 EC_DEC_PRE=0 EC_COMPACT=2",
-                                    "EC_OVERLAP=1 EC_PIPE_FULL=0 EC_COMPACT=0 EC_PATCH_X3=0", "EC_KPT_CHAIN=0 EC_ENC_CHAIN=0 EC_G8_DYN=0 EC_GEMM8_OFF=1"])
-def test_runtime_switch_matrix(switch):
-    """Every A/B switch that keeps an alternative code path alive in the shipped library (README "Runtime switches") through the
-    reference-generated golden vectors of the head and the detector + the cfg2 precision gate: a switch is read once per process, so
-    each runs in a child process."""
+# Switches of different subsystems share a run (each alternative path is still exercised; a failing group is bisected by hand), and the
+# four child processes run SIDE BY SIDE on the one GPU (round 5: ~35 s each - mostly interpreter start-up, engine builds and the host side of
+# small tests - were 6 x 35 s in a row, a third of the suite).
+SWITCHES = ["EC_CHAIN=0 EC_G8_DYN=1 EC_G8_TAB=0", "EC_OVERLAP=0 EC_DEC_PRE=0 EC_COMPACT=2",
+            "EC_OVERLAP=1 EC_PIPE_FULL=0 EC_COMPACT=0 EC_PATCH_X3=0", "EC_KPT_CHAIN=0 EC_ENC_CHAIN=0 EC_G8_DYN=0 EC_GEMM8_OFF=1"]
+
+
+@pytest.fixture(scope="module")
+def switch_children():
     import os
     import subprocess
     import sys
+    import tempfile
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, **dict(kv.split("=") for kv in switch.split()))
-    sel = ("reference_golden or (headline_mode_fp16_mixed_head and cfg2) or (forward_pipelined_bit_equal and 224-4) or support_cache_matches "
-           "or (episodes_stream and fp16)")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_model.py"), os.path.join(here, "test_gpu_precision_modes.py"),
-                        os.path.join(here, "test_gpu_next_rows.py"), "-q", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
+    sys.path.insert(0, here)
+    import test_gpu_precision_modes as tpm
+    tpm._case("cfg2")          # the oracle's answer for the one oracle-checked test of the children: computed once, read from the cache by all
+    sel = ("head_vs_reference_golden or forward_test_vs_reference_golden or (headline_mode_fp16_mixed_head and cfg2) or "
+           "(forward_pipelined_bit_equal and 224-4) or support_cache_matches or (episodes_stream and fp16)")
+    procs = {}
+    for sw in SWITCHES:
+        env = dict(os.environ, **dict(kv.split("=") for kv in sw.split()))
+        out = tempfile.TemporaryFile(mode="w+")
+        procs[sw] = (subprocess.Popen([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_model.py"), os.path.join(here, "test_gpu_precision_modes.py"),
+                                       os.path.join(here, "test_gpu_next_rows.py"), "-q", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"],
+                                      env=env, stdout=out, stderr=subprocess.STDOUT, text=True), out)
+    yield procs
+    for p, out in procs.values():
+        if p.poll() is None:
+            p.kill()
+        out.close()
+
+
+@pytest.mark.parametrize("switch", SWITCHES)
+def test_runtime_switch_matrix(switch, switch_children):
+    """Every A/B switch that keeps an alternative code path alive in the shipped library (README "Runtime switches") through the
+    reference-generated golden vectors of the head and the detector, the cfg2 precision gate, the pipelined and the episode-cache
+    paths: a switch is read once per process, so each group runs in a child process (all four started together by the fixture)."""
+    p, out = switch_children[switch]
+    p.wait(timeout=900)
+    out.seek(0)
+    text = out.read()
+    assert p.returncode == 0, text[-3000:]
+    assert " passed" in text and "failed" not in text, text[-500:]

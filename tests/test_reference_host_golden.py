@@ -64,3 +64,45 @@ def test_evaluate_vs_reference(tmp_path):
     ours = open(os.path.join(str(tmp_path), "result_keypoints.json")).read()
     assert ours == bytes(g["result_json"]).decode()
     assert len(json.loads(ours)) == len(pairs)
+
+
+def test_stream_schedule_covers_the_pair_order():
+    """episodes.stream_schedule cuts the reference's pair order (every support set followed by its queries, test_dataset.py:86-99) into
+    the calls of ec_forward_episodes: every pair exactly once and in order, an episode is encoded by the call that holds its first
+    query, its slot is not handed to another episode before the call after its last query, and too small a cache is an error."""
+    import pytest
+    from edgecape_amd.episodes import stream_schedule
+    rng = np.random.default_rng(3)
+    for n_ep, batch, cap in ((32, 60, 6), (7, 4, 6), (5, 100, 5), (9, 15, 17), (4, 1, 2)):
+        sizes = rng.integers(1, 16, n_ep) if batch != 60 else np.full(n_ep, 15)
+        ep = np.repeat(np.arange(n_ep), sizes)
+        calls = stream_schedule(ep, batch, cap)
+        assert np.array_equal(np.concatenate([c["queries"] for c in calls]), np.arange(len(ep)))
+        owner, encoded = {}, set()
+        for c in calls:
+            for e, s in zip(c["new_episodes"], c["new_slots"]):
+                assert e not in encoded and 0 <= s < cap
+                assert s not in owner or ep.tolist().index(e) > max(np.nonzero(ep == owner[s])[0])   # the old episode's queries are all behind us
+                owner[int(s)] = e
+                encoded.add(e)
+            assert all(owner[int(s)] == e for s, e in zip(c["slot_of_query"], ep[c["queries"]]))
+            assert sorted(set(c["new_episodes"])) == sorted(e for e in set(ep[c["queries"]].tolist()) if min(np.nonzero(ep == e)[0]) >= c["queries"][0])
+        assert encoded == set(range(n_ep))
+    with pytest.raises(ValueError):
+        stream_schedule(np.repeat(np.arange(6), 2), 12, 3)          # six episodes alive in one call, three slots
+    with pytest.raises(ValueError):
+        stream_schedule(np.array([0, 1, 0]), 2, 4)                  # not the reference's order
+
+
+def test_detector_support_key_tells_support_sets_apart():
+    """EdgeCape.enable_episode_cache recognises a support set by its annotations in img_metas: same files + crops + keypoints = same
+    set; another annotation in the same image file, another skeleton or another shot order is a different one."""
+    from edgecape_amd.detector import EdgeCape
+    base = dict(sample_image_file=["a.jpg", "b.jpg"], sample_center=[np.array([10., 20.]), np.array([5., 5.])],
+                sample_scale=[np.array([1., 1.]), np.array([2., 2.])], sample_skeleton=[[[0, 1], [1, 2]]] * 2)
+    k = EdgeCape._support_key
+    assert k(base) == k(dict(base, query_image_file="q.jpg"))
+    assert k(base) != k(dict(base, sample_center=[np.array([11., 20.]), np.array([5., 5.])]))
+    assert k(base) != k(dict(base, sample_skeleton=[[[0, 1]]] * 2))
+    assert k(base) != k(dict(base, sample_image_file=["b.jpg", "a.jpg"]))
+    assert k(dict(sample_image_file=["a.jpg"], sample_skeleton=[[]])) == k(dict(sample_image_file=["a.jpg"], sample_skeleton=[[]]))

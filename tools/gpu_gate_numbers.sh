@@ -5,9 +5,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/gates
 mkdir -p $O
 cd $R
-for c in cfg1 cfg2 cfg4 cfg5; do
+for cb in cfg1:4 cfg2:4 cfg4:3 cfg5:3; do
+  c=${cb%%:*}; nb=${cb##*:}
   T0=$(date +%s)
-  python tools/conformance.py --config $c --batches 4 --out $O/gate_$c.json > $O/$c.log 2>&1
+  python tools/conformance.py --config $c --batches $nb --out $O/gate_$c.json > $O/$c.log 2>&1
   echo "$c seconds: $(( $(date +%s) - T0 ))"
 done
 python - <<'PY'

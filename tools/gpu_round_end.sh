@@ -3,7 +3,7 @@
 # configuration, the bench lines (headline + BASELINE configs 4 / 5 + the reference's shipped ViT-S configuration, each WITH the CPU
 # baseline / parity sample and with `traffic` from the PMC summary of the same library), rocprofv3 kernel trace + stats.
 #   usage: bash tools/gpu_round_end.sh <tag> [--no-tests]   -> gpurun_out/<tag>/...   (copy what should be judged into profiles/)
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT $OUT/pmc
@@ -16,17 +16,18 @@ python tools/refresh_pmc.py --out $OUT/pmc --arch dinov2_vitl14 --image-size 384
 python tools/refresh_pmc.py --out $OUT/pmc --arch dinov2_vits14 --image-size 224 >> $OUT/pmc.log 2>&1
 cp $OUT/pmc/qkv_gemm_pmc*.json profiles/
 python bench.py > $OUT/bench.json 2> $OUT/bench.err; python tools/bench_line.py < $OUT/bench.json | cut -c1-400
-python bench.py --shots 5 --batch 16 --no-episode --no-alt --steps 10 --cpu-batches 16 --cpu-runs 3 > $OUT/cfg4_5shot_b16.json 2>> $OUT/bench.err
+python bench.py --shots 5 --batch 16 --no-alt --steps 10 --cpu-batches 16 --cpu-runs 3 > $OUT/cfg4_5shot_b16.json 2>> $OUT/bench.err
 python bench.py --arch dinov2_vitl14 --image-size 384 --batch 8 --no-episode --no-alt --steps 10 --cpu-batches 8 --cpu-runs 3 > $OUT/cfg5_vitl_384_b8.json 2>> $OUT/bench.err
-python bench.py --arch dinov2_vits14 --image-size 224 --no-episode --no-alt --steps 10 --cpu-batches 32 --cpu-runs 3 > $OUT/ref_vits_224_b32.json 2>> $OUT/bench.err
-python bench.py --precision bf16x3 --head-precision bf16x3 --no-cpu-baseline --no-episode --no-alt --steps 10 > $OUT/bench_bf16x3.json 2>> $OUT/bench.err
+python bench.py --arch dinov2_vits14 --image-size 224 --no-alt --steps 10 --cpu-batches 32 --cpu-runs 3 > $OUT/ref_vits_224_b32.json 2>> $OUT/bench.err
+python bench.py --precision bf16x3 --head-precision bf16x3 --no-cpu-baseline --no-episode --no-alt --sustained-seconds 0 --steps 10 > $OUT/bench_bf16x3.json 2>> $OUT/bench.err
 for f in cfg4_5shot_b16 cfg5_vitl_384_b8 ref_vits_224_b32 bench_bf16x3; do python tools/bench_line.py $f < $OUT/$f.json | cut -c1-200; done
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/prof -o r -- python $R/bench.py --no-cpu-baseline --no-episode --no-alt --steps 6 --warmup 3 > $OUT/prof_bench.json 2> $OUT/prof.err
+rocprofv3 --kernel-trace --stats -d $OUT/prof -o r -- python $R/bench.py --no-cpu-baseline --no-alt --sustained-seconds 0 --episode-images 64 --steps 6 --warmup 3 > $OUT/prof_bench.json 2> $OUT/prof.err
 cd $R
 DB=$(ls $OUT/prof/*/*results.db $OUT/prof/*results.db 2>/dev/null | head -1)
 python tools/rocpd_stats.py $DB $OUT/kernel_stats.csv
-python tools/trace_step.py $DB > $OUT/step_trace.txt 2>/dev/null
+python tools/trace_step.py $DB 0 -1 > $OUT/episode_call_trace.txt 2>/dev/null     # the last call of the episode leg (60 queries + 4 supports)
+python tools/trace_step.py $DB 0 -33 > $OUT/step_trace.txt 2>/dev/null           # the last headline step: 8 + 24 episode calls lie behind it
 head -n 14 $OUT/kernel_stats.csv | cut -c1-150
 rm -rf $OUT/prof $OUT/pmc/pmc_*
 ls $OUT

@@ -30,7 +30,8 @@ import rocpd_pmc  # noqa: E402
 from edgecape_amd import build, synth  # noqa: E402
 
 PASSES = [("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
-          ("sq", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES"])]
+          ("sq", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES"]),
+          ("inst", ["SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_SALU", "SQ_INSTS_LDS"])]   # (round 5: the attention kernel's instruction mix)
 
 
 def main():
@@ -44,7 +45,7 @@ def main():
     args = ap.parse_args()
     args.out = os.path.abspath(args.out)          # rocprofv3 runs from /tmp
     os.makedirs(args.out, exist_ok=True)
-    bench_cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-episode", "--no-alt", "--steps", "2", "--warmup", "1",
+    bench_cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-episode", "--no-alt", "--sustained-seconds", "0", "--steps", "2", "--warmup", "1",
              "--precision", args.precision, "--batch", str(args.batch), "--shots", str(args.shots), "--image-size", str(args.image_size),
              "--arch", args.arch]
     env = dict(os.environ, TMPDIR="/tmp")
