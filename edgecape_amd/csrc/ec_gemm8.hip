@@ -770,10 +770,10 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
     if (p.N > 16384) kind = G8_GENERIC; else q.bias = ds.zeros;
   }
   if (ntiles <= grid || grid < 8 || p.K < 256 || (kind != G8_BIAS_BF16 && kind != G8_GELU_BF16)) q.sched = nullptr;   // one tile per workgroup: nothing to deal out (K >= 256: the hand-over spans three K-tiles)
-  // (round 5 experiment, A/B only) the multi-round GEMMs of a PIPELINED call - the ones that take their tiles from the dynamic schedule -
-  // on ncu - R workgroups: R CUs stay free for the previous call's head, which otherwise holds whole CUs the persistent workgroups need
-  static const int reserve = getenv("EC_G8_RESERVE") ? atoi(getenv("EC_G8_RESERVE")) : 0;
-  if (q.sched && reserve > 0 && grid == ds.ncu && grid - reserve >= 64) grid -= reserve;
+  // (round 5, measured and removed: the multi-round GEMMs of a PIPELINED call on ncu - R workgroups, so that R CUs stay free for the
+  //  previous call's head instead of the head holding CUs the persistent workgroups want: R = 8 nothing, R = 16 / 32 -3 % pairs/s, QKV
+  //  0.349 -> 0.358 / 0.328 / 0.322 of peak beside the head; profiles/r05_cu_reserve_ab.txt.  The dynamic tile schedule already absorbs
+  //  late workgroups; fewer workgroups only lose their tiles' worth of CUs.)
   hipLaunchKernelGGL(table[p.h_f16 ? 1 : 0][kind][p.tag], dim3((unsigned)grid), dim3(512), G8_LDS, st, q);
   EC_LAUNCH_CHECK();
   return 1;
