@@ -2030,6 +2030,7 @@ int ec_support_create(ec_handle m, int max_episodes, ec_support_t* out) {
   auto al = [&](void** p, size_t bytes) -> int {
     EC_HIP(hipMalloc(p, bytes));
     c->owned.push_back(*p);
+    EC_HIP(hipMemset(*p, 0, bytes));   // (a slot's Markov stack is never written by a gt_skeleton model, yet travels with the slot)
     return 0;
   };
   int rc = 0;
