@@ -2,7 +2,7 @@
 # Conformance records of the CURRENT library for every benched configuration (tools/conformance.py: disjoint pairs x 2 weight seeds against
 # the CPU oracle, with the near-tie-guard analysis): fp16 / mixed on cfg1 (ViT-S/14 @ 224), cfg2, cfg4, cfg5; bf16x3 / bf16x3 on cfg1, cfg2.
 #   usage: bash tools/gpu_conformance_all.sh <tag>   -> gpurun_out/<tag>/conformance_*.json   (copy into profiles/ as r<NN>_conformance_*)
-export TAG=${1:-r04conf}
+export TAG=${1:-r05conf}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
