@@ -117,14 +117,24 @@ def timed_steps(step, steps, warmup, collective=None, before_timed=None):
 
 
 # ---- sharding -------------------------------------------------------------------------------------------------------
-def shard_indices(n_total, rank, world_size):
-    """DistributedSampler(shuffle=False) semantics: pad to equal length by wrapping around, rank r takes r, r+W, ..."""
-    per = -(-n_total // world_size)
-    idx = list(range(n_total))
-    pad = per * world_size - n_total
-    if pad > 0 and n_total > 0:
-        idx += (idx * (-(-pad // n_total)))[:pad]   # wraps more than once when n_total < world_size
-    return idx[rank::world_size]
+def shard_indices(n_total, rank, world_size, group=1):
+    """DistributedSampler(shuffle=False) semantics: pad to equal length by wrapping around, rank r takes r, r+W, ...
+    group > 1 (round 5): the same over GROUPS of `group` consecutive items - rank r takes groups r, r+W, ... whole.  The reference's
+    pair order is 15 consecutive pairs per support set (test_dataset.py:86-99): with group=15 a rank sees every one of its support sets
+    with all its queries, which is what the support-side episode cache needs (item-wise round-robin would hand every rank 15 / W
+    queries of EVERY support set and have all ranks encode all of them)."""
+    if group <= 1:
+        per = -(-n_total // world_size)
+        idx = list(range(n_total))
+        pad = per * world_size - n_total
+        if pad > 0 and n_total > 0:
+            idx += (idx * (-(-pad // n_total)))[:pad]   # wraps more than once when n_total < world_size
+        return idx[rank::world_size]
+    n_groups = -(-n_total // group)
+    out = []
+    for g in shard_indices(n_groups, rank, world_size):
+        out.extend(range(g * group, min((g + 1) * group, n_total)))
+    return out
 
 
 # ---- evaluation loops -----------------------------------------------------------------------------------------------
@@ -208,10 +218,11 @@ def _local_meta(local_results):
     return [len(local_results), kmax, -kmin, plen, bad]
 
 
-def collect_results(local_results, size, device=None, all_ranks=False):
+def collect_results(local_results, size, device=None, all_ranks=False, group=1):
     """collect_results_gpu (apis/test.py:154-198) on fixed-size records.  `local_results`: this rank's per-sample dicts in its
-    shard order (rank r holds dataset items r, r+W, ...); `size` = len(dataset).  Rank 0 (every rank with all_ranks=True) gets
-    the `size` result dicts in dataset order, the others None.  Ranks may hold unequal (even zero) numbers of samples."""
+    shard order (rank r holds dataset items r, r+W, ...; with group > 1 the items of shard_indices(size, r, W, group)); `size` =
+    len(dataset).  Rank 0 (every rank with all_ranks=True) gets the `size` result dicts in dataset order, the others None.  Ranks may
+    hold unequal (even zero) numbers of samples."""
     rank, world = rank_world()
     if world == 1:
         return list(local_results)[:size]
@@ -228,19 +239,31 @@ def collect_results(local_results, size, device=None, all_ranks=False):
     dist.all_gather(parts, mine)
     if rank != 0 and not all_ranks:
         return None
+    if group > 1:                                         # group-wise shards: put every record back at its dataset index
+        ordered = [None] * size
+        for r in range(world):
+            rows_r = parts[r].cpu().numpy()
+            for i, gi in enumerate(shard_indices(size, r, world, group)):
+                if i < n_rows and rows_r[i][0] and ordered[gi] is None:    # (wrapped-around padding repeats earlier items)
+                    ordered[gi] = _unpack(rows_r[i], K)
+        missing = [i for i, o in enumerate(ordered) if o is None]
+        if missing:
+            raise ValueError(f"collect_results: no rank delivered dataset items {missing[:8]}{'...' if len(missing) > 8 else ''}")
+        return ordered
     rows = torch.stack(parts, 1).reshape(n_rows * world, -1).cpu().numpy()   # row i*W + r  <-  rank r, local i
     ordered = [_unpack(r, K) for r in rows if r[0]]
     return ordered[:size]                                 # "the dataloader may pad some samples"
 
 
-def multi_gpu_test(model, data_loader, size=None, tmpdir=None, gpu_collect=True, all_ranks=False, pipelined=False):
-    """apis/test.py:50-91.  `data_loader` yields this rank's shard; `size` defaults to len(data_loader.dataset)."""
+def multi_gpu_test(model, data_loader, size=None, tmpdir=None, gpu_collect=True, all_ranks=False, pipelined=False, group=1):
+    """apis/test.py:50-91.  `data_loader` yields this rank's shard; `size` defaults to len(data_loader.dataset).  group: the shard
+    granularity the loader used (shard_indices(size, rank, world, group); 15 = whole episodes per rank, for the episode cache)."""
     if size is None:
         ds = getattr(data_loader, "dataset", None)
         if ds is None:
             raise ValueError("multi_gpu_test needs `size` (len(dataset)) when the loader has no .dataset")
         size = len(ds)
-    return collect_results(single_gpu_test(model, data_loader, pipelined=pipelined), size, all_ranks=all_ranks)
+    return collect_results(single_gpu_test(model, data_loader, pipelined=pipelined), size, all_ranks=all_ranks, group=group)
 
 
 def gather_predictions(local_preds, n_total, device=None):

@@ -59,10 +59,13 @@ def _worker(rank, world, port, n_total, mode, q):
         mine = apis.shard_indices(n_total, rank, world)
     elif mode == "uneven":         # un-padded shards of unequal length
         mine = list(range(rank, n_total, world))
+    elif mode == "episodes":       # whole episodes (groups of 3 consecutive pairs) per rank: what the episode cache needs (round 5)
+        mine = apis.shard_indices(n_total, rank, world, group=3)
+        assert all(mine[i] + 1 == mine[i + 1] for i in range(0, len(mine) - 1) if mine[i] % 3 != 2 and mine[i] + 1 < n_total)
     else:                          # "empty": rank 1 has nothing at all
         mine = list(range(n_total)) if rank == 0 else []
     loader = [dict(idx=[mine[i:i + 2]]) for i in range(0, len(mine), 2)]      # batches of 2 pairs
-    res = apis.multi_gpu_test(_FakeModel(), loader, size=n_total)
+    res = apis.multi_gpu_test(_FakeModel(), loader, size=n_total, group=3 if mode == "episodes" else 1)
     ev = None
     if rank == 0:                  # the gathered list feeds the reference-format evaluation unchanged
         with tempfile.TemporaryDirectory() as d:
@@ -85,7 +88,8 @@ def _worker(rank, world, port, n_total, mode, q):
     apis.finalize_distributed()
 
 
-@pytest.mark.parametrize("n_total,mode", [(7, "sampler"), (8, "sampler"), (7, "uneven"), (5, "empty"), (1, "sampler")])
+@pytest.mark.parametrize("n_total,mode", [(7, "sampler"), (8, "sampler"), (7, "uneven"), (5, "empty"), (1, "sampler"), (12, "episodes"), (10, "episodes"),
+                                          (2, "episodes")])
 def test_world2_multi_gpu_test_matches_single_process(n_total, mode):
     sys.path.insert(0, ROOT)
     from edgecape_amd import apis
@@ -270,6 +274,15 @@ def test_shard_indices_is_distributed_sampler():
         for r in range(w):
             ds = DistributedSampler(list(range(n)), num_replicas=w, rank=r, shuffle=False)
             assert list(ds) == apis.shard_indices(n, r, w)
+    # group-wise shards (round 5): every rank holds WHOLE groups, all ranks equally many, every item covered
+    for n, w, g in [(480, 8, 15), (45, 2, 15), (47, 4, 15), (7, 3, 15), (30, 4, 1)]:
+        shards = [apis.shard_indices(n, r, w, group=g) for r in range(w)]
+        n_groups = -(-n // g)
+        assert set(i for s in shards for i in s) == set(range(n))
+        assert len(set(len(set(i // g for i in s)) for s in shards)) == 1 or n_groups < w           # the same number of groups each
+        for s in shards:
+            for gi in set(i // g for i in s):
+                assert [i for i in s if i // g == gi][:min(g, n - gi * g)] == list(range(gi * g, min((gi + 1) * g, n)))
 
 
 def test_single_process_helpers_without_process_group():
