@@ -736,8 +736,7 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
     else if (p.act == ACT_GELU && !p.gamma) kind = G8_GELU_BF16;
   } else if (p.table && !p.resid && !p.gamma && !p.aux && p.act == ACT_NONE && p.period > 0 && p.ldt % 4 == 0 && p.ldc % 4 == 0 &&
              (long)p.M * p.ldc * (p.c_bf16 ? 2 : 4) < (1l << 31)) {
-    static const bool tab_off = getenv("EC_G8_TAB") && atoi(getenv("EC_G8_TAB")) == 0;   // A/B: the generic epilogue
-    if (!tab_off) kind = p.c_bf16 ? G8_TAB_H16 : G8_TAB_F32;
+    kind = p.c_bf16 ? G8_TAB_H16 : G8_TAB_F32;   // (the A/B switch back to the generic epilogue, EC_G8_TAB, went in round 5)
   }
 #define G8_ROW(F) \
       {gemm8_bf16_kernel<0, 0, F>, gemm8_bf16_kernel<0, 1, F>, gemm8_bf16_kernel<0, 2, F>, gemm8_bf16_kernel<0, 3, F>, gemm8_bf16_kernel<0, 4, F>}, \

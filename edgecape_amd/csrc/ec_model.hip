@@ -492,7 +492,7 @@ static int run_backbone(ec_model* m, const float* const* imgs, const int* counts
   // fp16 backbone: the patch embedding in SPLIT precision (round 3).  The image patches and the patch weights rounded to fp16 carry 38 %
   // of the error variance of the backbone's features (oracle/precision_sites.py) - every later block inherits it through the residual
   // stream - for 0.5 % of the FLOPs: with [hi | lo | hi] patches against [W_hi | W_hi | W_lo] weights the same 8-phase GEMM, K = 3 Kp,
-  // computes the products to ~2^-22.  EC_PATCH_X3=0: single fp16 operands as before.
+  // computes the products to ~2^-22.  (The bf16 backbone keeps single operands; the fp16 A/B switch EC_PATCH_X3 went in round 5.)
   const bool px3 = m->patch_w16x3 != nullptr;
   const int Kpe = px3 ? 3 * m->Kp : m->Kp;
   for (int s = 0, at = 0; s < n_src; at += counts[s], ++s)
@@ -872,8 +872,7 @@ static int run_dec_layer(ec_model* m, const DecLayer& L, const LayerIO& io, bool
 static int kpt_mlp(ec_model* m, const KptBranch& kb, const float* x, long ldx, int rows, const float* prev, float* out,
                    hipStream_t st, float* t1 = nullptr, float* t2 = nullptr, const ec_model::RowPlan* plan = nullptr) {
   const int d = m->d;
-  static const bool kpt_chain_off = getenv("EC_KPT_CHAIN") && atoi(getenv("EC_KPT_CHAIN")) == 0;
-  if (!kpt_chain_off && m->head_chain && chain_ok(kb.l0) && chain_ok(kb.l2) && chain_ok(kb.l4) && d == 256 && kb.l0.K == d &&
+  if (m->head_chain && chain_ok(kb.l0) && chain_ok(kb.l2) && chain_ok(kb.l4) && d == 256 && kb.l0.K == d &&
       kb.l0.N == d && kb.l2.K == d && kb.l2.N == d && kb.l4.K == d && kb.l4.N == d && kb.l0.h1 == kb.l2.h1 && kb.l0.h1 == kb.l4.h1) {
     // the three GELU Linear layers and the keypoint tail (kpt_out) as ONE row chain (see the decoder's helper lane)
     ChainBuild cb(plan);
@@ -1248,9 +1247,9 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     // staged into y's buffer (dead by then).  7 launches per layer become 2 and the encoder alone gets 25-30 % faster.  Round 2 measured
     // it 0.5-1 % SLOWER for the step, because its 424 CU-filling workgroups starved the support lane beside it, then the critical one;
     // under ec_forward_pipelined (round 3) the query lane is what the caller's stream waits for - the support lane and the decoder run
-    // beside the next backbone - so the encoder's time counts and the support lane's does not.  EC_ENC_CHAIN=0: separate launches.
-    static const bool enc_chain_on = !(getenv("EC_ENC_CHAIN") && atoi(getenv("EC_ENC_CHAIN")) == 0);
-    const bool enc_chain = enc_chain_on && m->head_chain && chain_ok(e.out) && chain_ok(e.l1) && chain_ok(e.l2) && e.out.K == d &&
+    // beside the next backbone - so the encoder's time counts and the support lane's does not.  (Re-measured in round 5 before the A/B
+    // switch EC_ENC_CHAIN went: within 1 % either way, profiles/r05_enc_chain_ab.txt; the fp32 head runs the separate launches.)
+    const bool enc_chain = m->head_chain && chain_ok(e.out) && chain_ok(e.l1) && chain_ok(e.l2) && e.out.K == d &&
                            e.l1.K == d && e.l2.N == d && CH_LDS0 + chain_layout_bytes(Fd) + chain_layout_bytes(d) <= 160 * 1024;
     if (enc_chain) {
       ChainBuild cb;
@@ -1395,15 +1394,13 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
     // b_{l+1} = sigmoid(inverse_sigmoid(b_l) + kpt_branch[l](x))   (un-normed x, :395-402), then qpe_{l+1} = ref_point_head(sine(b_{l+1})).
     // Layer l+1 waits for qpe_{l+1} right after its self-attention kernel (~25 us), so these seven dependent launches (~70 us) were on
     // the decoder's critical path: as ONE row chain (three GELU stages, the keypoint tail + sine embedding inside the kernel, two
-    // ref_point_head stages) the helper lane is back under the attention.  EC_KPT_CHAIN=0 restores the separate launches.
-    static const bool kpt_chain_off = getenv("EC_KPT_CHAIN") && atoi(getenv("EC_KPT_CHAIN")) == 0;
-    const bool kpt_chain = !kpt_chain_off && li + 1 < nL && m->head_chain && chain_ok(kb.l0) && chain_ok(kb.l2) && chain_ok(kb.l4) &&
+    // ref_point_head stages) the helper lane is back under the attention.  (The fp32 head runs the separate launches.)
+    const bool kpt_chain = li + 1 < nL && m->head_chain && chain_ok(kb.l0) && chain_ok(kb.l2) && chain_ok(kb.l4) &&
                            chain_ok(m->rp0) && chain_ok(m->rp1) && kb.l0.K == d && kb.l0.N == d && kb.l2.K == d && kb.l2.N == d &&
                            kb.l4.K == d && kb.l4.N == d && m->rp0.K == d && m->rp0.N == d && m->rp1.K == d && d == 256 &&
                            kb.l0.h1 == m->rp0.h1 && kb.l0.h1 == m->rp1.h1 && kb.l0.h1 == kb.l2.h1 && kb.l0.h1 == kb.l4.h1;
     // next layer's self-attention on the helper stream, right behind this layer's last chain (which produced its q|k|v)
-    static const bool pre_off = getenv("EC_DEC_PRE") && atoi(getenv("EC_DEC_PRE")) == 0;   // A/B switch
-    sa_prelaunched = !pre_off && ovd && kpt_chain && ss.dec_bias && ch && layer_chains(m, m->dec[li + 1]) && chain_ok(m->dec[li + 1].sa_in);
+    sa_prelaunched = ovd && kpt_chain && ss.dec_bias && ch && layer_chains(m, m->dec[li + 1]) && chain_ok(m->dec[li + 1].sa_in);
     if (sa_prelaunched) {
       LayerIO nio = io;
       nio.bias = ss.dec_bias + (size_t)(li + 1) * bs * nh * K * K;
@@ -1433,7 +1430,7 @@ static int run_head_query(ec_model* m, const float* fq, int bs, hipStream_t st, 
       if (!sa_prelaunched) RUN(mark(ev_qpe));
       RUN(ln(dx, dx_ld, hs, d, false, m->dec_norm, Mk, d, 1e-5f, ax));
       RUN(mark(ev_x));                     // x_{l+1} has been read (chain and dec_norm): layer l+1 may overwrite it
-    } else if (!kpt_chain_off && li + 1 == nL) {
+    } else if (li + 1 == nL) {
       // last layer: b_L = update(b_{L-1}, kpt_branch(x)) on the helper lane, dec_norm + kpt_branch(hs) beside it (one row chain each)
       RUN(ln(dx, dx_ld, hs, d, false, m->dec_norm, Mk, d, 1e-5f, last_split ? st : ax));
       RUN(kpt_mlp(m, kb, dx, dx_ld, Mk, bi, bnext, ax, nullptr, nullptr, dplan));
@@ -1712,7 +1709,7 @@ int ec_finalize(ec_handle m) {
     m->patch.N = C; m->patch.K = m->Kp; m->patch.b = pb->dev;
     if ((rc = upload(m, Wp, &m->patch.w))) return rc;
     if (m->bb16 && (rc = upload16(m, Wp, &m->patch.w16))) return rc;
-    if (m->bbf16 && !(getenv("EC_PATCH_X3") && atoi(getenv("EC_PATCH_X3")) == 0)) {
+    if (m->bbf16) {
       std::vector<bf16_t> w3((size_t)C * 3 * m->Kp);
       for (int n = 0; n < C; ++n)
         for (int k = 0; k < m->Kp; ++k) {

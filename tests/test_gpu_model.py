@@ -439,8 +439,7 @@ def test_support_cache_matches_pairwise_forward(shots):
 # Switches of different subsystems share a run (each alternative path is still exercised; a failing group is bisected by hand), and the
 # four child processes run SIDE BY SIDE on the one GPU (round 5: ~35 s each - mostly interpreter start-up, engine builds and the host side of
 # small tests - were 6 x 35 s in a row, a third of the suite).
-SWITCHES = ["EC_CHAIN=0 EC_G8_DYN=1 EC_G8_TAB=0", "EC_OVERLAP=0 EC_DEC_PRE=0 EC_COMPACT=2",
-            "EC_OVERLAP=1 EC_PIPE_FULL=0 EC_COMPACT=0 EC_PATCH_X3=0", "EC_KPT_CHAIN=0 EC_ENC_CHAIN=0 EC_G8_DYN=0 EC_GEMM8_OFF=1"]
+SWITCHES = ["EC_CHAIN=0 EC_G8_DYN=1", "EC_OVERLAP=0 EC_COMPACT=2", "EC_OVERLAP=1 EC_PIPE_FULL=0 EC_COMPACT=0", "EC_G8_DYN=0 EC_GEMM8_OFF=1"]
 
 
 @pytest.fixture(scope="module")

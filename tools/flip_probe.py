@@ -36,4 +36,4 @@ for b in range(int(os.environ.get("NB", 8))):
         print(f"batch {b} sample {s} kp {k}: oracle best {ar[s,k]} ({sr[s,k,ar[s,k]]:.5f}) second gap {r[0]-r[1]:.2e}; oracle at hip's {ag[s,k]}: {sr[s,k,ag[s,k]]:.5f}; "
               f"hip at oracle's best {sg[s,k,ar[s,k]]:.5f} at its own {sg[s,k,ag[s,k]]:.5f}; n identical rows in this sample: "
               f"{int((np.abs(sr[s] - sr[s, k]).max(-1) < 1e-6).sum())}")
-print("ENC_CHAIN", os.environ.get("EC_ENC_CHAIN", "default"), "flips", nf)
+print("flips", nf)
