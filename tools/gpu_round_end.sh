@@ -27,7 +27,7 @@ cd $R
 DB=$(ls $OUT/prof/*/*results.db $OUT/prof/*results.db 2>/dev/null | head -1)
 python tools/rocpd_stats.py $DB $OUT/kernel_stats.csv
 python tools/trace_step.py $DB 0 -1 > $OUT/episode_call_trace.txt 2>/dev/null     # the last call of the episode leg (60 queries + 4 supports)
-python tools/trace_step.py $DB 0 -33 > $OUT/step_trace.txt 2>/dev/null           # the last headline step: 8 + 24 episode calls lie behind it
+python tools/trace_step.py $DB 0 -34 > $OUT/step_trace.txt 2>/dev/null           # the last headline step but one (8 + 24 episode calls and the episode engine's build lie behind the last)
 head -n 14 $OUT/kernel_stats.csv | cut -c1-150
 rm -rf $OUT/prof $OUT/pmc/pmc_*
 ls $OUT
