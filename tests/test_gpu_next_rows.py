@@ -558,3 +558,79 @@ def test_detector_episode_cache_is_a_drop_in(shots):
             assert np.abs(a["preds"] - b["preds"]).max() < 1e-3, (slots, pipelined, float(np.abs(a["preds"] - b["preds"]).max()))   # pixels of a 224 px box
         st = next(iter(model._episodes.values()))
         assert len(st["slot_of"]) == min(slots, n_ep)   # three support sets seen, at most `slots` kept
+
+
+def test_forward_episodes_stress_ragged_stream():
+    """ec_forward_episodes on a RAGGED stream, pipelined with two alternating output sets and a copy stream behind ec_pipeline_flush (the
+    way detector.submit uses it): 11 episodes of 1..7 queries in calls of 5 with a 4-slot cache - slots re-used many times, calls with
+    three new episodes and with none, plain ec_forward calls mixed in between - every output of every call bit-equal to the same stream
+    issued plain (complete at the end of each call), fp16 / mixed with row compaction on in the pipelined calls only."""
+    from edgecape_amd.engine import HipEngine, SupportCache
+    from edgecape_amd.episodes import stream_schedule
+    arch, H, bs, S = "dinov2_vits14", 224, 5, 2
+    rng = np.random.default_rng(11)
+    sizes = rng.integers(1, 8, 11)
+    ep = np.repeat(np.arange(len(sizes), dtype=np.int32), sizes)
+    sup = synth.make_pairs(len(sizes), S, H, seed=310, fixed_n_kp=False)
+    qry = synth.make_pairs(len(ep), 1, H, seed=410)
+    mask = sup["target_weight_s"][0].copy()
+    for tw in sup["target_weight_s"]:
+        mask = mask * tw
+    mask[3] = 0.0                                   # an episode without any valid keypoint
+    skels = [m["sample_skeleton"][0] for m in sup["img_metas"]]
+    eng = HipEngine(synth.make_weights(arch, seed=23), arch=arch, image_size=H, max_batch=bs, max_shots=S, backbone_precision="fp16",
+                    head_precision="mixed")
+    calls = stream_schedule(ep, bs, 4)
+    assert max(len(c["new_episodes"]) for c in calls) >= 3 and min(len(c["new_episodes"]) for c in calls) == 0
+    prepared = []
+    for c in calls:
+        new = None
+        if len(c["new_episodes"]):
+            e = np.asarray(c["new_episodes"])
+            new = dict(img_s=[x[e] for x in sup["img_s"]], target_s=[x[e] for x in sup["target_s"]], mask_s=mask[e],
+                       skeletons=[skels[i] for i in e], slots=c["new_slots"])
+        prepared.append(eng.prepare_episode_call(qry["img_q"][c["queries"]], c["slot_of_query"], new))
+    keys = ("output_kpts", "initial_proposals", "similarity_map", "adj", "attn_adj", "out_points")
+    cache = SupportCache(eng, 4)
+    ref = []
+    for p in prepared:
+        o = eng.forward_episodes(cache, prepared=p)
+        torch.cuda.synchronize()
+        ref.append({k: o[k].cpu() for k in keys})
+    # a plain pairwise batch between the pipelined calls (every other entry point waits for a pending head)
+    pb = synth.make_pairs(bs, S, H, seed=77, fixed_n_kp=False)
+    pmask = pb["target_weight_s"][0].copy()
+    for tw in pb["target_weight_s"]:
+        pmask = pmask * tw
+    pskel = [m["sample_skeleton"][0] for m in pb["img_metas"]]
+    plain_ref = eng.forward(pb["img_q"], pb["img_s"], pb["target_s"], pmask, pskel)
+    torch.cuda.synchronize()
+    cache = SupportCache(eng, 4)
+    copy_stream = torch.cuda.Stream()
+    sets = {}
+    got, events, plain_got = [], [], []
+    for i, p in enumerate(prepared):
+        key = (p["bs"], i & 1)
+        if key not in sets:
+            sets[key] = eng._outputs(p["bs"])
+        if i >= 2:
+            events[i - 2].synchronize()             # the set's previous results (call i - 2 or earlier) have been copied out
+        eng.forward_episodes(cache, prepared=p, outputs=sets[key], pipelined=True)
+        copy_stream.wait_stream(torch.cuda.current_stream())
+        eng.pipeline_flush(copy_stream)
+        with torch.cuda.stream(copy_stream):
+            got.append({k: sets[key][0][k].to("cpu", non_blocking=True) for k in keys})
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+            events.append(ev)
+        if i in (2, 6):
+            plain_got.append(eng.forward(pb["img_q"], pb["img_s"], pb["target_s"], pmask, pskel))
+    eng.pipeline_flush()
+    torch.cuda.synchronize()
+    for i in range(len(prepared)):
+        for k in keys:
+            assert torch.isfinite(got[i][k]).all(), (i, k)
+            assert torch.equal(got[i][k], ref[i][k]), (i, k, float((got[i][k] - ref[i][k]).abs().max()))
+    for o in plain_got:
+        for k in keys:
+            assert torch.equal(o[k], plain_ref[k]), k
