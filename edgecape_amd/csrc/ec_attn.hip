@@ -706,6 +706,24 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
   lrun = xhalf_sum(lrun);
   const float inv = 1.f / lrun;
   if (q0 + j < p.Lq) {
+    if (p.o_x3) {   // bf16 split [hi | lo | hi], planes H * HD elements apart: the A operand of the K-concatenated proj GEMM (bf16x3 backbone)
+      bf16_t* O = (bf16_t*)p.O + (long)b * p.sO + (long)(q0 + j) * p.ldo + h * HD;
+      const long plane = (long)p.H * HD;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+          v[0] = ot[d][4 * g] * inv; v[1] = ot[d][4 * g + 1] * inv; v[2] = ot[d][4 * g + 2] * inv; v[3] = ot[d][4 * g + 3] * inv;
+          u32x2_t vh, vl;
+          split4_bf16(v, vh, vl);
+          bf16_t* o = O + d * 32 + 8 * g + 4 * hi;
+          *(u32x2_t*)o = vh;
+          *(u32x2_t*)(o + plane) = vl;
+          *(u32x2_t*)(o + 2 * plane) = vh;
+        }
+      return;
+    }
     float* O = (float*)p.O + (long)b * p.sO + (long)(q0 + j) * p.ldo + h * HD;
 #pragma unroll
     for (int d = 0; d < DT; ++d)
@@ -724,6 +742,7 @@ int attention(const AttnP& p, hipStream_t st) {
   EC_REQUIRE(p.B > 0 && p.H > 0 && p.Lq > 0 && p.Lk > 0, -1, "attention: empty problem");
   EC_REQUIRE(p.hd == 32 || p.hd == 64, -1, "attention: head dim must be 32 or 64");
   dim3 grid((p.Lq + 127) / 128, p.H, p.B);
+  EC_REQUIRE(!p.o_x3 || (!p.bf16 && p.split), -1, "attention: the split output exists in the bf16x3 mode only");
   if (!p.bf16 && p.split) {
     EC_REQUIRE(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldv % 4 == 0 && p.ldo % 4 == 0, -1, "attention: strides must be multiples of 4");
     if (p.kv16) {

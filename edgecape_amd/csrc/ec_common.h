@@ -101,6 +101,15 @@ template <bool F16> __device__ __forceinline__ u32x2_t pack4_h_ovfl(f32x4 v) {
     return __builtin_bit_cast(u32x2_t, __builtin_convertvector(v, bf16v4_));
   }
 }
+// bf16 SPLIT of four fp32 values (the K-concatenated form of the bf16x3 backbone, ec_model.hip run_backbone): hi = bf16(v) (RNE),
+// lo = bf16(v - hi); v = hi + lo to ~2^-17 |v|.  An infinite v gives lo = NaN: the products come out NaN, as with any infinite operand.
+__device__ __forceinline__ void split4_bf16(f32x4 v, u32x2_t& hi, u32x2_t& lo) {
+  hi = pack4_h_ovfl<false>(v);
+  f32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = v[e] - __uint_as_float((e & 1) ? (hi[e >> 1] & 0xffff0000u) : (hi[e >> 1] << 16));
+  lo = pack4_h_ovfl<false>(r);
+}
 template <bool F16> __device__ __forceinline__ bf16_t f2h(float f) {
   if constexpr (F16) return __builtin_bit_cast(bf16_t, (_Float16)sat_h16(f));
   else return __builtin_bit_cast(bf16_t, (__bf16)f);
@@ -201,6 +210,8 @@ struct GemmP {
   int period = 1;
   int act = ACT_NONE;
   int c_bf16 = 0;   // store C as bf16
+  int c_x3 = 0;     // store C as the bf16 split [hi | lo | hi] of the fp32 result (split4_bf16): 16-bit rows of stride ldc, the three
+                    // planes N elements apart (ldc >= 3 N) - the A operand of a following K-concatenated bf16x3 GEMM; exact GELU
   int ab_bf16 = 0;  // A and B are 16-bit (else fp32)
   int h_f16 = 0;    // the 16-bit format (operands and, with c_bf16, the output) is IEEE fp16 instead of bf16
   int split = 0;    // 1 = bf16x3: A fp32, B pre-split into [32 hi | 32 lo] bf16 per 32-k block (split_pack_weights);
@@ -252,6 +263,8 @@ struct AttnP {
   int f16 = 0;                                  // ... in IEEE fp16 instead of bf16
   int split = 0;                                // fp32 data, bf16x3 MFMAs (head throughput mode)
   int one = 0;                                  // split mode only: ONE fp16 MFMA per product instead of three bf16 ones (mixed head, see ec_attn.hip)
+  int o_x3 = 0;                                 // split mode only: O is written as the bf16 split [hi | lo | hi] (split4_bf16): 16-bit rows of
+                                                // stride ldo (sO in the same units), planes H * hd elements apart
   int kv16 = 0;                                 // split mode only: K and V are IEEE fp16 (ldk / ldv / sK / sV in fp16 elements), Q and O fp32
 };
 int attention(const AttnP& p, hipStream_t st);

@@ -136,11 +136,18 @@ __device__ __forceinline__ void g8_epilogue_generic(const GemmP& p, f32x4 (&acc)
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       } else if (p.act == ACT_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = p.c_bf16 ? gelu_fast8<F16>(v[e]) : gelu_erf(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = p.c_bf16 ? gelu_fast8<F16>(v[e]) : p.c_x3 ? gelu_fast32(v[e]) : gelu_erf(v[e]);
       }
       v *= gam4[ni];
       if (p.resid) v += *(const f32x4*)(p.resid + (long)m * p.ldr + n);
-      if (p.c_bf16) {
+      if (p.c_x3) {   // bf16 split [hi | lo | hi], planes N apart: the A operand of the next K-concatenated GEMM (fc1 -> fc2, bf16x3 backbone)
+        u32x2_t vh, vl;
+        split4_bf16(v, vh, vl);
+        bf16_t* c = (bf16_t*)p.C + (long)m * p.ldc + n;
+        *(u32x2_t*)c = vh;
+        *(u32x2_t*)(c + p.N) = vl;
+        *(u32x2_t*)(c + 2 * p.N) = vh;
+      } else if (p.c_bf16) {
         *(u32x2*)((char*)p.C + ((long)m * p.ldc + n) * 2) = pack4_h_ovfl<F16>(v);
       } else {
         *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = v;

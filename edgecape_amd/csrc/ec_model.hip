@@ -45,6 +45,7 @@ struct Lin {  // a Linear layer view: W [N,K] (+ optional bf16 copy), bias [N]
   const void* wc = nullptr;    // ... and its fragment-major packing for the row-chain kernel (ec_chain.hip), head only
   const bf16_t* wf16 = nullptr;  // plain IEEE fp16 [N, K] copy (single-pass fp16 layers of the head's mixed precision): the 8-phase 16-bit
                                // GEMM runs the large image-row projections of the skeleton head on it when a 16-bit copy of A exists
+  const bf16_t* w16x3 = nullptr; // bf16 [N, 3 K] = [W_hi | W_hi | W_lo]: K-concatenated bf16x3 operand of the 8-phase GEMM (EC_BF16X3 backbone)
   const float* b = nullptr;
   int N = 0, K = 0;
   bool w16_is_f16 = false;     // w16 holds IEEE fp16 (EC_F16 backbone) instead of bf16
@@ -84,6 +85,7 @@ struct ec_model {
   bool bb16 = false;         // backbone GEMM operands / activations are 16-bit ...
   bool bbf16 = false;        // ... in IEEE fp16 (EC_F16) instead of bf16 (EC_BF16)
   bool bb_split = false;     // EC_BF16X3 backbone: fp32 activations, every MFMA operand split hi+lo bf16 (3 MFMAs per product)
+  bool bb_x3 = false;        // ... its block GEMMs in the K-CONCATENATED form on the 8-phase 16-bit kernel (run_backbone); EC_BB_X3=0: A/B
   bool head_split = false;   // head GEMMs in bf16x3 (ec_gemm.hip GM_SPLIT)
   bool head_mixed = false;   // ... except the Linear layers of the skeleton head and the decoder layers: single-pass fp16 (GM_SPLIT1)
   bool cur_h1 = false;       // build time: the Lin being made belongs to that set
@@ -249,6 +251,26 @@ static int upload_split(ec_model* m, const float* W, long rows, long K, const fl
   else split_pack_weights(W, rows, K, packed.data());
   return upload(m, packed, out);
 }
+// K-concatenated bf16x3 operand: row n = [W_hi | W_hi | W_lo] (bf16, 3 K long).  Against activation rows [a_hi | a_lo | a_hi] ONE 16-bit
+// GEMM of depth 3 K adds a_hi W_hi + a_lo W_hi + a_hi W_lo in its fp32 accumulators - the three products of the bf16x3 mode (the
+// lo x lo term, ~2^-16 of the product, is dropped there as well).
+static int upload_x3(ec_model* m, const float* W, long rows, long K, const bf16_t** out) {
+  std::vector<bf16_t> w3((size_t)rows * 3 * K);
+  for (long n = 0; n < rows; ++n) {
+    bf16_t* row = &w3[(size_t)n * 3 * K];
+    for (long k = 0; k < K; ++k) {
+      const float w = W[n * K + k];
+      const bf16_t h = f2bf(w);
+      row[k] = h; row[K + k] = h; row[2 * K + k] = f2bf(w - bf2f(h));
+    }
+  }
+  bf16_t* p3 = nullptr;
+  int rc = dalloc(m, &p3, w3.size());
+  if (rc) return rc;
+  EC_HIP(hipMemcpy(p3, w3.data(), w3.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+  *out = p3;
+  return 0;
+}
 // fragment-major split packing for the row-chain kernel; shapes the kernel cannot take simply get no such copy
 static int upload_chain(ec_model* m, const float* W, long rows, long K, const void** out) {
   if (rows % 32 != 0 || K % 128 != 0) return 0;
@@ -288,6 +310,7 @@ static int make_lin(ec_model* m, const std::string& wname, const std::string& bn
     if (rc) return rc;
     if (m->head_chain && name_is_head(wname) && (rc = upload_chain(m, w->host.data(), out->N, out->K, &out->wc))) return rc;
     out->h1 = m->cur_h1 && name_is_head(wname);
+    if (m->bb_x3 && !name_is_head(wname) && (rc = upload_x3(m, w->host.data(), out->N, out->K, &out->w16x3))) return rc;
   }
   return 0;
 }
@@ -460,6 +483,21 @@ static int linear(const void* A, long lda, bool a16, const Lin& W, void* C, long
   return gemm_nt(p, st);
 }
 
+// K-concatenated bf16x3 Linear: A = bf16 [M, 3 K] planes [hi | lo | hi] (row stride 3 K), W.w16x3; C fp32, or (c_x3) the split planes
+// of the result, row stride ldc
+static int linear_x3(const void* A, const Lin& W, void* C, long ldc, bool c_x3, int M, int act, hipStream_t st, const float* gamma,
+                     const float* resid, long ldr, int tag) {
+  EC_REQUIRE(W.w16x3 != nullptr, EC_ERR_STATE, "linear_x3: K-concatenated weight copy was not built");
+  GemmP p;
+  p.tag = tag;
+  p.A = A; p.lda = 3l * W.K; p.ab_bf16 = 1; p.h_f16 = 0;
+  p.B = W.w16x3; p.ldb = 3l * W.K;
+  p.C = C; p.ldc = ldc; p.c_x3 = c_x3 ? 1 : 0;
+  p.bias = W.b; p.gamma = gamma; p.resid = resid; p.ldr = ldr;
+  p.M = M; p.N = W.N; p.K = 3 * W.K; p.act = act;
+  return gemm_nt(p, st);
+}
+
 static int ln(const float* x, long ldx, void* y, long ldy, int y16, const Norm& n, int rows, int cols, float eps, hipStream_t st,
               int drop_period = 0, const void* add = nullptr, long ldadd = 0, const void* add2 = nullptr, bool write_x = true,
               int add_fmt = 0) {
@@ -520,11 +558,14 @@ static int run_backbone(ec_model* m, const float* const* imgs, const int* counts
   int* const sched = (m->g8_dyn_mode == 1 || (m->g8_dyn_mode == 2 && m->dq_active)) ? m->g8_sched : nullptr;
   for (size_t i = 0; i < m->blocks.size(); ++i) {
     const BBlock& b = m->blocks[i];
-    RUN(ln(m->bb_x, C, m->bb_xn, C, hfmt, b.n1, (int)M, C, 1e-6f, st, 0, pend, C, pend2));
+    const bool x3 = m->bb_x3;
+    RUN(ln(m->bb_x, C, m->bb_xn, x3 ? 3 * C : C, x3 ? 3 : hfmt, b.n1, (int)M, C, 1e-6f, st, 0, pend, C, pend2));
     pend = pend2 = nullptr;
     const bool prof = m->prof_on && (m->prof_mode != 2 || i == m->prof_pass % m->blocks.size()) && m->prof_used + 2 <= m->prof_ev.size();
     if (prof) EC_HIP(hipEventRecord(m->prof_ev[m->prof_used++], st));
-    {
+    if (x3) {
+      RUN(linear_x3(m->bb_xn, b.qkv, m->bb_qkv, 3 * C, false, (int)M, ACT_NONE, st, nullptr, nullptr, 0, 1));
+    } else {
       GemmP p;
       p.tag = 1;
       p.A = m->bb_xn; p.lda = C; p.ab_bf16 = h16; p.h_f16 = m->bbf16;
@@ -543,8 +584,17 @@ static int run_backbone(ec_model* m, const float* const* imgs, const int* counts
     a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
     a.sQ = a.sK = a.sV = (long)T * 3 * C; a.sO = (long)T * C;
     a.B = n; a.H = nh; a.Lq = T; a.Lk = T; a.hd = C / nh; a.bf16 = h16; a.f16 = m->bbf16; a.split = m->bb_split ? 1 : 0;
+    if (x3) { a.o_x3 = 1; a.ldo = 3 * C; a.sO = (long)T * 3 * C; }
     RUN(attention(a, st));
-    if (h16) {
+    if (x3) {
+      // K-concatenated bf16x3 (round 5): every block GEMM is ONE 16-bit GEMM of depth 3 K on the 8-phase kernel - activations as bf16
+      // [hi | lo | hi] planes written by their producers (LayerNorm, attention, the fc1 epilogue), weights [W_hi | W_hi | W_lo] - with the
+      // fp32 epilogue of the exact mode (residual added in place); the same three products per multiply as the split-on-load kernel
+      RUN(linear_x3(m->bb_att, b.proj, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls1, m->bb_x, C, 2));
+      RUN(ln(m->bb_x, C, m->bb_xn, 3 * C, 3, b.n2, (int)M, C, 1e-6f, st));
+      RUN(linear_x3(m->bb_xn, b.fc1, m->bb_h, 12 * C, true, (int)M, ACT_GELU, st, nullptr, nullptr, 0, 3));
+      RUN(linear_x3(m->bb_h, b.fc2, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls2, m->bb_x, C, 4));
+    } else if (h16) {
       RUN(linear(m->bb_att, C, true, b.proj, m->bb_y, C, true, (int)M, ACT_NONE, st, b.ls1, nullptr, 0, nullptr, 0, 1, nullptr, 0, 2));
       RUN(ln(m->bb_x, C, m->bb_xn, C, hfmt, b.n2, (int)M, C, 1e-6f, st, 0, m->bb_y, C, nullptr, false));
       RUN(linear(m->bb_xn, C, true, b.fc1, m->bb_h, 4 * C, true, (int)M, ACT_GELU, st, nullptr, nullptr, 0, nullptr, 0, 1, nullptr, 0, 3, sched));
@@ -1638,6 +1688,7 @@ int ec_create(const ec_config* cfg, ec_handle* out) {
   EC_REQUIRE(cfg->backbone_precision >= EC_F32 && cfg->backbone_precision <= EC_F16, EC_ERR_ARG,
              "backbone_precision: EC_F32 (exact), EC_BF16X3 (split bf16, fp32-class), EC_BF16 or EC_F16 (16-bit MFMA operands)");
   m->bb_split = cfg->backbone_precision == EC_BF16X3;
+  m->bb_x3 = m->bb_split && cfg->embed_dim % 128 == 0 && !(getenv("EC_BB_X3") && atoi(getenv("EC_BB_X3")) == 0);
   m->bb16 = cfg->backbone_precision == EC_BF16 || cfg->backbone_precision == EC_F16;
   m->bbf16 = cfg->backbone_precision == EC_F16;
   m->head_split = cfg->head_precision == EC_BF16X3 || cfg->head_precision == EC_MIXED;
@@ -1837,12 +1888,13 @@ int ec_finalize(ec_handle m) {
   const size_t es = m->bb16 ? 2 : 4;
   const size_t MT = (size_t)n * T;
   if ((rc = dalloc(m, &m->bb_x, MT * C))) return rc;
-  if ((rc = dmalloc(m, &m->bb_xn, MT * C * es))) return rc;
+  const size_t es3 = m->bb_x3 ? 6 : es;   // K-concatenated bf16x3: three bf16 planes per activation value
+  if ((rc = dmalloc(m, &m->bb_xn, MT * C * es3))) return rc;
   if ((rc = dmalloc(m, &m->bb_qkv, MT * 3 * C * es))) return rc;
-  if ((rc = dmalloc(m, &m->bb_att, MT * C * es))) return rc;
+  if ((rc = dmalloc(m, &m->bb_att, MT * C * es3))) return rc;
   if (m->bb16 && (rc = dmalloc(m, &m->bb_y, MT * C * 2))) return rc;
   if (m->bb16 && (rc = dmalloc(m, &m->bb_y2, MT * C * 2))) return rc;
-  if ((rc = dmalloc(m, &m->bb_h, std::max(MT * 4 * C, MT * 3 * m->Kp) * es))) return rc;
+  if ((rc = dmalloc(m, &m->bb_h, std::max(MT * 4 * C * es3, MT * 3 * m->Kp * es)))) return rc;
   if ((rc = dalloc(m, &m->feat, (size_t)n * HW * C))) return rc;
   if ((rc = dalloc(m, &m->feat_nchw_tmp, (size_t)n * HW * C))) return rc;
   if ((rc = dalloc(m, &m->d_off, (size_t)bs + 1))) return rc;

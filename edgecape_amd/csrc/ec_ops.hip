@@ -11,7 +11,8 @@ namespace {
 // LayerNorm: one wave per row, float4 loads, values kept in registers (cols <= 1024).
 // Reference: DINOv2 norm1/norm2/norm (eps 1e-6), head LayerNorms (eps 1e-5, encoder_decoder.py:450-451,566-576).
 // ------------------------------------------------------------------------------------------------
-// OUT: 0 = fp32 output, 1 = bf16, 2 = IEEE fp16 (the fused branch inputs `add` / `add2` are in the same 16-bit format)
+// OUT: 0 = fp32 output, 1 = bf16, 2 = IEEE fp16 (the fused branch inputs `add` / `add2` are in the same 16-bit format),
+//      3 = bf16 split [hi | lo | hi] in three planes `cols` elements apart (ldy >= 3 cols): the A operand of a K-concatenated bf16x3 GEMM
 template <int OUT, bool ADD, bool ADD_F16 = (OUT == 2)>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnP p) {
   constexpr bool OUT_BF16 = OUT != 0;
@@ -70,7 +71,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnP p) {
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * w[e] + b[e];
-      if (OUT_BF16) {
+      if constexpr (OUT == 3) {
+        bf16_t* y = (bf16_t*)p.y + orow * p.ldy + c;
+        u32x2_t hi, lo;
+        split4_bf16(o, hi, lo);
+        *(u32x2_t*)y = hi;
+        *(u32x2_t*)(y + p.cols) = lo;
+        *(u32x2_t*)(y + 2 * p.cols) = hi;
+      } else if (OUT_BF16) {
         bf16_t* y = (bf16_t*)p.y + orow * p.ldy + c;
         *(u32x2_t*)y = pack4_h<F16>(o);
       } else {
@@ -778,7 +786,10 @@ int layernorm(const LnP& p, hipStream_t st) {
   // y_bf16: 0 fp32, 1 bf16, 2 fp16 output; a fused branch add is 16-bit in add_fmt's format (defaults to the output's, bf16 if fp32)
   const int afmt = p.add_fmt ? p.add_fmt : (p.y_bf16 ? p.y_bf16 : 1);
   EC_REQUIRE(!p.add || p.y_bf16 == 0 || afmt == p.y_bf16, -1, "layernorm: fused add and output must share the 16-bit format");
-  if (p.add) {
+  if (p.y_bf16 == 3) {
+    EC_REQUIRE(!p.add && p.ldy >= 3 * (long)p.cols, -1, "layernorm: split output takes no fused add and needs ldy >= 3 cols");
+    hipLaunchKernelGGL((layernorm_kernel<3, false>), grid, dim3(256), 0, st, p);
+  } else if (p.add) {
     if (p.y_bf16 == 2) hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, dim3(256), 0, st, p);
     else if (p.y_bf16 == 1) hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, dim3(256), 0, st, p);
     else if (afmt == 2) hipLaunchKernelGGL((layernorm_kernel<0, true, true>), grid, dim3(256), 0, st, p);
