@@ -512,8 +512,22 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  // XCD-aware workgroup map, as in attn_bf16_kernel (1-D launch: the query blocks of one (image, head) on consecutive slots of ONE XCD,
+  // so its K / V - fp32 here, twice the bytes - go through one L2 once instead of through three).  bf16x3 backbone, cfg2: see DESIGN 8c.
+  int item, qb;
+  {
+    const int nqb = (p.Lq + 127) >> 7, NI = p.H * p.B, L = blockIdx.x;
+    const int Gm = (NI >> 3) * 8 * nqb;
+    if (L < Gm) {
+      const int slot = L >> 3, grp = slot / nqb;
+      item = grp * 8 + (L & 7); qb = slot - grp * nqb;
+    } else {
+      const int Lt = L - Gm, it = Lt / nqb;
+      item = (NI & ~7) + it; qb = Lt - it * nqb;
+    }
+  }
+  const int b = item / p.H, h = item - b * p.H;
+  const int q0 = qb * 128 + wave * 32;
   const float* Q = (const float*)p.Q + (long)b * p.sQ + h * HD;
   const kv_t* K = (const kv_t*)p.K + (long)b * p.sK + h * HD;
   const kv_t* V = (const kv_t*)p.V + (long)b * p.sV + h * HD;
@@ -745,15 +759,16 @@ int attention(const AttnP& p, hipStream_t st) {
   EC_REQUIRE(!p.o_x3 || (!p.bf16 && p.split), -1, "attention: the split output exists in the bf16x3 mode only");
   if (!p.bf16 && p.split) {
     EC_REQUIRE(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldv % 4 == 0 && p.ldo % 4 == 0, -1, "attention: strides must be multiples of 4");
+    const dim3 g1(grid.x * grid.y * grid.z);   // 1-D: the kernel maps the id to (query block, head, image) itself (XCD-aware)
     if (p.kv16) {
       EC_REQUIRE(p.hd == 64, -1, "attention: fp16 K / V only for head dim 64 (the token -> image cross attention)");
-      if (p.one) hipLaunchKernelGGL((attn_split_kernel<64, true, true>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((attn_split_kernel<64, true>), grid, dim3(256), 0, st, p);
+      if (p.one) hipLaunchKernelGGL((attn_split_kernel<64, true, true>), g1, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((attn_split_kernel<64, true>), g1, dim3(256), 0, st, p);
     } else if (p.one) {
-      if (p.hd == 64) hipLaunchKernelGGL((attn_split_kernel<64, false, true>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((attn_split_kernel<32, false, true>), grid, dim3(256), 0, st, p);
-    } else if (p.hd == 64) hipLaunchKernelGGL((attn_split_kernel<64>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((attn_split_kernel<32>), grid, dim3(256), 0, st, p);
+      if (p.hd == 64) hipLaunchKernelGGL((attn_split_kernel<64, false, true>), g1, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((attn_split_kernel<32, false, true>), g1, dim3(256), 0, st, p);
+    } else if (p.hd == 64) hipLaunchKernelGGL((attn_split_kernel<64>), g1, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_split_kernel<32>), g1, dim3(256), 0, st, p);
     EC_LAUNCH_CHECK();
     return 0;
   }

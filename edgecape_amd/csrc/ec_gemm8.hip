@@ -70,7 +70,14 @@ constexpr int G8_AHEAD = 5;               // half-tiles the load stream runs ahe
 // Epilogue kinds (compile-time): the three shapes of the bf16 backbone blocks + a generic one (every GemmP option).
 // G8_TAB_*: C = acc + bias[n] + table[m % period][n] (the patch embedding's positional table; the head's image K|V / image-query
 // projections, whose positional half is folded into such a table), fp32 or 16-bit output, through the staged whole-line epilogue.
-enum { G8_GENERIC = 0, G8_BIAS_BF16 = 1, G8_SCALE_BF16 = 2, G8_GELU_BF16 = 3, G8_TAB_H16 = 4, G8_TAB_F32 = 5 };
+// G8_F32 / G8_RES_F32 / G8_GELU_X3 (round 5): the epilogues of the K-CONCATENATED bf16x3 backbone (ec_model.hip run_backbone: A = bf16
+// [hi | lo | hi] planes, B = [W_hi | W_hi | W_lo], K = 3 x the layer's depth), through the same staged whole-line pieces:
+//   G8_F32      C = acc + bias, fp32 (QKV)
+//   G8_RES_F32  C = (acc + bias) * gamma + C, fp32, in place (proj / fc2: LayerScale + the fp32 residual stream; resid == C)
+//   G8_GELU_X3  C = bf16 split planes [hi | lo | hi] of gelu(acc + bias), N elements apart (fc1: the A operand of fc2)
+// (the generic kind did this first: 12 spilled VGPRs, fragment-wise quarter-line stores - QKV 227 us, fc1 343 us at cfg2)
+enum { G8_GENERIC = 0, G8_BIAS_BF16 = 1, G8_SCALE_BF16 = 2, G8_GELU_BF16 = 3, G8_TAB_H16 = 4, G8_TAB_F32 = 5, G8_F32 = 6, G8_RES_F32 = 7, G8_GELU_X3 = 8 };
+constexpr bool g8_f32_out(int kind) { return kind == G8_TAB_F32 || kind == G8_F32 || kind == G8_RES_F32; }
 
 // GELU for 16-bit outputs (erf form: nn.GELU default, dinov2 Mlp) with ONE transcendental (round 4):
 //     gelu(x) = x Phi(x) = max(x, 0) - |x| Phi(-|x|),      Phi(-a) = 2^L(a),  L(a) = log2 Phi(-a)  smooth and concave on a >= 0
@@ -173,9 +180,78 @@ __device__ __forceinline__ void g8_epilogue_generic(const GemmP& p, f32x4 (&acc)
 template <int KIND, bool F16, int LAB>
 __device__ __forceinline__ void g8_piece(f32x4 (&a)[4], const __amdgpu_buffer_rsrc_t rsC, unsigned goff, unsigned ldc2, bool col_ok, char* stg,
                                          const char* bias_lds, const char* gam_lds, int lane, const float* trow = nullptr, int ncols = 64,
-                                         const char* bias_next = nullptr) {
+                                         const char* bias_next = nullptr, unsigned plane = 0) {
   const int wrow = lane & 15, wq = lane >> 4;                       // writer: fragment row, column quad
   const int rrow = lane >> 3, rch = lane & 7;                       // reader: row within 8, 16-byte chunk
+  if constexpr (KIND == G8_F32 || KIND == G8_RES_F32) {
+    // fp32 output as in G8_TAB_F32 (two halves of 16 rows x 32 columns through the 2 KiB slot, whole-line stores).  G8_RES_F32: the
+    // residual is C itself - it is loaded in the STORE layout (the same 16 bytes per lane that the lane writes afterwards: whole lines,
+    // no address arithmetic of its own, in-place safe) at the top of the piece and added behind the transposition
+    u32x4 r[2][2];
+    if constexpr (KIND == G8_RES_F32) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          r[half][j] = __builtin_amdgcn_raw_buffer_load_b128(rsC, half * 32 + rch * 4 < ncols ? goff + (unsigned)(j * 8) * ldc2 + (unsigned)(half * 128) : 0xFFFFFFF0u, 0, 0);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int ni = half * 2 + q;
+        const int c0 = half * 32 + q * 16 + wq * 4;
+        f32x4 v = a[ni] + *(const f32x4*)(bias_lds + c0 * 4);
+        if constexpr (KIND == G8_RES_F32) v *= *(const f32x4*)(gam_lds + c0 * 4);
+        *(f32x4*)(stg + wrow * 128 + (((q * 4 + wq) ^ (wrow & 7)) << 4)) = v;
+        a[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = j * 8 + rrow;
+        f32x4 o = *(const f32x4*)(stg + row * 128 + ((rch ^ (row & 7)) << 4));
+        if constexpr (KIND == G8_RES_F32) o += __builtin_bit_cast(f32x4, r[half][j]);
+        const bool ok = half * 32 + rch * 4 < ncols;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsC, ok ? goff + (unsigned)(j * 8) * ldc2 + (unsigned)(half * 128) : 0xFFFFFFF0u, 0, 0);
+      }
+    }
+    return;
+  }
+  if constexpr (KIND == G8_GELU_X3) {
+    // fc1 of the K-concatenated bf16x3 backbone: gelu(acc + bias) (single-transcendental form, 6.4e-7), split into bf16 hi + lo, the hi
+    // plane staged and stored twice (planes 0 and 2), then the lo plane (plane 1): 6 whole-line stores per piece
+    u32x2_t vh[4], vl[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int c0 = (ni >> 1) * 32 + (ni & 1) * 16 + wq * 4;
+      f32x4 v = a[ni] + *(const f32x4*)(bias_lds + c0 * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_fast8<true>(v[e]);
+      split4_bf16(v, vh[ni], vl[ni]);
+      a[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int chunk = (ni >> 1) * 4 + (ni & 1) * 2 + (wq >> 1);
+        *(u32x2_t*)(stg + wrow * 128 + ((chunk ^ (wrow & 7)) << 4) + (wq & 1) * 8) = pl ? vl[ni] : vh[ni];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = j * 8 + rrow;
+        const u32x4 o = *(const u32x4*)(stg + row * 128 + ((rch ^ (row & 7)) << 4));
+        const unsigned off = goff + (unsigned)(j * 8) * ldc2;
+        if (pl == 0) {
+          __builtin_amdgcn_raw_buffer_store_b128(o, rsC, col_ok ? off : 0xFFFFFFF0u, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(o, rsC, col_ok ? off + 2u * plane : 0xFFFFFFF0u, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(o, rsC, col_ok ? off + plane : 0xFFFFFFF0u, 0, 0);
+        }
+      }
+    }
+    return;
+  }
   if constexpr (KIND == G8_TAB_F32) {
     // fp32 output: the 2 KiB staging slot takes 16 rows x 32 columns, so a piece leaves in two halves of two stores each (8 rows x
     // 128 B = whole lines; the generic epilogue's fragment-wise stores are 16 rows x 64 B, half lines at twice the cost per byte)
@@ -319,8 +395,9 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool FAST = KIND != G8_GENERIC && !(LAB & 32);   // bias from LDS, epilogue pieces through the staging slot
   constexpr bool NODRAIN = FAST && !(LAB & 64);              // the load stream is not drained at the seam
-  constexpr int NB = KIND == G8_SCALE_BF16 ? 2 : 1;          // LDS-DMA pieces of one bias (+ LayerScale) slice
-  constexpr int NST = KIND == G8_TAB_F32 ? 32 : 16;          // global stores of one tile's epilogue per wave
+  constexpr bool GAMMA = KIND == G8_SCALE_BF16 || KIND == G8_RES_F32;
+  constexpr int NB = GAMMA ? 2 : 1;                          // LDS-DMA pieces of one bias (+ LayerScale) slice
+  constexpr int NST = KIND == G8_GELU_X3 ? 48 : g8_f32_out(KIND) ? 32 : 16;   // global stores of one tile's epilogue per wave
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -456,7 +533,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
       const unsigned vo = (unsigned)(((t % ntn) << 8) + wc * 64 + g8_lane_now()) * 4u;
       const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.N * 4, 0x00020000);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lptr_t)(smem + G8_BIAS + (parity * 8 + wave) * 256), 4, vo, 0, 0, 0);
-      if constexpr (KIND == G8_SCALE_BF16) {
+      if constexpr (GAMMA) {
         const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gamma), 0, p.N * 4, 0x00020000);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rg_, (lptr_t)(smem + G8_GAMMA + (parity * 8 + wave) * 256), 4, vo, 0, 0, 0);
       }
@@ -506,7 +583,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
     }
   bf16x8 af[4][2], b0[2][2], b1[2][2];
 
-  const unsigned ldc2 = (unsigned)p.ldc * (KIND == G8_TAB_F32 ? 4u : 2u);   // row pitch of C in bytes
+  const unsigned ldc2 = (unsigned)p.ldc * (g8_f32_out(KIND) ? 4u : 2u);   // row pitch of C in bytes
   const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((unsigned)p.M * ldc2), 0x00020000);   // (host: < 2 GiB)
   auto pieces = [&](int mi0, int m0, int n0, int par) {   // pieces mi0, mi0 + 1 of tile (m0, n0)
     if constexpr (FAST) {
@@ -525,7 +602,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
         }
       } else {
         const bool col_ok = n0 + wc * 64 + (lane & 7) * 8 < p.N;
-        constexpr unsigned esz = KIND == G8_TAB_F32 ? 4u : 2u;
+        constexpr unsigned esz = g8_f32_out(KIND) ? 4u : 2u;
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
           const int r0 = m0 + wr * 128 + (mi0 + d) * 16;
@@ -533,6 +610,9 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
           if constexpr (KIND == G8_TAB_H16 || KIND == G8_TAB_F32) {
             const float* trow = p.table + (long)((r0 + (lane & 15)) % p.period) * p.ldt + n0 + wc * 64;
             g8_piece<KIND, F16, LAB>(acc[mi0 + d], rsC, goff, ldc2, col_ok, stg, bl, gl, lane, trow, min(max(p.N - n0 - wc * 64, 0), 64));
+          } else if constexpr (KIND == G8_F32 || KIND == G8_RES_F32 || KIND == G8_GELU_X3) {
+            g8_piece<KIND, F16, LAB>(acc[mi0 + d], rsC, goff, ldc2, col_ok, stg, bl, gl, lane, nullptr, min(max(p.N - n0 - wc * 64, 0), 64), nullptr,
+                                     (unsigned)p.N * 2u);
           } else {
             g8_piece<KIND == G8_GENERIC ? G8_BIAS_BF16 : KIND, F16, LAB>(acc[mi0 + d], rsC, goff, ldc2, col_ok, stg, bl, gl, lane, nullptr, 64, bn);
           }
@@ -744,15 +824,25 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
   } else if (p.table && !p.resid && !p.gamma && !p.aux && p.act == ACT_NONE && p.period > 0 && p.ldt % 4 == 0 && p.ldc % 4 == 0 &&
              (long)p.M * p.ldc * (p.c_bf16 ? 2 : 4) < (1l << 31)) {
     kind = p.c_bf16 ? G8_TAB_H16 : G8_TAB_F32;   // (the A/B switch back to the generic epilogue, EC_G8_TAB, went in round 5)
+  } else if (p.c_x3 && !p.h_f16 && p.bias && p.act == ACT_GELU && !p.gamma && !p.resid && !p.table && (long)p.M * p.ldc * 2 < (1l << 31)) {
+    kind = G8_GELU_X3;
+  } else if (!p.c_bf16 && !p.c_x3 && p.bias && !p.table && !p.aux && p.act == ACT_NONE && p.ldc % 4 == 0 && (long)p.M * p.ldc * 4 < (1l << 31)) {
+    static const bool x3epi = !(getenv("EC_G8_X3EPI") && atoi(getenv("EC_G8_X3EPI")) == 0);   // A/B: 0 = the generic epilogue
+    if (x3epi && !p.resid && !p.gamma) kind = G8_F32;
+    else if (x3epi && p.resid == (const float*)p.C && p.ldr == p.ldc && p.gamma) kind = G8_RES_F32;
   }
+  if (kind == G8_GELU_X3 && getenv("EC_G8_X3EPI") && atoi(getenv("EC_G8_X3EPI")) == 0) kind = G8_GENERIC;
 #define G8_ROW(F) \
       {gemm8_bf16_kernel<0, 0, F>, gemm8_bf16_kernel<0, 1, F>, gemm8_bf16_kernel<0, 2, F>, gemm8_bf16_kernel<0, 3, F>, gemm8_bf16_kernel<0, 4, F>}, \
       {gemm8_bf16_kernel<1, 0, F>, gemm8_bf16_kernel<1, 1, F>, gemm8_bf16_kernel<1, 0, F>, gemm8_bf16_kernel<1, 0, F>, gemm8_bf16_kernel<1, 0, F>}, \
       {gemm8_bf16_kernel<2, 0, F>, gemm8_bf16_kernel<2, 0, F>, gemm8_bf16_kernel<2, 2, F>, gemm8_bf16_kernel<2, 0, F>, gemm8_bf16_kernel<2, 4, F>}, \
       {gemm8_bf16_kernel<3, 0, F>, gemm8_bf16_kernel<3, 0, F>, gemm8_bf16_kernel<3, 0, F>, gemm8_bf16_kernel<3, 3, F>, gemm8_bf16_kernel<3, 0, F>}, \
       {gemm8_bf16_kernel<4, 0, F>, gemm8_bf16_kernel<4, 0, F>, gemm8_bf16_kernel<4, 0, F>, gemm8_bf16_kernel<4, 0, F>, gemm8_bf16_kernel<4, 0, F>}, \
-      {gemm8_bf16_kernel<5, 0, F>, gemm8_bf16_kernel<5, 0, F>, gemm8_bf16_kernel<5, 0, F>, gemm8_bf16_kernel<5, 0, F>, gemm8_bf16_kernel<5, 0, F>}
-  static const kern_t table[2][6][5] = {{G8_ROW(false)}, {G8_ROW(true)}};
+      {gemm8_bf16_kernel<5, 0, F>, gemm8_bf16_kernel<5, 0, F>, gemm8_bf16_kernel<5, 0, F>, gemm8_bf16_kernel<5, 0, F>, gemm8_bf16_kernel<5, 0, F>}, \
+      {gemm8_bf16_kernel<6, 0, F>, gemm8_bf16_kernel<6, 1, F>, gemm8_bf16_kernel<6, 0, F>, gemm8_bf16_kernel<6, 0, F>, gemm8_bf16_kernel<6, 0, F>}, \
+      {gemm8_bf16_kernel<7, 0, F>, gemm8_bf16_kernel<7, 0, F>, gemm8_bf16_kernel<7, 2, F>, gemm8_bf16_kernel<7, 0, F>, gemm8_bf16_kernel<7, 4, F>}, \
+      {gemm8_bf16_kernel<8, 3, false>, gemm8_bf16_kernel<8, 3, false>, gemm8_bf16_kernel<8, 3, false>, gemm8_bf16_kernel<8, 3, false>, gemm8_bf16_kernel<8, 3, false>}
+  static const kern_t table[2][9][5] = {{G8_ROW(false)}, {G8_ROW(true)}};
 #undef G8_ROW
   int dev = 0;
   EC_HIP(hipGetDevice(&dev));
@@ -760,7 +850,7 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
   G8Dev& ds = g8_dev[dev];
   if (!ds.attr_done) {
     for (int f = 0; f < 2; ++f)
-      for (int k = 0; k < 6; ++k)
+      for (int k = 0; k < 9; ++k)
         for (int t = 0; t < 5; ++t)
           EC_HIP(hipFuncSetAttribute((const void*)table[f][k][t], hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));
     EC_HIP(hipMalloc((void**)&ds.zeros, 16384 * sizeof(float)));

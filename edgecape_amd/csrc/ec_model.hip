@@ -531,16 +531,17 @@ static int run_backbone(ec_model* m, const float* const* imgs, const int* counts
   // of the error variance of the backbone's features (oracle/precision_sites.py) - every later block inherits it through the residual
   // stream - for 0.5 % of the FLOPs: with [hi | lo | hi] patches against [W_hi | W_hi | W_lo] weights the same 8-phase GEMM, K = 3 Kp,
   // computes the products to ~2^-22.  (The bf16 backbone keeps single operands; the fp16 A/B switch EC_PATCH_X3 went in round 5.)
-  const bool px3 = m->patch_w16x3 != nullptr;
+  const bool px3 = m->patch_w16x3 != nullptr;       // fp16 backbone: fp16 planes; bf16x3 backbone (K-concatenated form): bf16 planes
+  const bool pb3 = px3 && m->bb_x3;
   const int Kpe = px3 ? 3 * m->Kp : m->Kp;
   for (int s = 0, at = 0; s < n_src; at += counts[s], ++s)
     if (counts[s] > 0)
-      RUN(im2col14(imgs[s], (char*)m->bb_h + (size_t)at * T * Kpe * (h16 ? 2 : 4), px3 ? 3 : hfmt, counts[s], m->H, m->W, m->gh, m->gw, m->Kp, st));
+      RUN(im2col14(imgs[s], (char*)m->bb_h + (size_t)at * T * Kpe * (h16 || pb3 ? 2 : 4), pb3 ? 4 : px3 ? 3 : hfmt, counts[s], m->H, m->W, m->gh, m->gw, m->Kp, st));
   {  // patch embedding: ONE GEMM over all n*T token rows (the zero cls rows produce bias + pos[0], overwritten below);
      // epilogue adds the conv bias and the positional table row m % T
     GemmP p;
-    p.A = m->bb_h; p.lda = Kpe; p.ab_bf16 = h16; p.h_f16 = m->bbf16;
-    p.split = m->bb_split ? 1 : 0;
+    p.A = m->bb_h; p.lda = Kpe; p.ab_bf16 = h16 || pb3; p.h_f16 = m->bbf16;
+    p.split = (m->bb_split && !pb3) ? 1 : 0;
     p.B = px3 ? (const void*)m->patch_w16x3 : h16 ? (const void*)m->patch.w16 : m->patch.wsel(m->bb_split); p.ldb = Kpe;
     p.C = m->bb_x; p.ldc = C;
     p.bias = m->patch.b; p.table = m->pos; p.ldt = C; p.period = T;
@@ -1776,6 +1777,7 @@ int ec_finalize(ec_handle m) {
       m->patch_w16x3 = p3;
     }
     if (m->bb_split && (rc = upload_split(m, Wp.data(), C, m->Kp, &m->patch.ws))) return rc;
+    if (m->bb_x3 && (3 * m->Kp) % 128 == 0 && (rc = upload_x3(m, Wp.data(), C, m->Kp, &m->patch_w16x3))) return rc;
     GET(cls, bp + "cls_token"); GET(pos, "@pos_table");
     m->cls = cls->dev; m->pos = pos->dev;
     if ((rc = make_norm(m, bp + "norm", &m->bnorm))) return rc;

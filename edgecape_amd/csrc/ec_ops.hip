@@ -157,7 +157,7 @@ __global__ void transpose_pad_bf16_kernel(const float* src, bf16_t* dst, int L, 
 
 // im2col for Conv2d(3, C, k=14, s=14) (DINOv2 PatchEmbed): patches[(n*gh+py)*gw+px][c*196+ky*14+kx] of an H x W image,
 // gh = H / 14, gw = W / 14 (floor: stride-14 VALID convolution), row length Kp >= 588 (zero padded) so the GEMM K is a multiple of 128 bytes.
-template <int OUT>   // 0 fp32, 1 bf16, 2 fp16, 3 fp16 split [hi | lo | hi]
+template <int OUT>   // 0 fp32, 1 bf16, 2 fp16, 3 fp16 split [hi | lo | hi], 4 bf16 split [hi | lo | hi] (bf16x3 backbone)
 __global__ __launch_bounds__(256) void im2col14_kernel(const float* img, void* out, int H, int W, int gh, int gw, int Kp) {
   // output rows are TOKEN rows: image n owns rows n*(g*g+1) .. ; row 0 of each image (the cls token) is zero-filled so the
   // patch embedding is ONE GEMM over M = n_img * T contiguous rows (its cls rows are overwritten by set_cls_rows).
@@ -180,6 +180,14 @@ __global__ __launch_bounds__(256) void im2col14_kernel(const float* img, void* o
   __syncthreads();
   if constexpr (OUT == 0) {
     for (int i = threadIdx.x; i < Kp / 4; i += blockDim.x) *(f32x4*)((float*)out + orow * Kp + i * 4) = *(const f32x4*)(px + i * 4);
+  } else if constexpr (OUT == 4) {
+    const int c4n = Kp / 4;
+    for (int i = threadIdx.x; i < c4n; i += blockDim.x) {
+      u32x2_t h, l;
+      split4_bf16(*(const f32x4*)(px + i * 4), h, l);
+      bf16_t* o = (bf16_t*)out + orow * 3 * Kp + i * 4;
+      *(u32x2_t*)o = h; *(u32x2_t*)(o + Kp) = l; *(u32x2_t*)(o + 2 * Kp) = h;
+    }
   } else if constexpr (OUT == 3) {
     // split-precision patch embedding (fp16 backbone): the row is [hi | lo | hi], hi = fp16(v), lo = fp16(v - hi); against the weight
     // rows [W_hi | W_hi | W_lo] one K = 3 Kp GEMM adds hi*W_hi + lo*W_hi + hi*W_lo - the product to ~2^-22
@@ -1002,7 +1010,8 @@ int transpose_pad_bf16(const float* src, bf16_t* dst, int B, int L, int E, int L
 int im2col14(const float* img, void* patches, int out_bf16, int n_img, int H, int W, int gh, int gw, int Kp, hipStream_t st) {
   EC_REQUIRE(Kp % 8 == 0 && Kp <= 1024, -1, "im2col14: padded row length must be a multiple of 8, at most 1024");
   const dim3 grid(n_img * (gh * gw + 1));
-  if (out_bf16 == 3) hipLaunchKernelGGL(im2col14_kernel<3>, grid, dim3(256), 0, st, img, patches, H, W, gh, gw, Kp);
+  if (out_bf16 == 4) hipLaunchKernelGGL(im2col14_kernel<4>, grid, dim3(256), 0, st, img, patches, H, W, gh, gw, Kp);
+  else if (out_bf16 == 3) hipLaunchKernelGGL(im2col14_kernel<3>, grid, dim3(256), 0, st, img, patches, H, W, gh, gw, Kp);
   else if (out_bf16 == 2) hipLaunchKernelGGL(im2col14_kernel<2>, grid, dim3(256), 0, st, img, patches, H, W, gh, gw, Kp);
   else if (out_bf16) hipLaunchKernelGGL(im2col14_kernel<1>, grid, dim3(256), 0, st, img, patches, H, W, gh, gw, Kp);
   else hipLaunchKernelGGL(im2col14_kernel<0>, grid, dim3(256), 0, st, img, patches, H, W, gh, gw, Kp);

@@ -108,6 +108,34 @@ def test_backbone_vs_oracle(arch, image_size):
     assert np.array_equal(tok.reshape(3, g, g, -1).transpose(0, 3, 1, 2), got)
 
 
+@pytest.mark.parametrize("arch,image_size,n_img", [("dinov2_vits14", 224, 2), ("dinov2_vitb14", 256, 5), ("dinov2_vits14", (224, 308), 5)])
+def test_backbone_bf16x3_kconcat_vs_oracle(arch, image_size, n_img, monkeypatch):
+    """bf16x3 backbone in its K-CONCATENATED form (round 5: activations as bf16 [hi | lo | hi] planes written by LayerNorm / attention /
+    the fc1 epilogue, weights [W_hi | W_hi | W_lo], one 16-bit GEMM of depth 3 K per Linear) against the CPU oracle and against the
+    split-on-load kernels it replaces (EC_BB_X3=0).  2 images of ViT-S: M = 514 rows, the small-M fallback (2-barrier 16-bit kernel with
+    the split-plane store); 5 images of ViT-B: M = 1625, the 8-phase kernel's fp32 / residual / GELU + split epilogues with a ragged last
+    row tile; ViT-S on a non-square image: N = 1152 / 384 / 1536, half-filled column tiles."""
+    from oracle import edgecape_oracle as orc
+    sd = synth.make_weights(arch, seed=23)
+    rng = np.random.default_rng(9)
+    img = np.stack([synth._smooth_image(rng, *image_size) if isinstance(image_size, tuple) else synth._smooth_image(rng, image_size)
+                    for _ in range(n_img)])
+    with torch.no_grad():
+        ref = orc.dinov2_features(sd, img, synth.ARCHS[arch]["heads"]).numpy()
+    scale = float(np.abs(ref).max())
+    errs = {}
+    for x3 in ("1", "0"):
+        monkeypatch.setenv("EC_BB_X3", x3)
+        eng = _engine(sd, arch, image_size, n_img, 1, backbone_precision="bf16x3", head_precision="bf16x3")
+        got = eng.backbone(img, nchw=True).cpu().numpy()
+        assert np.isfinite(got).all()
+        errs[x3] = float(np.abs(got - ref).max())
+        del eng
+    print(arch, image_size, n_img, "feature err: K-concatenated", errs["1"], "split on load", errs["0"], "scale", scale)
+    assert errs["1"] < 1e-4 * max(scale, 1.0)            # fp32 kernels: < 2e-4 (test_backbone_vs_oracle); bf16x3 sits at ~1e-5
+    assert errs["1"] < 3 * errs["0"] + 1e-5
+
+
 @pytest.mark.parametrize("arch,image_size", [("dinov2_vits14", 224), ("dinov2_vitb14", 256), ("dinov2_vitl14", 384),
                                              ("dinov2_vits14", (224, 308))])
 def test_backbone_vs_hf_golden(arch, image_size):
