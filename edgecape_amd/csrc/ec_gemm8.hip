@@ -827,11 +827,11 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
   } else if (p.c_x3 && !p.h_f16 && p.bias && p.act == ACT_GELU && !p.gamma && !p.resid && !p.table && (long)p.M * p.ldc * 2 < (1l << 31)) {
     kind = G8_GELU_X3;
   } else if (!p.c_bf16 && !p.c_x3 && p.bias && !p.table && !p.aux && p.act == ACT_NONE && p.ldc % 4 == 0 && (long)p.M * p.ldc * 4 < (1l << 31)) {
-    static const bool x3epi = !(getenv("EC_G8_X3EPI") && atoi(getenv("EC_G8_X3EPI")) == 0);   // A/B: 0 = the generic epilogue
-    if (x3epi && !p.resid && !p.gamma) kind = G8_F32;
-    else if (x3epi && p.resid == (const float*)p.C && p.ldr == p.ldc && p.gamma) kind = G8_RES_F32;
+    // (measured against the generic epilogue behind a switch that is gone again, cfg2 bf16x3 / bf16x3, interleaved on one box:
+    //  2501 / 2501 vs 2316 / 2297 pairs/s; QKV 201 vs 227 us, proj 89 vs 101, fc1 284 vs 343, fc2 238 vs 243; profiles/r05_x3_ab.txt)
+    if (!p.resid && !p.gamma) kind = G8_F32;
+    else if (p.resid == (const float*)p.C && p.ldr == p.ldc && p.gamma) kind = G8_RES_F32;
   }
-  if (kind == G8_GELU_X3 && getenv("EC_G8_X3EPI") && atoi(getenv("EC_G8_X3EPI")) == 0) kind = G8_GENERIC;
 #define G8_ROW(F) \
       {gemm8_bf16_kernel<0, 0, F>, gemm8_bf16_kernel<0, 1, F>, gemm8_bf16_kernel<0, 2, F>, gemm8_bf16_kernel<0, 3, F>, gemm8_bf16_kernel<0, 4, F>}, \
       {gemm8_bf16_kernel<1, 0, F>, gemm8_bf16_kernel<1, 1, F>, gemm8_bf16_kernel<1, 0, F>, gemm8_bf16_kernel<1, 0, F>, gemm8_bf16_kernel<1, 0, F>}, \
