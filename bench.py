@@ -253,6 +253,14 @@ def main():
                          "peak_note": "2500 / 3: three bf16 MFMAs per product"},
             "argmax_flips": conf_c.get("argmax_flips") if conf_c else None, "conformance_at_scale": conf_c,
             "note": "meets the 1e-3 coordinate tolerance on every keypoint; the headline precision meets it on all but the measured flip rate"}
+        if not args.no_episode:
+            # the reference's evaluation protocol (15 queries per support set, `episode_cached` above) in the conforming precision
+            del eng, outputs
+            torch.cuda.empty_cache()
+            eng = outputs = None
+            ep_c = episode_mode(args, sd, synth, bs, S, H, arch, apis, rank, world, precision="bf16x3", head_precision="bf16x3")
+            result["conforming_mode"]["episode_cached"] = {k: ep_c[k] for k in ("value", "unit", "queries_per_call", "calls_per_pass", "ms_per_call", "seconds",
+                                                                                 "backbone_images_per_pair", "entry_point")}
     if world == 1 and not args.no_alt and args.precision != "bf16":
         # the same step with bf16 operands (north_star's wording): same kernels and rate, 8x coarser rounding - measured beside the
         # headline so both precisions come from one process on one box; it does NOT meet the 1e-3 gate (test_bf16_mode_cfg2_bounded)
@@ -328,7 +336,7 @@ def pmc_traffic(args, bs, S, H, arch, source_hash):
             "mfma_util_pmc": d.get("mfma_util"), "traffic_source": os.path.relpath(path, ROOT)}
 
 
-def episode_mode(args, sd, synth, bs, S, H, arch, apis, rank=0, world=1, n_ep=32, qpe=15, passes=3, n_img=0):
+def episode_mode(args, sd, synth, bs, S, H, arch, apis, rank=0, world=1, n_ep=32, qpe=15, passes=3, n_img=0, precision=None, head_precision=None):
     """The reference's real evaluation protocol (not `value`): every support set is paired with 15 queries
     (EdgeCape/datasets/datasets/mp100/test_dataset.py:86-99), so `n_ep` episodes are `n_ep * 15` pairs.  Streamed through
     ec_forward_episodes: a call takes the next q queries of the pair order and encodes the episodes that start in it - their support
@@ -342,7 +350,8 @@ def episode_mode(args, sd, synth, bs, S, H, arch, apis, rank=0, world=1, n_ep=32
     n_img = n_img or args.episode_images or (1 + S) * bs
     q = max(1, n_img * qpe // (qpe + S))
     cap = (q + qpe - 1) // qpe + 2
-    eng = HipEngine(sd, arch=arch, image_size=H, max_batch=q, max_shots=S, backbone_precision=args.precision, head_precision=args.head_precision)
+    eng = HipEngine(sd, arch=arch, image_size=H, max_batch=q, max_shots=S, backbone_precision=precision or args.precision,
+                    head_precision=head_precision or args.head_precision)
     ep = np.repeat(np.arange(n_ep, dtype=np.int32), qpe)
     calls = stream_schedule(ep, q, cap)
     # synthetic data of the protocol's shape: n_ep support sets, and one pool of q query images that every call re-reads (distinct

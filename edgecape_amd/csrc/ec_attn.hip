@@ -629,7 +629,8 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
     // per lane: vector-memory instructions cost ~64 cycles of issue each), out-of-range keys count as masked
     bool lm = k0 + lane >= p.Lk;
     if (km && !lm && k0 + lane >= p.mask_start) lm = km[k0 + lane - p.mask_start] != 0;
-    const unsigned long long mbits = __ballot(lm) >> (4 * hi);      // bit (32 t + (r&3) + 8 (r>>2)) <-> accumulator register r
+    const unsigned long long mball = __ballot(lm);
+    const unsigned long long mbits = mball >> (4 * hi);             // bit (32 t + (r&3) + 8 (r>>2)) <-> accumulator register r
     if (bias) {   // additive bias [Lq, Lk] of this (batch, head): the lane's keys come in runs of four consecutive k
       const float* brow = bias + (long)qrow * p.Lk + k0 + 4 * hi;
       const bool vec = (p.Lk & 3) == 0;
@@ -650,18 +651,26 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
         }
     }
     float tmax = -INFINITY;
+    if (mball == 0ull) {   // (wave-uniform: a full tile without masked keys - every tile of the backbone's attention but the last - skips the selects)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool masked = (mbits >> (32 * t + (r & 3) + 8 * (r >> 2))) & 1ull;
-        const float v = masked ? -INFINITY : s[t][r];
-        s[t][r] = v;
-        tmax = fmaxf(tmax, v);
-      }
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[t][r]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool masked = (mbits >> (32 * t + (r & 3) + 8 * (r >> 2))) & 1ull;
+          const float v = masked ? -INFINITY : s[t][r];
+          s[t][r] = v;
+          tmax = fmaxf(tmax, v);
+        }
+    }
     tmax = xhalf_max(tmax);
     const float mnew = fmaxf(mrun, tmax);
     const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+    const bool rose = mnew > mrun;   // (per query: false leaves alpha = 1 exactly)
     mrun = mnew;
     float psum = 0.f;
 #pragma unroll
@@ -673,10 +682,12 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
         psum += e;
       }
     lrun = lrun * alpha + psum;
+    if (__builtin_amdgcn_ballot_w64(rose) != 0ull) {   // no query of the wave raised its maximum: the rescale by exactly 1 is skipped
 #pragma unroll
-    for (int d = 0; d < DT; ++d)
+      for (int d = 0; d < DT; ++d)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+        for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+    }
     // O^T += V^T P^T.  Accumulator registers 8 uu .. 8 uu + 7 of sub-tile t are exactly the eight k-slots this lane feeds.
 #pragma unroll
     for (int t = 0; t < 2; ++t)
