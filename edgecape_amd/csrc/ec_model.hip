@@ -305,12 +305,14 @@ static int make_lin(ec_model* m, const std::string& wname, const std::string& bn
     int rc = upload16(m, w->host, &out->w16);
     if (rc) return rc;
     out->w16_is_f16 = m->bbf16;
+  } else if (m->bb_x3 && !name_is_head(wname)) {   // bf16x3 backbone, K-concatenated form: the only copy its GEMMs read
+    int rc = upload_x3(m, w->host.data(), out->N, out->K, &out->w16x3);
+    if (rc) return rc;
   } else if ((m->head_split && name_is_head(wname)) || (m->bb_split && !name_is_head(wname))) {
     int rc = upload_split(m, w->host.data(), out->N, out->K, &out->ws);
     if (rc) return rc;
     if (m->head_chain && name_is_head(wname) && (rc = upload_chain(m, w->host.data(), out->N, out->K, &out->wc))) return rc;
     out->h1 = m->cur_h1 && name_is_head(wname);
-    if (m->bb_x3 && !name_is_head(wname) && (rc = upload_x3(m, w->host.data(), out->N, out->K, &out->w16x3))) return rc;
   }
   return 0;
 }
@@ -1776,8 +1778,8 @@ int ec_finalize(ec_handle m) {
       EC_HIP(hipMemcpy(p3, w3.data(), w3.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
       m->patch_w16x3 = p3;
     }
-    if (m->bb_split && (rc = upload_split(m, Wp.data(), C, m->Kp, &m->patch.ws))) return rc;
-    if (m->bb_x3 && (3 * m->Kp) % 128 == 0 && (rc = upload_x3(m, Wp.data(), C, m->Kp, &m->patch_w16x3))) return rc;
+    if (m->bb_x3) { if ((rc = upload_x3(m, Wp.data(), C, m->Kp, &m->patch_w16x3))) return rc; }   // (3 Kp = 1920: fifteen 128-element K steps)
+    else if (m->bb_split && (rc = upload_split(m, Wp.data(), C, m->Kp, &m->patch.ws))) return rc;
     GET(cls, bp + "cls_token"); GET(pos, "@pos_table");
     m->cls = cls->dev; m->pos = pos->dev;
     if ((rc = make_norm(m, bp + "norm", &m->bnorm))) return rc;
