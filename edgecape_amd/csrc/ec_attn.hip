@@ -731,7 +731,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
   lrun = xhalf_sum(lrun);
   const float inv = 1.f / lrun;
   if (q0 + j < p.Lq) {
-    if (p.o_x3) {   // bf16 split [hi | lo | hi], planes H * HD elements apart: the A operand of the K-concatenated proj GEMM (bf16x3 backbone)
+    if (p.o_x3) {   // bf16 split [hi | lo], planes H * HD elements apart: the A operand of the K-concatenated proj GEMM (bf16x3 backbone)
       bf16_t* O = (bf16_t*)p.O + (long)b * p.sO + (long)(q0 + j) * p.ldo + h * HD;
       const long plane = (long)p.H * HD;
 #pragma unroll
@@ -745,7 +745,6 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
           bf16_t* o = O + d * 32 + 8 * g + 4 * hi;
           *(u32x2_t*)o = vh;
           *(u32x2_t*)(o + plane) = vl;
-          *(u32x2_t*)(o + 2 * plane) = vh;
         }
       return;
     }

@@ -210,8 +210,12 @@ struct GemmP {
   int period = 1;
   int act = ACT_NONE;
   int c_bf16 = 0;   // store C as bf16
-  int c_x3 = 0;     // store C as the bf16 split [hi | lo | hi] of the fp32 result (split4_bf16): 16-bit rows of stride ldc, the three
-                    // planes N elements apart (ldc >= 3 N) - the A operand of a following K-concatenated bf16x3 GEMM; exact GELU
+  int c_x3 = 0;     // store C as the bf16 split [hi | lo] of the fp32 result (split4_bf16): 16-bit rows of stride ldc, the two
+                    // planes N elements apart (ldc >= 2 N) - the A operand of a following K-concatenated bf16x3 GEMM; exact GELU
+  int kwrap = 0;    // 16-bit operands only: K-CONCATENATED bf16x3 product over TWO-plane operands.  kwrap = K-steps (64 elements) per plane;
+                    // K = 3 * 64 * kwrap logical steps, step kt reads A at plane step (kt < 2 kwrap ? kt : kt - 2 kwrap) - planes
+                    // [hi | lo | hi] of A = [hi | lo] - and B at (kt < kwrap ? kt : kt - kwrap) - planes [hi | hi | lo] of B = [W_hi | W_lo]:
+                    // a_hi W_hi + a_lo W_hi + a_hi W_lo in one accumulator, no plane stored or fetched from HBM twice.  lda, ldb >= 128 kwrap.
   int ab_bf16 = 0;  // A and B are 16-bit (else fp32)
   int h_f16 = 0;    // the 16-bit format (operands and, with c_bf16, the output) is IEEE fp16 instead of bf16
   int split = 0;    // 1 = bf16x3: A fp32, B pre-split into [32 hi | 32 lo] bf16 per 32-k block (split_pack_weights);
@@ -263,7 +267,7 @@ struct AttnP {
   int f16 = 0;                                  // ... in IEEE fp16 instead of bf16
   int split = 0;                                // fp32 data, bf16x3 MFMAs (head throughput mode)
   int one = 0;                                  // split mode only: ONE fp16 MFMA per product instead of three bf16 ones (mixed head, see ec_attn.hip)
-  int o_x3 = 0;                                 // split mode only: O is written as the bf16 split [hi | lo | hi] (split4_bf16): 16-bit rows of
+  int o_x3 = 0;                                 // split mode only: O is written as the bf16 split [hi | lo] (split4_bf16): 16-bit rows of
                                                 // stride ldo (sO in the same units), planes H * hd elements apart
   int kv16 = 0;                                 // split mode only: K and V are IEEE fp16 (ldk / ldv / sK / sV in fp16 elements), Q and O fp32
 };

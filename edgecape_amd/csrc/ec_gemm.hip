@@ -135,8 +135,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_nt_kernel(GemmP p) {
   auto stage = [&](int bz, int m0, int n0, int kt, char* buf) {
     const char* A = (const char*)p.A + (long)bz * p.sA * esz;
     const char* B = (const char*)p.B + (long)bz * p.sB * esz;
-    stage_rows<BM, NW>(A, lda_b, m0, p.M, (long)kt * KBYTES, buf, wave, lane);
-    stage_rows<BN, NW>(B, ldb_b, n0, p.N, (long)kt * KBYTES, buf + A_BYTES, wave, lane);
+    // (GemmP::kwrap, 16-bit modes: the K-concatenated bf16x3 product over two-plane operands - A planes hi | lo | hi, B planes hi | hi | lo)
+    const int kta = (BF16 && p.kwrap && kt >= 2 * p.kwrap) ? kt - 2 * p.kwrap : kt;
+    const int ktb = (BF16 && p.kwrap && kt >= p.kwrap) ? kt - p.kwrap : kt;
+    stage_rows<BM, NW>(A, lda_b, m0, p.M, (long)kta * KBYTES, buf, wave, lane);
+    stage_rows<BN, NW>(B, ldb_b, n0, p.N, (long)ktb * KBYTES, buf + A_BYTES, wave, lane);
   };
 
   int t = xcd * chunk + slot;
@@ -325,14 +328,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_nt_kernel(GemmP p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
           }
-          if (p.c_x3) {   // bf16 split [hi | lo | hi], planes N apart (GemmP::c_x3; the small-M fallback of the bf16x3 backbone's fc1)
+          if (p.c_x3) {   // bf16 split [hi | lo], planes N apart (GemmP::c_x3; the small-M fallback of the bf16x3 backbone's fc1)
             u32x2_t h0, l0, h1, l1;
             split4_bf16(f32x4{v[0], v[1], v[2], v[3]}, h0, l0);
             split4_bf16(f32x4{v[4], v[5], v[6], v[7]}, h1, l1);
             char* cp = Cb + ((long)m * p.ldc + n) * 2;
             *(u32x4*)cp = u32x4{h0[0], h0[1], h1[0], h1[1]};
             *(u32x4*)(cp + (long)p.N * 2) = u32x4{l0[0], l0[1], l1[0], l1[1]};
-            *(u32x4*)(cp + (long)p.N * 4) = u32x4{h0[0], h0[1], h1[0], h1[1]};
           } else if (p.c_bf16) {
             u32x4 o;
 #pragma unroll
@@ -565,8 +567,10 @@ int gemm_nt(const GemmP& p, hipStream_t st) {
   EC_REQUIRE(p.act != ACT_TANHGATE || p.aux, -1, "gemm_nt: tanh-gate epilogue needs aux");
   EC_REQUIRE(p.tag >= 0 && p.tag < 5, -1, "gemm_nt: bad tag");
   EC_REQUIRE(!(p.split && p.ab_bf16), -1, "gemm_nt: split (bf16x3) mode takes fp32 A and a pre-split B");
-  EC_REQUIRE(!p.c_x3 || (p.ab_bf16 && !p.h_f16 && !p.c_bf16 && p.batch == 1 && p.ldc >= 3l * p.N), -1,
-             "gemm_nt: split output (c_x3) takes bf16 operands, one batch and ldc >= 3 N");
+  EC_REQUIRE(!p.c_x3 || (p.ab_bf16 && !p.h_f16 && !p.c_bf16 && p.batch == 1 && p.ldc >= 2l * p.N), -1,
+             "gemm_nt: split output (c_x3) takes bf16 operands, one batch and ldc >= 2 N");
+  EC_REQUIRE(!p.kwrap || (p.ab_bf16 && p.K == 3 * 64 * p.kwrap && p.lda >= 128l * p.kwrap && p.ldb >= 128l * p.kwrap), -1,
+             "gemm_nt: kwrap takes 16-bit two-plane operands of 64 * kwrap elements per plane and K = 3 planes");
   if (p.ab_bf16) {   // large 16-bit problems: the 8-phase 256x256x64 kernel (block GEMMs of the backbone)
     const int rc = gemm8_bf16(p, st);
     if (rc != 0) return rc < 0 ? rc : 0;

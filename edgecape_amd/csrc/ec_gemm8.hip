@@ -74,7 +74,10 @@ constexpr int G8_AHEAD = 5;               // half-tiles the load stream runs ahe
 // [hi | lo | hi] planes, B = [W_hi | W_hi | W_lo], K = 3 x the layer's depth), through the same staged whole-line pieces:
 //   G8_F32      C = acc + bias, fp32 (QKV)
 //   G8_RES_F32  C = (acc + bias) * gamma + C, fp32, in place (proj / fc2: LayerScale + the fp32 residual stream; resid == C)
-//   G8_GELU_X3  C = bf16 split planes [hi | lo | hi] of gelu(acc + bias), N elements apart (fc1: the A operand of fc2)
+//   G8_GELU_X3  C = bf16 split planes [hi | lo] of gelu(acc + bias), N elements apart (fc1: the A operand of fc2)
+// Their operands are TWO-plane (GemmP::kwrap): the load stream's K position wraps per operand - A walks its planes hi | lo | hi, B its
+// planes hi | hi | lo - so no plane is written, stored or fetched from HBM twice (scalar arithmetic in the issue slot only; compiled
+// into these kinds, the table-fp32 kind of the patch embedding and the generic kind).
 // (the generic kind did this first: 12 spilled VGPRs, fragment-wise quarter-line stores - QKV 227 us, fc1 343 us at cfg2)
 enum { G8_GENERIC = 0, G8_BIAS_BF16 = 1, G8_SCALE_BF16 = 2, G8_GELU_BF16 = 3, G8_TAB_H16 = 4, G8_TAB_F32 = 5, G8_F32 = 6, G8_RES_F32 = 7, G8_GELU_X3 = 8 };
 constexpr bool g8_f32_out(int kind) { return kind == G8_TAB_F32 || kind == G8_F32 || kind == G8_RES_F32; }
@@ -147,13 +150,12 @@ __device__ __forceinline__ void g8_epilogue_generic(const GemmP& p, f32x4 (&acc)
       }
       v *= gam4[ni];
       if (p.resid) v += *(const f32x4*)(p.resid + (long)m * p.ldr + n);
-      if (p.c_x3) {   // bf16 split [hi | lo | hi], planes N apart: the A operand of the next K-concatenated GEMM (fc1 -> fc2, bf16x3 backbone)
+      if (p.c_x3) {   // bf16 split [hi | lo], planes N apart: the A operand of the next K-concatenated GEMM (fc1 -> fc2, bf16x3 backbone)
         u32x2_t vh, vl;
         split4_bf16(v, vh, vl);
         bf16_t* c = (bf16_t*)p.C + (long)m * p.ldc + n;
         *(u32x2_t*)c = vh;
         *(u32x2_t*)(c + p.N) = vl;
-        *(u32x2_t*)(c + 2 * p.N) = vh;
       } else if (p.c_bf16) {
         *(u32x2*)((char*)p.C + ((long)m * p.ldc + n) * 2) = pack4_h_ovfl<F16>(v);
       } else {
@@ -219,7 +221,7 @@ __device__ __forceinline__ void g8_piece(f32x4 (&a)[4], const __amdgpu_buffer_rs
   }
   if constexpr (KIND == G8_GELU_X3) {
     // fc1 of the K-concatenated bf16x3 backbone: gelu(acc + bias) (single-transcendental form, 6.4e-7), split into bf16 hi + lo, the hi
-    // plane staged and stored twice (planes 0 and 2), then the lo plane (plane 1): 6 whole-line stores per piece
+    // plane staged and stored, then the lo plane: 4 whole-line stores per piece
     u32x2_t vh[4], vl[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -242,12 +244,7 @@ __device__ __forceinline__ void g8_piece(f32x4 (&a)[4], const __amdgpu_buffer_rs
         const int row = j * 8 + rrow;
         const u32x4 o = *(const u32x4*)(stg + row * 128 + ((rch ^ (row & 7)) << 4));
         const unsigned off = goff + (unsigned)(j * 8) * ldc2;
-        if (pl == 0) {
-          __builtin_amdgcn_raw_buffer_store_b128(o, rsC, col_ok ? off : 0xFFFFFFF0u, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(o, rsC, col_ok ? off + 2u * plane : 0xFFFFFFF0u, 0, 0);
-        } else {
-          __builtin_amdgcn_raw_buffer_store_b128(o, rsC, col_ok ? off + plane : 0xFFFFFFF0u, 0, 0);
-        }
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsC, col_ok ? off + (pl ? plane : 0u) : 0xFFFFFFF0u, 0, 0);
       }
     }
     return;
@@ -397,7 +394,8 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   constexpr bool NODRAIN = FAST && !(LAB & 64);              // the load stream is not drained at the seam
   constexpr bool GAMMA = KIND == G8_SCALE_BF16 || KIND == G8_RES_F32;
   constexpr int NB = GAMMA ? 2 : 1;                          // LDS-DMA pieces of one bias (+ LayerScale) slice
-  constexpr int NST = KIND == G8_GELU_X3 ? 48 : g8_f32_out(KIND) ? 32 : 16;   // global stores of one tile's epilogue per wave
+  constexpr int NST = (KIND == G8_GELU_X3 || g8_f32_out(KIND)) ? 32 : 16;   // global stores of one tile's epilogue per wave
+  constexpr bool WRAP = KIND == G8_GENERIC || KIND == G8_TAB_F32 || KIND == G8_F32 || KIND == G8_RES_F32 || KIND == G8_GELU_X3;   // GemmP::kwrap
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -479,8 +477,10 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   // four offset VGPRs instead of four 64-bit row pointers, no per-issue address arithmetic.
   // (host: operand bytes < 4 GiB.  The descriptors end with the operands' last row: the second piece of a clamped edge row group
   // reaches up to 8 rows past it, reads zeros there - range check - and those rows / columns are never stored)
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)(((unsigned)(p.M - 1) * (unsigned)p.lda + (unsigned)p.K) * 2u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)(((unsigned)(p.N - 1) * (unsigned)p.ldb + (unsigned)p.K) * 2u), 0x00020000);
+  const unsigned kphys = (WRAP && p.kwrap) ? 128u * (unsigned)p.kwrap : (unsigned)p.K;   // elements of an operand row that exist in memory
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)(((unsigned)(p.M - 1) * (unsigned)p.lda + kphys) * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)(((unsigned)(p.N - 1) * (unsigned)p.ldb + kphys) * 2u), 0x00020000);
+  const int kwA = (WRAP && p.kwrap) ? 2 * p.kwrap : 0x7fffffff, kwB = (WRAP && p.kwrap) ? p.kwrap : 0x7fffffff;   // first K-tile of the wrapped plane
   unsigned vo0, vo1, vo2, vo3;                       // A-h0, B-h0, B-h1, A-h1: byte offset of this lane's row (+ chunk)
   // (round 3, measured and removed: a per-tile ROTATION of the K walk, so that the workgroups sharing an operand panel are at
   // different K positions, and a start stagger over the slots.  Neither changes FETCH_SIZE / TCC_MISS on any of the four block
@@ -512,12 +512,14 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   auto issue = [&](const __amdgpu_buffer_rsrc_t rs, unsigned vo, unsigned ld8, int half) {
     if constexpr (LAB & 4) { if (lab_steady) return; }
     char* dst = smem + (ls_kt & 1) * G8_KT + half * G8_HALF + wave * 2048;
+    int kpos = ls_kt;                                  // K-tile of the operand's memory image (half 0 / 3: A, 1 / 2: B)
+    if constexpr (WRAP) kpos = (half == 0 || half == 3) ? (ls_kt >= kwA ? ls_kt - kwA : ls_kt) : (ls_kt >= kwB ? ls_kt - kwB : ls_kt);
     // (the K position and the second piece's +64 B go into the SCALAR offset: the instruction's immediate offset would be added to
     // the LDS address as well as to the memory address)
     // second piece: rows 8..15 of the group (+ 8 rows; their chunks are stored XOR 2: the swizzle of the reader)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)dst, 16, vo, ls_kt * 128, 0, 0);
-    if constexpr (LAB & 256) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + 1024), 16, vo, ls_kt * 128 + 64, 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + 1024), 16, (vo ^ 32u) + ld8, ls_kt * 128, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)dst, 16, vo, kpos * 128, 0, 0);
+    if constexpr (LAB & 256) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + 1024), 16, vo, kpos * 128 + 64, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + 1024), 16, (vo ^ 32u) + ld8, kpos * 128, 0, 0);
   };
   auto advance = [&]() {
     if (++ls_kt == nk) {
@@ -832,6 +834,7 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
     if (!p.resid && !p.gamma) kind = G8_F32;
     else if (p.resid == (const float*)p.C && p.ldr == p.ldc && p.gamma) kind = G8_RES_F32;
   }
+  if (p.kwrap && kind >= G8_BIAS_BF16 && kind <= G8_TAB_H16) kind = G8_GENERIC;   // (the K wrap is compiled into the other kinds only)
 #define G8_ROW(F) \
       {gemm8_bf16_kernel<0, 0, F>, gemm8_bf16_kernel<0, 1, F>, gemm8_bf16_kernel<0, 2, F>, gemm8_bf16_kernel<0, 3, F>, gemm8_bf16_kernel<0, 4, F>}, \
       {gemm8_bf16_kernel<1, 0, F>, gemm8_bf16_kernel<1, 1, F>, gemm8_bf16_kernel<1, 0, F>, gemm8_bf16_kernel<1, 0, F>, gemm8_bf16_kernel<1, 0, F>}, \

@@ -45,7 +45,7 @@ struct Lin {  // a Linear layer view: W [N,K] (+ optional bf16 copy), bias [N]
   const void* wc = nullptr;    // ... and its fragment-major packing for the row-chain kernel (ec_chain.hip), head only
   const bf16_t* wf16 = nullptr;  // plain IEEE fp16 [N, K] copy (single-pass fp16 layers of the head's mixed precision): the 8-phase 16-bit
                                // GEMM runs the large image-row projections of the skeleton head on it when a 16-bit copy of A exists
-  const bf16_t* w16x3 = nullptr; // bf16 [N, 3 K] = [W_hi | W_hi | W_lo]: K-concatenated bf16x3 operand of the 8-phase GEMM (EC_BF16X3 backbone)
+  const bf16_t* w16x3 = nullptr; // bf16 [N, 2 K] = [W_hi | W_lo]: K-concatenated bf16x3 operand of the 8-phase GEMM (EC_BF16X3 backbone, GemmP::kwrap)
   const float* b = nullptr;
   int N = 0, K = 0;
   bool w16_is_f16 = false;     // w16 holds IEEE fp16 (EC_F16 backbone) instead of bf16
@@ -251,17 +251,18 @@ static int upload_split(ec_model* m, const float* W, long rows, long K, const fl
   else split_pack_weights(W, rows, K, packed.data());
   return upload(m, packed, out);
 }
-// K-concatenated bf16x3 operand: row n = [W_hi | W_hi | W_lo] (bf16, 3 K long).  Against activation rows [a_hi | a_lo | a_hi] ONE 16-bit
-// GEMM of depth 3 K adds a_hi W_hi + a_lo W_hi + a_hi W_lo in its fp32 accumulators - the three products of the bf16x3 mode (the
-// lo x lo term, ~2^-16 of the product, is dropped there as well).
+// K-concatenated bf16x3 operand: row n = [W_hi | W_lo] (bf16, 2 K long), walked by the GEMM's load stream as [W_hi | W_hi | W_lo]
+// (GemmP::kwrap).  Against activation rows [a_hi | a_lo], walked as [a_hi | a_lo | a_hi], ONE 16-bit GEMM of depth 3 K adds
+// a_hi W_hi + a_lo W_hi + a_hi W_lo in its fp32 accumulators - the three products of the bf16x3 mode (the lo x lo term, ~2^-16 of the
+// product, is dropped there as well).
 static int upload_x3(ec_model* m, const float* W, long rows, long K, const bf16_t** out) {
-  std::vector<bf16_t> w3((size_t)rows * 3 * K);
+  std::vector<bf16_t> w3((size_t)rows * 2 * K);
   for (long n = 0; n < rows; ++n) {
-    bf16_t* row = &w3[(size_t)n * 3 * K];
+    bf16_t* row = &w3[(size_t)n * 2 * K];
     for (long k = 0; k < K; ++k) {
       const float w = W[n * K + k];
       const bf16_t h = f2bf(w);
-      row[k] = h; row[K + k] = h; row[2 * K + k] = f2bf(w - bf2f(h));
+      row[k] = h; row[K + k] = f2bf(w - bf2f(h));
     }
   }
   bf16_t* p3 = nullptr;
@@ -485,15 +486,15 @@ static int linear(const void* A, long lda, bool a16, const Lin& W, void* C, long
   return gemm_nt(p, st);
 }
 
-// K-concatenated bf16x3 Linear: A = bf16 [M, 3 K] planes [hi | lo | hi] (row stride 3 K), W.w16x3; C fp32, or (c_x3) the split planes
-// of the result, row stride ldc
+// K-concatenated bf16x3 Linear: A = bf16 [M, 2 K] planes [hi | lo] (row stride 2 K), W.w16x3 = [W_hi | W_lo]; C fp32, or (c_x3) the
+// split planes of the result, row stride ldc
 static int linear_x3(const void* A, const Lin& W, void* C, long ldc, bool c_x3, int M, int act, hipStream_t st, const float* gamma,
                      const float* resid, long ldr, int tag) {
   EC_REQUIRE(W.w16x3 != nullptr, EC_ERR_STATE, "linear_x3: K-concatenated weight copy was not built");
   GemmP p;
   p.tag = tag;
-  p.A = A; p.lda = 3l * W.K; p.ab_bf16 = 1; p.h_f16 = 0;
-  p.B = W.w16x3; p.ldb = 3l * W.K;
+  p.A = A; p.lda = 2l * W.K; p.ab_bf16 = 1; p.h_f16 = 0;
+  p.B = W.w16x3; p.ldb = 2l * W.K; p.kwrap = W.K / 64;
   p.C = C; p.ldc = ldc; p.c_x3 = c_x3 ? 1 : 0;
   p.bias = W.b; p.gamma = gamma; p.resid = resid; p.ldr = ldr;
   p.M = M; p.N = W.N; p.K = 3 * W.K; p.act = act;
@@ -533,9 +534,9 @@ static int run_backbone(ec_model* m, const float* const* imgs, const int* counts
   // of the error variance of the backbone's features (oracle/precision_sites.py) - every later block inherits it through the residual
   // stream - for 0.5 % of the FLOPs: with [hi | lo | hi] patches against [W_hi | W_hi | W_lo] weights the same 8-phase GEMM, K = 3 Kp,
   // computes the products to ~2^-22.  (The bf16 backbone keeps single operands; the fp16 A/B switch EC_PATCH_X3 went in round 5.)
-  const bool px3 = m->patch_w16x3 != nullptr;       // fp16 backbone: fp16 planes; bf16x3 backbone (K-concatenated form): bf16 planes
+  const bool px3 = m->patch_w16x3 != nullptr;       // fp16 backbone: three fp16 planes; bf16x3 backbone (K-concatenated form): two bf16 planes
   const bool pb3 = px3 && m->bb_x3;
-  const int Kpe = px3 ? 3 * m->Kp : m->Kp;
+  const int Kpe = pb3 ? 2 * m->Kp : px3 ? 3 * m->Kp : m->Kp;   // row length of the patch rows / weight rows in memory
   for (int s = 0, at = 0; s < n_src; at += counts[s], ++s)
     if (counts[s] > 0)
       RUN(im2col14(imgs[s], (char*)m->bb_h + (size_t)at * T * Kpe * (h16 || pb3 ? 2 : 4), pb3 ? 4 : px3 ? 3 : hfmt, counts[s], m->H, m->W, m->gh, m->gw, m->Kp, st));
@@ -547,7 +548,8 @@ static int run_backbone(ec_model* m, const float* const* imgs, const int* counts
     p.B = px3 ? (const void*)m->patch_w16x3 : h16 ? (const void*)m->patch.w16 : m->patch.wsel(m->bb_split); p.ldb = Kpe;
     p.C = m->bb_x; p.ldc = C;
     p.bias = m->patch.b; p.table = m->pos; p.ldt = C; p.period = T;
-    p.M = (int)M; p.N = C; p.K = Kpe;
+    p.M = (int)M; p.N = C; p.K = pb3 ? 3 * m->Kp : Kpe;
+    if (pb3) p.kwrap = m->Kp / 64;
     RUN(gemm_nt(p, st));
   }
   RUN(set_cls_rows(m->bb_x, C, m->cls, m->pos, n, T, C, st));
@@ -562,7 +564,7 @@ static int run_backbone(ec_model* m, const float* const* imgs, const int* counts
   for (size_t i = 0; i < m->blocks.size(); ++i) {
     const BBlock& b = m->blocks[i];
     const bool x3 = m->bb_x3;
-    RUN(ln(m->bb_x, C, m->bb_xn, x3 ? 3 * C : C, x3 ? 3 : hfmt, b.n1, (int)M, C, 1e-6f, st, 0, pend, C, pend2));
+    RUN(ln(m->bb_x, C, m->bb_xn, x3 ? 2 * C : C, x3 ? 3 : hfmt, b.n1, (int)M, C, 1e-6f, st, 0, pend, C, pend2));
     pend = pend2 = nullptr;
     const bool prof = m->prof_on && (m->prof_mode != 2 || i == m->prof_pass % m->blocks.size()) && m->prof_used + 2 <= m->prof_ev.size();
     if (prof) EC_HIP(hipEventRecord(m->prof_ev[m->prof_used++], st));
@@ -587,15 +589,16 @@ static int run_backbone(ec_model* m, const float* const* imgs, const int* counts
     a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
     a.sQ = a.sK = a.sV = (long)T * 3 * C; a.sO = (long)T * C;
     a.B = n; a.H = nh; a.Lq = T; a.Lk = T; a.hd = C / nh; a.bf16 = h16; a.f16 = m->bbf16; a.split = m->bb_split ? 1 : 0;
-    if (x3) { a.o_x3 = 1; a.ldo = 3 * C; a.sO = (long)T * 3 * C; }
+    if (x3) { a.o_x3 = 1; a.ldo = 2 * C; a.sO = (long)T * 2 * C; }
     RUN(attention(a, st));
     if (x3) {
       // K-concatenated bf16x3 (round 5): every block GEMM is ONE 16-bit GEMM of depth 3 K on the 8-phase kernel - activations as bf16
-      // [hi | lo | hi] planes written by their producers (LayerNorm, attention, the fc1 epilogue), weights [W_hi | W_hi | W_lo] - with the
-      // fp32 epilogue of the exact mode (residual added in place); the same three products per multiply as the split-on-load kernel
+      // [hi | lo] planes written by their producers (LayerNorm, attention, the fc1 epilogue) and walked hi | lo | hi by the load stream,
+      // weights [W_hi | W_lo] walked hi | hi | lo (GemmP::kwrap) - with the fp32 epilogue of the exact mode (residual added in place);
+      // the same three products per multiply as the split-on-load kernel
       RUN(linear_x3(m->bb_att, b.proj, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls1, m->bb_x, C, 2));
-      RUN(ln(m->bb_x, C, m->bb_xn, 3 * C, 3, b.n2, (int)M, C, 1e-6f, st));
-      RUN(linear_x3(m->bb_xn, b.fc1, m->bb_h, 12 * C, true, (int)M, ACT_GELU, st, nullptr, nullptr, 0, 3));
+      RUN(ln(m->bb_x, C, m->bb_xn, 2 * C, 3, b.n2, (int)M, C, 1e-6f, st));
+      RUN(linear_x3(m->bb_xn, b.fc1, m->bb_h, 8 * C, true, (int)M, ACT_GELU, st, nullptr, nullptr, 0, 3));
       RUN(linear_x3(m->bb_h, b.fc2, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls2, m->bb_x, C, 4));
     } else if (h16) {
       RUN(linear(m->bb_att, C, true, b.proj, m->bb_y, C, true, (int)M, ACT_NONE, st, b.ls1, nullptr, 0, nullptr, 0, 1, nullptr, 0, 2));
@@ -1778,7 +1781,7 @@ int ec_finalize(ec_handle m) {
       EC_HIP(hipMemcpy(p3, w3.data(), w3.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
       m->patch_w16x3 = p3;
     }
-    if (m->bb_x3) { if ((rc = upload_x3(m, Wp.data(), C, m->Kp, &m->patch_w16x3))) return rc; }   // (3 Kp = 1920: fifteen 128-element K steps)
+    if (m->bb_x3) { if ((rc = upload_x3(m, Wp.data(), C, m->Kp, &m->patch_w16x3))) return rc; }   // (Kp = 640: ten K-tiles per plane)
     else if (m->bb_split && (rc = upload_split(m, Wp.data(), C, m->Kp, &m->patch.ws))) return rc;
     GET(cls, bp + "cls_token"); GET(pos, "@pos_table");
     m->cls = cls->dev; m->pos = pos->dev;
@@ -1892,7 +1895,7 @@ int ec_finalize(ec_handle m) {
   const size_t es = m->bb16 ? 2 : 4;
   const size_t MT = (size_t)n * T;
   if ((rc = dalloc(m, &m->bb_x, MT * C))) return rc;
-  const size_t es3 = m->bb_x3 ? 6 : es;   // K-concatenated bf16x3: three bf16 planes per activation value
+  const size_t es3 = m->bb_x3 ? 4 : es;   // K-concatenated bf16x3: two bf16 planes per activation value
   if ((rc = dmalloc(m, &m->bb_xn, MT * C * es3))) return rc;
   if ((rc = dmalloc(m, &m->bb_qkv, MT * 3 * C * es))) return rc;
   if ((rc = dmalloc(m, &m->bb_att, MT * C * es3))) return rc;

@@ -12,7 +12,7 @@ namespace {
 // Reference: DINOv2 norm1/norm2/norm (eps 1e-6), head LayerNorms (eps 1e-5, encoder_decoder.py:450-451,566-576).
 // ------------------------------------------------------------------------------------------------
 // OUT: 0 = fp32 output, 1 = bf16, 2 = IEEE fp16 (the fused branch inputs `add` / `add2` are in the same 16-bit format),
-//      3 = bf16 split [hi | lo | hi] in three planes `cols` elements apart (ldy >= 3 cols): the A operand of a K-concatenated bf16x3 GEMM
+//      3 = bf16 split [hi | lo] in two planes `cols` elements apart (ldy >= 2 cols): the A operand of a K-concatenated bf16x3 GEMM
 template <int OUT, bool ADD, bool ADD_F16 = (OUT == 2)>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnP p) {
   constexpr bool OUT_BF16 = OUT != 0;
@@ -77,7 +77,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnP p) {
         split4_bf16(o, hi, lo);
         *(u32x2_t*)y = hi;
         *(u32x2_t*)(y + p.cols) = lo;
-        *(u32x2_t*)(y + 2 * p.cols) = hi;
       } else if (OUT_BF16) {
         bf16_t* y = (bf16_t*)p.y + orow * p.ldy + c;
         *(u32x2_t*)y = pack4_h<F16>(o);
@@ -157,7 +156,7 @@ __global__ void transpose_pad_bf16_kernel(const float* src, bf16_t* dst, int L, 
 
 // im2col for Conv2d(3, C, k=14, s=14) (DINOv2 PatchEmbed): patches[(n*gh+py)*gw+px][c*196+ky*14+kx] of an H x W image,
 // gh = H / 14, gw = W / 14 (floor: stride-14 VALID convolution), row length Kp >= 588 (zero padded) so the GEMM K is a multiple of 128 bytes.
-template <int OUT>   // 0 fp32, 1 bf16, 2 fp16, 3 fp16 split [hi | lo | hi], 4 bf16 split [hi | lo | hi] (bf16x3 backbone)
+template <int OUT>   // 0 fp32, 1 bf16, 2 fp16, 3 fp16 split [hi | lo | hi], 4 bf16 split [hi | lo] (bf16x3 backbone, GemmP::kwrap)
 __global__ __launch_bounds__(256) void im2col14_kernel(const float* img, void* out, int H, int W, int gh, int gw, int Kp) {
   // output rows are TOKEN rows: image n owns rows n*(g*g+1) .. ; row 0 of each image (the cls token) is zero-filled so the
   // patch embedding is ONE GEMM over M = n_img * T contiguous rows (its cls rows are overwritten by set_cls_rows).
@@ -185,8 +184,8 @@ __global__ __launch_bounds__(256) void im2col14_kernel(const float* img, void* o
     for (int i = threadIdx.x; i < c4n; i += blockDim.x) {
       u32x2_t h, l;
       split4_bf16(*(const f32x4*)(px + i * 4), h, l);
-      bf16_t* o = (bf16_t*)out + orow * 3 * Kp + i * 4;
-      *(u32x2_t*)o = h; *(u32x2_t*)(o + Kp) = l; *(u32x2_t*)(o + 2 * Kp) = h;
+      bf16_t* o = (bf16_t*)out + orow * 2 * Kp + i * 4;
+      *(u32x2_t*)o = h; *(u32x2_t*)(o + Kp) = l;
     }
   } else if constexpr (OUT == 3) {
     // split-precision patch embedding (fp16 backbone): the row is [hi | lo | hi], hi = fp16(v), lo = fp16(v - hi); against the weight
@@ -795,7 +794,7 @@ int layernorm(const LnP& p, hipStream_t st) {
   const int afmt = p.add_fmt ? p.add_fmt : (p.y_bf16 ? p.y_bf16 : 1);
   EC_REQUIRE(!p.add || p.y_bf16 == 0 || afmt == p.y_bf16, -1, "layernorm: fused add and output must share the 16-bit format");
   if (p.y_bf16 == 3) {
-    EC_REQUIRE(!p.add && p.ldy >= 3 * (long)p.cols, -1, "layernorm: split output takes no fused add and needs ldy >= 3 cols");
+    EC_REQUIRE(!p.add && p.ldy >= 2 * (long)p.cols, -1, "layernorm: split output takes no fused add and needs ldy >= 2 cols");
     hipLaunchKernelGGL((layernorm_kernel<3, false>), grid, dim3(256), 0, st, p);
   } else if (p.add) {
     if (p.y_bf16 == 2) hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, dim3(256), 0, st, p);

@@ -52,7 +52,11 @@ enum ec_status {
 enum ec_precision {
   EC_F32 = 0,     /* fp32 operands, exact products (v_mfma_f32_32x32x2_f32) */
   EC_BF16 = 1,    /* bf16 operands, fp32 accumulate */
-  EC_BF16X3 = 2,  /* fp32 data, each operand split into hi+lo bf16, 3 bf16 MFMAs per product: ~2^-17 relative (head only) */
+  EC_BF16X3 = 2,  /* fp32 data, each operand split into hi+lo bf16, 3 bf16 MFMAs per product: ~2^-17 relative.  The tolerance-conforming
+                     fast mode when used for backbone AND head (0 / 1 / 1 / 1 argmax flips of ~20 000 valid keypoints on cfg1 / 2 / 4 / 5,
+                     max |d kpt| <= 1.1e-5 otherwise; profiles/r05_conformance_*bf16x3*.json).  As a backbone precision (round 5) the
+                     block GEMMs run K-concatenated on the 16-bit 8-phase kernel: activations as bf16 [hi | lo] planes written by their
+                     producers, weights [W_hi | W_lo], one GEMM of depth 3 K per Linear */
   EC_F16 = 3,     /* IEEE fp16 operands (11 significand bits, same MFMA rate as bf16), fp32 accumulate: the backbone mode that
                      keeps output_kpts inside the 1e-3 tolerance at bf16 speed (backbone only) */
   EC_MIXED = 4    /* head only: EC_BF16X3 everywhere the proposal generator's argmax depends on (input projections, support pooling,

@@ -14,6 +14,7 @@ python tools/refresh_pmc.py --out $OUT/pmc > $OUT/pmc.log 2>&1; tail -n 3 $OUT/p
 python tools/refresh_pmc.py --out $OUT/pmc --shots 5 --batch 16 >> $OUT/pmc.log 2>&1
 python tools/refresh_pmc.py --out $OUT/pmc --arch dinov2_vitl14 --image-size 384 --batch 8 >> $OUT/pmc.log 2>&1
 python tools/refresh_pmc.py --out $OUT/pmc --arch dinov2_vits14 --image-size 224 >> $OUT/pmc.log 2>&1
+python tools/refresh_pmc.py --out $OUT/pmc --precision bf16x3 >> $OUT/pmc.log 2>&1
 cp $OUT/pmc/qkv_gemm_pmc*.json profiles/
 python bench.py > $OUT/bench.json 2> $OUT/bench.err; python tools/bench_line.py < $OUT/bench.json | cut -c1-400
 python bench.py --shots 5 --batch 16 --no-alt --steps 10 --cpu-batches 16 --cpu-runs 3 > $OUT/cfg4_5shot_b16.json 2>> $OUT/bench.err
@@ -29,5 +30,13 @@ python tools/rocpd_stats.py $DB $OUT/kernel_stats.csv
 python tools/trace_step.py $DB 0 -1 > $OUT/episode_call_trace.txt 2>/dev/null     # the last call of the episode leg (60 queries + 4 supports)
 python tools/trace_step.py $DB 0 -34 > $OUT/step_trace.txt 2>/dev/null           # the last headline step but one (8 + 24 episode calls and the episode engine's build lie behind the last)
 head -n 14 $OUT/kernel_stats.csv | cut -c1-150
-rm -rf $OUT/prof $OUT/pmc/pmc_*
+rm -rf $OUT/prof
+# the conforming mode's kernels (bf16x3 / bf16x3: K-concatenated GEMMs on the 8-phase kernel)
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $OUT/prof3 -o r -- python $R/bench.py --precision bf16x3 --head-precision bf16x3 --no-cpu-baseline --no-episode --no-alt --sustained-seconds 0 --steps 6 --warmup 3 > $OUT/prof_bench_bf16x3.json 2> $OUT/prof3.err
+cd $R
+DB=$(ls $OUT/prof3/*/*results.db $OUT/prof3/*results.db 2>/dev/null | head -1)
+python tools/rocpd_stats.py $DB $OUT/kernel_stats_bf16x3.csv
+head -n 8 $OUT/kernel_stats_bf16x3.csv | cut -c1-150
+rm -rf $OUT/prof3 $OUT/pmc/pmc_*
 ls $OUT
