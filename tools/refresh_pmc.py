@@ -81,7 +81,7 @@ def main():
     M, K, N = (1 + args.shots) * args.batch * T, a["C"], 3 * a["C"]
     algorithmic = M * K * 2 + N * K * 2 + M * N * 2 + N * 4          # A + W + C (16-bit) + bias
     if x3:
-        algorithmic = M * 3 * K * 2 + N * 3 * K * 2 + M * N * 4 + N * 4   # three bf16 planes of A and W, fp32 C
+        algorithmic = M * 2 * K * 2 + N * 2 * K * 2 + M * N * 4 + N * 4   # two bf16 planes of A and of W in memory (GemmP::kwrap), fp32 C
     fetch_kb, write_kb = get("FETCH_SIZE"), get("WRITE_SIZE")
     traffic = (2.0 * fetch_kb + write_kb) * 1024.0
     gui = get("GRBM_GUI_ACTIVE")
