@@ -336,13 +336,14 @@ def pmc_traffic(args, bs, S, H, arch, source_hash):
             "mfma_util_pmc": d.get("mfma_util"), "traffic_source": os.path.relpath(path, ROOT)}
 
 
-def episode_mode(args, sd, synth, bs, S, H, arch, apis, rank=0, world=1, n_ep=32, qpe=15, passes=3, n_img=0, precision=None, head_precision=None):
+def episode_mode(args, sd, synth, bs, S, H, arch, apis, rank=0, world=1, n_ep=32, qpe=15, passes=6, n_img=0, precision=None, head_precision=None):
     """The reference's real evaluation protocol (not `value`): every support set is paired with 15 queries
     (EdgeCape/datasets/datasets/mp100/test_dataset.py:86-99), so `n_ep` episodes are `n_ep * 15` pairs.  Streamed through
     ec_forward_episodes: a call takes the next q queries of the pair order and encodes the episodes that start in it - their support
     images ride in the queries' backbone pass - with q chosen so that a call's backbone pass has about as many images as a headline
     step ((1 + S) * bs).  EVERY encode lies inside the timed region, amortised as the protocol amortises it; calls are pipelined
-    (head of call i beside the backbone of call i + 1) with an ec_pipeline_flush inside the timed region.  Every rank streams its
+    (head of call i beside the backbone of call i + 1) with an ec_pipeline_flush inside the timed region (one un-overlapped head at the
+    end of `passes` x n_ep episodes: 6 passes = 192 episodes = 2880 pairs, ~0.3 s - a test split of MP-100 is thousands).  Every rank streams its
     own n_ep episodes (weak scaling, as the headline); the region is apis.timed_steps' (barriers, max over ranks)."""
     import torch
     from edgecape_amd.engine import HipEngine
