@@ -13,6 +13,11 @@ similarity-map error is the continuous proxy of the flip RATE (12 of 20 293 at t
 profiles/r05_conformance_*.json).  Nothing here runs in the product; it prices a lead before any kernel is written.
 
     python oracle/correction_terms_study.py [--pairs 8] [--arch dinov2_vitb14]
+
+Second use (round 5): a given batch of the at-scale conformance sets (tests/test_gpu_precision_modes.py conformance_at_scale: its
+configuration, weight seed and batch index) under the same schemes, with one keypoint singled out - does the emulated scheme flip the
+near-tie that the GPU mode flips?
+    python oracle/correction_terms_study.py --config cfg4 --wseed 1 --batch-index 14 --kpt 9,23 --schemes bf16x3,fp16x3,fp16+e4m3
 """
 import argparse
 import os
@@ -121,6 +126,38 @@ def run(sd, batch, heads, scheme):
         return fq, orc.head_forward(sd, fq, fs, batch["target_s"], mask_s, skel)
 
 
+def one_conformance_batch(args):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_precision_modes as T
+    c = T.CFG[args.config]
+    sd = synth.make_weights(c["arch"], seed=args.wseed)
+    heads = synth.ARCHS[c["arch"]]["heads"]
+    batch = synth.make_pairs(c["bs"], c["S"], c["H"], seed=c["iseed"] + 100000 * (1 + args.wseed), first_index=args.batch_index * c["bs"], fixed_n_kp=False)
+    mask = batch["target_weight_s"][0].copy()
+    for tw in batch["target_weight_s"]:
+        mask = mask * tw
+    valid = mask[:, :, 0] > 0
+    skel = [m["sample_skeleton"][0] for m in batch["img_metas"]]
+
+    def sim(scheme):
+        with torch.no_grad():
+            fq = backbone(sd, batch["img_q"], heads, scheme)
+            fs = [backbone(sd, im, heads, scheme) for im in batch["img_s"]]
+            return orc.head_forward(sd, fq, fs, batch["target_s"], orc._t(mask), skel)["similarity_map"].reshape(c["bs"], 100, -1).numpy()
+
+    so = orc.forward_test(sd, batch, heads)[1]["similarity_map"].reshape(c["bs"], 100, -1).numpy()
+    s0 = sim("fp32")
+    gap = lambda m: np.where(valid, np.sort(m, -1)[:, :, -1] - np.sort(m, -1)[:, :, -2], np.inf)
+    i = tuple(int(x) for x in args.kpt.split(",")) if args.kpt else tuple(int(x) for x in np.unravel_index(np.argmin(gap(so)), valid.shape))
+    print(f"{args.config}, weight seed {args.wseed}, batch {args.batch_index}: {int(valid.sum())} valid keypoints; keypoint {i}: top-2 gap {gap(so)[i]:.3e} in the oracle's map "
+          f"(argmax {int(so[i].argmax())}), {gap(s0)[i]:.3e} in this script's fp32 backbone (argmax {int(s0[i].argmax())})")
+    for scheme in args.schemes.split(","):
+        s = sim(scheme)
+        print(f"{scheme:12s} flips in the batch {int(((s.argmax(-1) != s0.argmax(-1)) & valid).sum())}   keypoint {i}: argmax {int(s[i].argmax())} "
+              f"{'FLIPPED' if s[i].argmax() != s0[i].argmax() else 'kept'}, map err at it {float(np.abs(s[i] - s0[i]).max()):.2e}   "
+              f"batch map err mean {float(np.abs(s - s0)[valid].mean()):.2e} max {float(np.abs(s - s0)[valid].max()):.2e}", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", type=int, default=8)
@@ -128,7 +165,12 @@ def main():
     ap.add_argument("--wseed", type=int, default=0)
     ap.add_argument("--outliers", action="store_true", help="weights with planted DINOv2-like activation outliers")
     ap.add_argument("--schemes", default="fp16,bf16x3,fp16x3,fp16+none,fp16+e4m3,fp16+e5m2,fp16+e4m3:w,bf16+e4m3")
+    ap.add_argument("--config", default=None, help="cfg1 | cfg2 | cfg4 | cfg5: one batch of the at-scale conformance set instead of --pairs")
+    ap.add_argument("--batch-index", type=int, default=0)
+    ap.add_argument("--kpt", default=None, help="sample,keypoint to single out")
     args = ap.parse_args()
+    if args.config:
+        return one_conformance_batch(args)
     sd = synth.make_weights(args.arch, seed=args.wseed)
     if args.outliers:
         sd = synth.add_activation_outliers(sd, args.arch)
