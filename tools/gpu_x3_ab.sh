@@ -1,5 +1,6 @@
 #!/bin/bash
-# K-concatenated bf16x3 backbone (EC_BB_X3, round 5): parity tests, interleaved bench A/B against the split-on-load kernel, kernel stats of both.
+# K-concatenated bf16x3 backbone (EC_BB_X3, round 5): parity tests, interleaved bench A/B against the split-on-load kernel, kernel stats.
+# (profiles/r05_x3_ab.txt also has a "gen" leg - the generic epilogue behind a switch, EC_G8_X3EPI, that is gone from the library again)
 #   usage: bash tools/gpu_x3_ab.sh <tag>   -> gpurun_out/<tag>/
 TAG=${1:-x3a}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -12,7 +13,6 @@ if [ "$2" != "--no-tests" ]; then
 fi
 for i in 1 2; do
   EC_BB_X3=0 $B > $OUT/bench_x3off_$i.json 2>> $OUT/bench.err
-  EC_G8_X3EPI=0 $B > $OUT/bench_x3gen_$i.json 2>> $OUT/bench.err
   $B > $OUT/bench_x3on_$i.json 2>> $OUT/bench.err
 done
 for f in $OUT/bench_x3*.json; do echo $f; python tools/bench_line.py x < $f | cut -c1-250; done
