@@ -13,13 +13,13 @@ from . import build as _build
 
 _LIB = None
 
-EC_F32, EC_BF16, EC_BF16X3, EC_F16, EC_MIXED = 0, 1, 2, 3, 4
+EC_F32, EC_BF16, EC_BF16X3, EC_F16, EC_MIXED, EC_F16X2 = 0, 1, 2, 3, 4, 5
 EC_ABI_VERSION = 5   # include/edgecape_hip.h EC_ABI_VERSION: bumped whenever a struct layout or a signature changes
 EC_DT_F32, EC_DT_F16, EC_DT_BF16, EC_DT_F64 = 0, 1, 2, 3
 EC_LAYOUT_TOKENS, EC_LAYOUT_NCHW = 0, 1
 
 EXPORTS = ["ec_last_error", "ec_version", "ec_create", "ec_destroy", "ec_load_tensor", "ec_set_pos_embed", "ec_finalize",
-           "ec_backbone", "ec_head", "ec_forward", "ec_forward_pipelined", "ec_pipeline_flush", "ec_support_create", "ec_support_destroy", "ec_support_encode", "ec_forward_cached", "ec_forward_episodes", "ec_preprocess_images", "ec_preprocess_images_cv2", "ec_msra_targets", "ec_debug_read", "ec_profile", "ec_profile_read", "ec_op_linear", "ec_op_linear_h16", "ec_op_gemm_bench", "ec_op_bgemm", "ec_op_layernorm",
+           "ec_backbone", "ec_head", "ec_forward", "ec_forward_pipelined", "ec_pipeline_flush", "ec_support_create", "ec_support_destroy", "ec_support_encode", "ec_forward_cached", "ec_forward_episodes", "ec_preprocess_images", "ec_preprocess_images_cv2", "ec_msra_targets", "ec_debug_read", "ec_profile", "ec_profile_read", "ec_op_linear", "ec_op_linear_h16", "ec_op_linear_x2", "ec_op_gemm_bench", "ec_op_bgemm", "ec_op_layernorm",
            "ec_op_attention", "ec_op_chain", "ec_abi_sizes"]
 
 
@@ -97,6 +97,7 @@ def load():
     lib.ec_profile_read.argtypes = [vp, C.POINTER(cf), C.POINTER(ci)]
     lib.ec_op_linear.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
     lib.ec_op_linear_h16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+    lib.ec_op_linear_x2.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, C.POINTER(cf)]
     lib.ec_op_gemm_bench.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, C.POINTER(cf)]
     lib.ec_op_bgemm.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, vp]
     lib.ec_op_layernorm.argtypes = [vp, vp, vp, vp, ci, ci, cf, vp]

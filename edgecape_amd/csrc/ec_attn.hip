@@ -731,6 +731,25 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
   lrun = xhalf_sum(lrun);
   const float inv = 1.f / lrun;
   if (q0 + j < p.Lq) {
+    if (p.o_x3 == 3) {   // fp16x2 row [fp16 | e5m2 lo8 | e5m2 hi8] (ec_common.h split4_x2; ldo / sO in 16-bit units, ldo >= 2 H HD): proj's A operand
+      char* O = (char*)p.O + ((long)b * p.sO + (long)(q0 + j) * p.ldo) * 2;
+      const long C = (long)p.H * HD;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+          v[0] = ot[d][4 * g] * inv; v[1] = ot[d][4 * g + 1] * inv; v[2] = ot[d][4 * g + 2] * inv; v[3] = ot[d][4 * g + 3] * inv;
+          u32x2_t vh;
+          unsigned l8, h8;
+          split4_x2(v, vh, l8, h8);
+          const long c = h * HD + d * 32 + 8 * g + 4 * hi;
+          *(u32x2_t*)(O + c * 2) = vh;
+          *(unsigned*)(O + 2 * C + c) = l8;
+          *(unsigned*)(O + 3 * C + c) = h8;
+        }
+      return;
+    }
     if (p.o_x3) {   // bf16 split [hi | lo], planes H * HD elements apart: the A operand of the K-concatenated proj GEMM (bf16x3 backbone)
       bf16_t* O = (bf16_t*)p.O + (long)b * p.sO + (long)(q0 + j) * p.ldo + h * HD;
       const long plane = (long)p.H * HD;
@@ -741,7 +760,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
           f32x4 v;
           v[0] = ot[d][4 * g] * inv; v[1] = ot[d][4 * g + 1] * inv; v[2] = ot[d][4 * g + 2] * inv; v[3] = ot[d][4 * g + 3] * inv;
           u32x2_t vh, vl;
-          split4_bf16(v, vh, vl);
+          if (p.o_x3 == 2) split4_h<true>(v, vh, vl); else split4_bf16(v, vh, vl);
           bf16_t* o = O + d * 32 + 8 * g + 4 * hi;
           *(u32x2_t*)o = vh;
           *(u32x2_t*)(o + plane) = vl;

@@ -110,6 +110,64 @@ __device__ __forceinline__ void split4_bf16(f32x4 v, u32x2_t& hi, u32x2_t& lo) {
   for (int e = 0; e < 4; ++e) r[e] = v[e] - __uint_as_float((e & 1) ? (hi[e >> 1] & 0xffff0000u) : (hi[e >> 1] << 16));
   lo = pack4_h_ovfl<false>(r);
 }
+// The same split in the operand format of the GEMM that reads the planes.  F16 (IEEE fp16 planes): hi + lo carries 22 significand bits
+// instead of 16 - 4.5 x less error in the backbone's features for the same three MFMAs (profiles/r05_x3_fp16_planes_ab.txt) - and the
+// lo part of a small value is an fp16 SUBNORMAL, which the gfx950 matrix pipe keeps (tools/mfma_f16_denorm_probe.hip).  Magnitudes past
+// 65504 saturate (NaN stays NaN: sat_h16), first in hi, then in the remainder.  OVFL: the caller has MODE.FP16_OVFL switched on (the
+// 8-phase GEMM's epilogue), the conversions saturate by themselves.
+template <bool F16, bool OVFL = false> __device__ __forceinline__ void split4_h(f32x4 v, u32x2_t& hi, u32x2_t& lo) {
+  if constexpr (!F16) {
+    split4_bf16(v, hi, lo);
+  } else {
+    f32x4 s = v;
+    if constexpr (!OVFL) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = sat_h16(v[e]);
+    }
+    const f16x4 h = __builtin_convertvector(s, f16x4);
+    hi = __builtin_bit_cast(u32x2_t, h);
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = OVFL ? v[e] - (float)h[e] : sat_h16(v[e] - (float)h[e]);
+    lo = __builtin_bit_cast(u32x2_t, __builtin_convertvector(r, f16x4));
+  }
+}
+// ---- fp16x2 operand format (EC_F16X2 backbone, round 6): TWO MFMA units per product instead of the three of bf16x3 / fp16x3 ------------
+//     a W  ~  a_hi W_hi   [fp16 x fp16, v_mfma_f32_16x16x32_f16]
+//           + q5(a_lo) q4(W_hi) + q5(a_hi) q4(W_lo)   [FP8, v_mfma_scale_f32_16x16x128_f8f6f4: four times the flops per instruction at twice
+//                                                     the issue cost - one pass of depth 2 K for BOTH correction terms = one unit]
+// The correction terms are ~2^-12 of the product, so a few significand bits of THEIR operands suffice (oracle/x2_at_scale.py: the CPU
+// emulation of this scheme at the conformance sets' scale, before any kernel was written).  An activation row of K values is stored as
+//     [ hi: K x fp16 | lo8: K x e5m2 of (a - hi) * 2^11 | hi8: K x e5m2 of a ]          4 K bytes, as the two-plane bf16x3 row it replaces
+// - e5m2 has fp16's exponent range and (a - hi) * 2^11 has the exponent range of a itself, so BOTH FP8 planes take FIXED power-of-two
+// scales (E8M0 116 = 2^-11 and 127 = 1 in the MFMA's scale operand): no data-dependent scale, no reduction in any producer (LayerNorm,
+// attention, the fc1 epilogue each convert their own four values), and nothing can overflow while a fits fp16 (e5m2 conversions
+// saturate at +-57344).  A weight row is [ W_hi: K x fp16 | W_hi8: K x e4m3 of W * 2^s1 | W_lo8: K x e4m3 of (W - W_hi) * 2^s2 ] with one
+// static power-of-two scale per tensor and plane (ec_finalize knows the weights).  The GEMM's load stream walks both rows straight
+// through (no K wrap): K / 64 K-tiles of fp16 MFMAs, then K / 64 K-tiles of FP8 MFMAs - 128 bytes of a row are one 16x16x128 operand.
+__device__ __forceinline__ unsigned pack4_e5m2(f32x4 v) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], 0.f, __builtin_amdgcn_fmed3f(v[e], -57344.f, 57344.f));   // saturate, NaN stays NaN (sat_h16's form)
+  int r = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], 0, false);
+  r = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], r, true);
+  return (unsigned)r;
+}
+// OVFL: the caller has MODE.FP16_OVFL on (8-phase GEMM epilogue): the fp16 conversion saturates by itself
+template <bool OVFL = false> __device__ __forceinline__ void split4_x2(f32x4 v, u32x2_t& hi, unsigned& lo8, unsigned& hi8) {
+  f32x4 s = v;
+  if constexpr (!OVFL) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = sat_h16(v[e]);
+  }
+  const f16x4 h = __builtin_convertvector(s, f16x4);
+  hi = __builtin_bit_cast(u32x2_t, h);
+  f32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = (v[e] - (float)h[e]) * 2048.f;
+  lo8 = pack4_e5m2(r);
+  hi8 = pack4_e5m2(v);
+}
+constexpr int X2_SCALE_LO8 = 127 - 11, X2_SCALE_HI8 = 127;   // E8M0 scale bytes of the two activation planes
 template <bool F16> __device__ __forceinline__ bf16_t f2h(float f) {
   if constexpr (F16) return __builtin_bit_cast(bf16_t, (_Float16)sat_h16(f));
   else return __builtin_bit_cast(bf16_t, (__bf16)f);
@@ -216,6 +274,11 @@ struct GemmP {
                     // K = 3 * 64 * kwrap logical steps, step kt reads A at plane step (kt < 2 kwrap ? kt : kt - 2 kwrap) - planes
                     // [hi | lo | hi] of A = [hi | lo] - and B at (kt < kwrap ? kt : kt - kwrap) - planes [hi | hi | lo] of B = [W_hi | W_lo]:
                     // a_hi W_hi + a_lo W_hi + a_hi W_lo in one accumulator, no plane stored or fetched from HBM twice.  lda, ldb >= 128 kwrap.
+  int x2 = 0;       // fp16x2 operands (split4_x2 above; 8-phase kernel only): rows of K = 2 K_layer 16-bit units = [fp16 plane | FP8 plane | FP8
+                    // plane]; x2 = K_layer / 64 = number of fp16 K-tiles, the other K_layer / 64 K-tiles are FP8 (first half: A lo8 x B hi8,
+                    // second half: A hi8 x B lo8).  x2_sa: E8M0 scale bytes of B's (the weight's) two FP8 planes, byte 0 | byte 1.
+  int x2_sa = 0;
+  int c_x2 = 0;     // store C in the fp16x2 row format [hi | lo8 | hi8] (ldc in 16-bit units >= 2 N): the A operand of a following x2 GEMM
   int ab_bf16 = 0;  // A and B are 16-bit (else fp32)
   int h_f16 = 0;    // the 16-bit format (operands and, with c_bf16, the output) is IEEE fp16 instead of bf16
   int split = 0;    // 1 = bf16x3: A fp32, B pre-split into [32 hi | 32 lo] bf16 per 32-k block (split_pack_weights);

@@ -330,8 +330,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_nt_kernel(GemmP p) {
           }
           if (p.c_x3) {   // bf16 split [hi | lo], planes N apart (GemmP::c_x3; the small-M fallback of the bf16x3 backbone's fc1)
             u32x2_t h0, l0, h1, l1;
-            split4_bf16(f32x4{v[0], v[1], v[2], v[3]}, h0, l0);
-            split4_bf16(f32x4{v[4], v[5], v[6], v[7]}, h1, l1);
+            split4_h<F16>(f32x4{v[0], v[1], v[2], v[3]}, h0, l0);
+            split4_h<F16>(f32x4{v[4], v[5], v[6], v[7]}, h1, l1);
             char* cp = Cb + ((long)m * p.ldc + n) * 2;
             *(u32x4*)cp = u32x4{h0[0], h0[1], h1[0], h1[1]};
             *(u32x4*)(cp + (long)p.N * 2) = u32x4{l0[0], l0[1], l1[0], l1[1]};
@@ -567,14 +567,15 @@ int gemm_nt(const GemmP& p, hipStream_t st) {
   EC_REQUIRE(p.act != ACT_TANHGATE || p.aux, -1, "gemm_nt: tanh-gate epilogue needs aux");
   EC_REQUIRE(p.tag >= 0 && p.tag < 5, -1, "gemm_nt: bad tag");
   EC_REQUIRE(!(p.split && p.ab_bf16), -1, "gemm_nt: split (bf16x3) mode takes fp32 A and a pre-split B");
-  EC_REQUIRE(!p.c_x3 || (p.ab_bf16 && !p.h_f16 && !p.c_bf16 && p.batch == 1 && p.ldc >= 2l * p.N), -1,
-             "gemm_nt: split output (c_x3) takes bf16 operands, one batch and ldc >= 2 N");
+  EC_REQUIRE(!p.c_x3 || (p.ab_bf16 && !p.c_bf16 && p.batch == 1 && p.ldc >= 2l * p.N), -1,
+             "gemm_nt: split output (c_x3) takes 16-bit operands, one batch and ldc >= 2 N");
   EC_REQUIRE(!p.kwrap || (p.ab_bf16 && p.K == 3 * 64 * p.kwrap && p.lda >= 128l * p.kwrap && p.ldb >= 128l * p.kwrap), -1,
              "gemm_nt: kwrap takes 16-bit two-plane operands of 64 * kwrap elements per plane and K = 3 planes");
   if (p.ab_bf16) {   // large 16-bit problems: the 8-phase 256x256x64 kernel (block GEMMs of the backbone)
     const int rc = gemm8_bf16(p, st);
     if (rc != 0) return rc < 0 ? rc : 0;
   }
+  EC_REQUIRE(!p.x2 && !p.c_x2, -1, "gemm_nt: fp16x2 operands exist on the 8-phase kernel only (K_layer % 128 == 0, N >= 256, N % 16 == 0)");
   // Tile choice.  The fp32 MFMA rate (64 FLOP/clk/SIMD = 614 GFLOP/s per CU) is reached by any of these tiles, so what
   // matters for the head's small problems (M = bs*K = 3200 rows, N = 256) is how evenly the tiles spread over the 256
   // CUs: pick the tile minimising  ceil(tiles / CUs) * tile_area / efficiency.  256x256 only pays for the big backbone

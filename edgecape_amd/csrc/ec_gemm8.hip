@@ -36,6 +36,8 @@
 //     works on 16-byte row segments.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "ec_common.h"
 
 namespace ec {
@@ -79,7 +81,9 @@ constexpr int G8_AHEAD = 5;               // half-tiles the load stream runs ahe
 // planes hi | hi | lo - so no plane is written, stored or fetched from HBM twice (scalar arithmetic in the issue slot only; compiled
 // into these kinds, the table-fp32 kind of the patch embedding and the generic kind).
 // (the generic kind did this first: 12 spilled VGPRs, fragment-wise quarter-line stores - QKV 227 us, fc1 343 us at cfg2)
-enum { G8_GENERIC = 0, G8_BIAS_BF16 = 1, G8_SCALE_BF16 = 2, G8_GELU_BF16 = 3, G8_TAB_H16 = 4, G8_TAB_F32 = 5, G8_F32 = 6, G8_RES_F32 = 7, G8_GELU_X3 = 8 };
+// G8_GELU_X2 (round 6): fc1 of the fp16x2 backbone (ec_common.h split4_x2): C = [fp16 plane | e5m2 lo8 plane | e5m2 hi8 plane] of gelu(acc + bias).
+// The fp16x2 operands themselves are a template flag of the kernel (X2), not a kind: G8_F32 / G8_RES_F32 / G8_GELU_X2 are its epilogues.
+enum { G8_GENERIC = 0, G8_BIAS_BF16 = 1, G8_SCALE_BF16 = 2, G8_GELU_BF16 = 3, G8_TAB_H16 = 4, G8_TAB_F32 = 5, G8_F32 = 6, G8_RES_F32 = 7, G8_GELU_X3 = 8, G8_GELU_X2 = 9 };
 constexpr bool g8_f32_out(int kind) { return kind == G8_TAB_F32 || kind == G8_F32 || kind == G8_RES_F32; }
 
 // GELU for 16-bit outputs (erf form: nn.GELU default, dinov2 Mlp) with ONE transcendental (round 4):
@@ -152,7 +156,7 @@ __device__ __forceinline__ void g8_epilogue_generic(const GemmP& p, f32x4 (&acc)
       if (p.resid) v += *(const f32x4*)(p.resid + (long)m * p.ldr + n);
       if (p.c_x3) {   // bf16 split [hi | lo], planes N apart: the A operand of the next K-concatenated GEMM (fc1 -> fc2, bf16x3 backbone)
         u32x2_t vh, vl;
-        split4_bf16(v, vh, vl);
+        split4_h<F16, true>(v, vh, vl);   // (F16: inside the epilogue's FP16_OVFL window)
         bf16_t* c = (bf16_t*)p.C + (long)m * p.ldc + n;
         *(u32x2_t*)c = vh;
         *(u32x2_t*)(c + p.N) = vl;
@@ -182,7 +186,7 @@ __device__ __forceinline__ void g8_epilogue_generic(const GemmP& p, f32x4 (&acc)
 template <int KIND, bool F16, int LAB>
 __device__ __forceinline__ void g8_piece(f32x4 (&a)[4], const __amdgpu_buffer_rsrc_t rsC, unsigned goff, unsigned ldc2, bool col_ok, char* stg,
                                          const char* bias_lds, const char* gam_lds, int lane, const float* trow = nullptr, int ncols = 64,
-                                         const char* bias_next = nullptr, unsigned plane = 0) {
+                                         const char* bias_next = nullptr, unsigned plane = 0, unsigned goff8 = 0, bool col_ok8 = false) {
   const int wrow = lane & 15, wq = lane >> 4;                       // writer: fragment row, column quad
   const int rrow = lane >> 3, rch = lane & 7;                       // reader: row within 8, 16-byte chunk
   if constexpr (KIND == G8_F32 || KIND == G8_RES_F32) {
@@ -228,8 +232,8 @@ __device__ __forceinline__ void g8_piece(f32x4 (&a)[4], const __amdgpu_buffer_rs
       const int c0 = (ni >> 1) * 32 + (ni & 1) * 16 + wq * 4;
       f32x4 v = a[ni] + *(const f32x4*)(bias_lds + c0 * 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = gelu_fast8<true>(v[e]);
-      split4_bf16(v, vh[ni], vl[ni]);
+      for (int e = 0; e < 4; ++e) v[e] = F16 ? gelu_fast32(v[e]) : gelu_fast8<true>(v[e]);   // fp16 planes carry 22 bits: 6.7e-8 instead of 6.4e-7
+      split4_h<F16, true>(v, vh[ni], vl[ni]);
       a[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
@@ -246,6 +250,51 @@ __device__ __forceinline__ void g8_piece(f32x4 (&a)[4], const __amdgpu_buffer_rs
         const unsigned off = goff + (unsigned)(j * 8) * ldc2;
         __builtin_amdgcn_raw_buffer_store_b128(o, rsC, col_ok ? off + (pl ? plane : 0u) : 0xFFFFFFF0u, 0, 0);
       }
+    }
+    return;
+  }
+  if constexpr (KIND == G8_GELU_X2) {
+    // fc1 of the fp16x2 backbone: gelu(acc + bias) (single-transcendental form, 6.4e-7), split4_x2.  The fp16 plane leaves as in
+    // G8_GELU_X3 (two whole-line stores); then BOTH FP8 planes go through the same 2 KiB slot as [16 rows][64 B lo8 | 64 B hi8] and
+    // leave in two stores of 8 rows x (64 + 64) B: four stores per piece, as the bf16x3 kind.  plane = N bytes (one FP8 plane of a row),
+    // goff8 = byte offset in C of (row r0 + (lane >> 3), lo8 / hi8 plane by lane & 4, column n0 + wc*64 + (lane & 3) * 16).
+    u32x2_t vh[4];
+    unsigned l8[4], h8[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int c0 = (ni >> 1) * 32 + (ni & 1) * 16 + wq * 4;
+      f32x4 v = a[ni] + *(const f32x4*)(bias_lds + c0 * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_fast8<true>(v[e]);
+      split4_x2<true>(v, vh[ni], l8[ni], h8[ni]);
+      a[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int chunk = (ni >> 1) * 4 + (ni & 1) * 2 + (wq >> 1);
+      *(u32x2_t*)(stg + wrow * 128 + ((chunk ^ (wrow & 7)) << 4) + (wq & 1) * 8) = vh[ni];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = j * 8 + rrow;
+      const u32x4 o = *(const u32x4*)(stg + row * 128 + ((rch ^ (row & 7)) << 4));
+      __builtin_amdgcn_raw_buffer_store_b128(o, rsC, col_ok ? goff + (unsigned)(j * 8) * ldc2 : 0xFFFFFFF0u, 0, 0);
+    }
+    // FP8 planes: dword (wq ^ 2 (wrow >> 3)) of 16-byte chunk ((ni >> 1) * 2 + (ni & 1) + 4 * plane) ^ (wrow & 7) - rows r and r + 8 of a
+    // 32-lane write group land on different banks (ds_write_b32: 32 banks = one 128-byte row); the reader of rows 8..15 swaps the halves back
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int chunk = (ni >> 1) * 2 + (ni & 1) + 4 * pl;
+        *(unsigned*)(stg + wrow * 128 + ((chunk ^ (wrow & 7)) << 4) + ((wq ^ ((wrow >> 3) << 1)) << 2)) = pl ? h8[ni] : l8[ni];
+      }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = j * 8 + rrow;
+      u32x4 o = *(const u32x4*)(stg + row * 128 + ((rch ^ (row & 7)) << 4));
+      if (j) o = u32x4{o[2], o[3], o[0], o[1]};
+      __builtin_amdgcn_raw_buffer_store_b128(o, rsC, col_ok8 ? goff8 + (unsigned)(j * 8) * ldc2 : 0xFFFFFFF0u, 0, 0);
     }
     return;
   }
@@ -349,6 +398,34 @@ __device__ __forceinline__ void g8_piece_reg(f32x4 (&a)[4], const __amdgpu_buffe
   }
 }
 
+// One FP8 MFMA of the fp16x2 K-tiles: 128 bytes of a weight row against 128 bytes of an activation row.  The lane's 32 operand bytes are
+// the SAME two 16-byte LDS fragments the fp16 MFMAs of a K-tile use (k halves 0 and 1 of lane group g: bytes 16 g.. and 64 + 16 g.. of the
+// 128-byte row) - which 32 of the 128 k positions a lane group holds does not matter as long as both operands agree, and the scales
+// are per plane, not per 32-element block, so the fragment reads and the LDS image are exactly the fp16 kernel's.
+// Operand A = weights (e4m3, cbsz 0, scale byte sw), operand B = activations (e5m2, blgp 1, scale byte sa): tools/fp8_mfma_probe.hip.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+__device__ __forceinline__ f32x4 g8_mfma_f8(bf16x8 w0, bf16x8 w1, bf16x8 a0, bf16x8 a1, f32x4 c, int sw, int sa) {
+  const i32x8 w = __builtin_shufflevector(__builtin_bit_cast(i32x4, w0), __builtin_bit_cast(i32x4, w1), 0, 1, 2, 3, 4, 5, 6, 7);
+  const i32x8 a = __builtin_shufflevector(__builtin_bit_cast(i32x4, a0), __builtin_bit_cast(i32x4, a1), 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, a, c, 0, 1, 0, sw, 0, sa);
+}
+// The 16 (fp16) / 8 (FP8) MFMAs of one phase: accumulator quadrant acc[AO .. AO + 3][FO .. FO + 1], weight fragments BQ, activation fragments af
+#define G8_MM(AO, FO, BQ)                                                                                                           \
+  do {                                                                                                                              \
+    if constexpr (f8) {                                                                                                             \
+      _Pragma("unroll") for (int fi = 0; fi < 4; ++fi)                                                                              \
+        _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                               \
+          acc[AO + fi][FO + f] = g8_mfma_f8(BQ[f][0], BQ[f][1], af[fi][0], af[fi][1], acc[AO + fi][FO + f], sca, scb);              \
+      break;                                                                                                                        \
+    }                                                                                                                               \
+    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                                                \
+      _Pragma("unroll") for (int fi = 0; fi < 4; ++fi)                                                                              \
+        _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                               \
+          if constexpr (LAB & 8) asm volatile("" ::"v"(BQ[f][kh]), "v"(af[fi][kh]));                                                \
+          else acc[AO + fi][FO + f] = mfma16x16x32_h<F16>(BQ[f][kh], af[fi][kh], acc[AO + fi][FO + f]);                             \
+  } while (0)
+
 // Lane id recomputed in place (two VALU, no live range): values derived from the kernel's `lane` and kept across the K loop get
 // spilled at 256 VGPRs, and a spill reload is a VMEM load whose wait drains the LDS-DMA stream.
 __device__ __forceinline__ int g8_lane_now() {
@@ -384,8 +461,10 @@ template <int N> __device__ __forceinline__ void g8_wait_vm() { asm volatile("s_
 // GELU 117 vs 101 us): work moved into one wave's memory segment stretches that barrier interval for the partner's MFMA block too
 // (MI355X_MICROARCH.md "Two waves per SIMD", item 3), so it was removed.  Also rejected in round 1: one barrier per phase with the
 // groups half a phase apart (8192^3 1300 vs 1355 TFLOP/s) and two 32-MFMA phases per K-tile (+2 % at 8192^3, 0 at K = 768).
-template <int KIND, int TAG, bool F16 = false, int LAB = 0>
+template <int KIND, int TAG, bool F16 = false, int LAB = 0, bool X2 = false>
 __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
+  static_assert(!X2 || (F16 && (KIND == G8_F32 || KIND == G8_RES_F32 || KIND == G8_GELU_X2)), "fp16x2 operands: fp16 main product, three epilogues");
+  static_assert(KIND != G8_GELU_X2 || X2, "the fp16x2 output format is written by the fp16x2 GEMM");
   // Epilogue pieces by lane swaps (no LDS round trip: fc1 + GELU, VALU-bound, 101 -> 95 us) or through the LDS staging slot (whole
   // 128-byte lines per store: the bias / LayerScale kinds are bound by the stores themselves, QKV 64.6 vs 66.4 us); LAB & 128 flips it.
   constexpr bool REGEPI = (KIND == G8_GELU_BF16) != ((LAB & 128) != 0);
@@ -394,8 +473,8 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   constexpr bool NODRAIN = FAST && !(LAB & 64);              // the load stream is not drained at the seam
   constexpr bool GAMMA = KIND == G8_SCALE_BF16 || KIND == G8_RES_F32;
   constexpr int NB = GAMMA ? 2 : 1;                          // LDS-DMA pieces of one bias (+ LayerScale) slice
-  constexpr int NST = (KIND == G8_GELU_X3 || g8_f32_out(KIND)) ? 32 : 16;   // global stores of one tile's epilogue per wave
-  constexpr bool WRAP = KIND == G8_GENERIC || KIND == G8_TAB_F32 || KIND == G8_F32 || KIND == G8_RES_F32 || KIND == G8_GELU_X3;   // GemmP::kwrap
+  constexpr int NST = (KIND == G8_GELU_X3 || KIND == G8_GELU_X2 || g8_f32_out(KIND)) ? 32 : 16;   // global stores of one tile's epilogue per wave
+  constexpr bool WRAP = !X2 && (KIND == G8_GENERIC || KIND == G8_TAB_F32 || KIND == G8_F32 || KIND == G8_RES_F32 || KIND == G8_GELU_X3);   // GemmP::kwrap
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -612,6 +691,10 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
           if constexpr (KIND == G8_TAB_H16 || KIND == G8_TAB_F32) {
             const float* trow = p.table + (long)((r0 + (lane & 15)) % p.period) * p.ldt + n0 + wc * 64;
             g8_piece<KIND, F16, LAB>(acc[mi0 + d], rsC, goff, ldc2, col_ok, stg, bl, gl, lane, trow, min(max(p.N - n0 - wc * 64, 0), 64));
+          } else if constexpr (KIND == G8_GELU_X2) {
+            const unsigned goff8 = (unsigned)(r0 + (lane >> 3)) * ldc2 + (unsigned)p.N * (2u + ((lane >> 2) & 1)) + (unsigned)(n0 + wc * 64) + (unsigned)(lane & 3) * 16u;
+            g8_piece<KIND, F16, LAB>(acc[mi0 + d], rsC, goff, ldc2, col_ok, stg, bl, gl, lane, nullptr, 64, nullptr, (unsigned)p.N, goff8,
+                                     n0 + wc * 64 + (lane & 3) * 16 < p.N);
           } else if constexpr (KIND == G8_F32 || KIND == G8_RES_F32 || KIND == G8_GELU_X3) {
             g8_piece<KIND, F16, LAB>(acc[mi0 + d], rsC, goff, ldc2, col_ok, stg, bl, gl, lane, nullptr, min(max(p.N - n0 - wc * 64, 0), 64), nullptr,
                                      (unsigned)p.N * 2u);
@@ -624,18 +707,30 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   };
 
   if constexpr (LAB & 8192) { if (wr == 1) __builtin_amdgcn_s_setprio(1); }   // lab: STATIC priority for the younger wave group, no per-phase flips
+  const int nk16 = X2 ? p.x2 : 0;                      // fp16x2: number of fp16 K-tiles (the other nk - nk16 = nk16 are FP8)
+  // E8M0 scale bytes of the weight row's two FP8 planes, replicated into all four bytes of the MFMA's scale register: every lane and
+  // byte carries the plane's scale, so the result does not depend on which (lane, byte) the hardware reads for a 32-element block
+  const int x2_sa0 = (p.x2_sa & 0xff) * 0x01010101, x2_sa1 = ((p.x2_sa >> 8) & 0xff) * 0x01010101;
   int it = 0;                                          // tile counter of this workgroup (bias parity)
   for (int t = t_first; t < t_end; t = t_nxt, t_nxt = t_nn, t_nn = dyn ? t_end : t_nxt + nslot, ++it) {
     const int m0 = (t / ntn) << 8, n0 = (t % ntn) << 8;
     if (it < 9) stamp(1 + 3 * it);
-    for (int kt2 = 0; kt2 < nk; kt2 += 2) {
+    // One PAIR of K-tiles (both LDS buffers).  F8 (fp16x2 operands only): the pair's MFMAs are the FP8 ones - a second instantiation of
+    // the same body in a loop of its own, so neither loop carries a branch around its MFMA blocks.
+    auto kpair = [&](auto f8c, const int kt2) __attribute__((always_inline)) {
+      constexpr bool f8 = decltype(f8c)::value;
 #pragma unroll
       for (int buf = 0; buf < 2; ++buf) {
         const char* ab = a_base + buf * G8_KT;
         const char* bb = b_base + buf * G8_KT;
-        const bool head = buf == 0 && kt2 == 0;                        // first K-tile of the tile
+        const bool head = !f8 && buf == 0 && kt2 == 0;                 // first K-tile of the tile (never an FP8 one)
         const bool seam = NODRAIN && head && it > 0;                   // ... with the previous tile's stores in the VM queue
         const bool rd = !(LAB & 2048) || (it == 0 && kt2 == 0);        // lab: fragment reads only in the workgroup's first K-tile pair
+        // fp16x2 operands: K-tiles [0, nk16) are fp16 MFMAs, [nk16, nk16 + nk16 / 2) FP8 MFMAs of A's lo8 plane against B's hi8 plane,
+        // the rest A's hi8 plane against B's lo8 plane (uniform per K-tile: scalar branch, scalar selects)
+        const bool pl1 = f8 && kt2 + buf >= nk16 + (nk16 >> 1);
+        const int sca = pl1 ? x2_sa1 : x2_sa0, scb = (pl1 ? X2_SCALE_HI8 : X2_SCALE_LO8) * 0x01010101;
+        (void)sca; (void)scb;
         // ---------------- phase 0: quadrant (m-half 0, n-half 0)
         if (rd) {
 #pragma unroll
@@ -663,13 +758,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
         }
         G8_BAR();
         if constexpr (!(LAB & 24576)) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-          for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-            for (int f = 0; f < 2; ++f)
-              if constexpr (LAB & 8) asm volatile("" ::"v"(b0[f][kh]), "v"(af[fi][kh])); else acc[fi][f] = mfma16x16x32_h<F16>(b0[f][kh], af[fi][kh], acc[fi][f]);
+        G8_MM(0, 0, b0);
         if constexpr (!(LAB & 24576)) __builtin_amdgcn_s_setprio(0);
         G8_BAR();
         // ---------------- phase 1: quadrant (0, 1)
@@ -687,13 +776,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
         }
         G8_BAR();
         if constexpr (!(LAB & 24576)) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-          for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-            for (int f = 0; f < 2; ++f)
-              if constexpr (LAB & 8) asm volatile("" ::"v"(b1[f][kh]), "v"(af[fi][kh])); else acc[fi][2 + f] = mfma16x16x32_h<F16>(b1[f][kh], af[fi][kh], acc[fi][2 + f]);
+        G8_MM(0, 2, b1);
         if constexpr (!(LAB & 24576)) __builtin_amdgcn_s_setprio(0);
         G8_BAR();
         // ---------------- phase 2: quadrant (1, 1)
@@ -716,13 +799,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
         }
         G8_BAR();
         if constexpr (!(LAB & 24576)) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-          for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-            for (int f = 0; f < 2; ++f)
-              if constexpr (LAB & 8) asm volatile("" ::"v"(b1[f][kh]), "v"(af[fi][kh])); else acc[4 + fi][2 + f] = mfma16x16x32_h<F16>(b1[f][kh], af[fi][kh], acc[4 + fi][2 + f]);
+        G8_MM(4, 2, b1);
         if constexpr (!(LAB & 24576)) __builtin_amdgcn_s_setprio(0);
         G8_BAR();
         // ---------------- phase 3: quadrant (1, 0); the load stream moves on to the next K-tile
@@ -746,16 +823,14 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
         }
         G8_BAR();
         if constexpr (!(LAB & 24576)) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-          for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-            for (int f = 0; f < 2; ++f)
-              if constexpr (LAB & 8) asm volatile("" ::"v"(b0[f][kh]), "v"(af[fi][kh])); else acc[4 + fi][f] = mfma16x16x32_h<F16>(b0[f][kh], af[fi][kh], acc[4 + fi][f]);
+        G8_MM(4, 0, b0);
         if constexpr (!(LAB & 24576)) __builtin_amdgcn_s_setprio(0);
         if (buf == 0 || kt2 + 2 < nk) G8_BAR();   // the tile's last barrier is placed around its epilogue
       }
+    };
+    for (int kt2 = 0; kt2 < (X2 ? nk16 : nk); kt2 += 2) kpair(std::false_type{}, kt2);
+    if constexpr (X2) {
+      for (int kt2 = nk16; kt2 < nk; kt2 += 2) kpair(std::true_type{}, kt2);
     }
     // ---- epilogue at the end of the tile.  Both groups run it concurrently: group 0 passes the tile's last barrier first.
     if (it < 9) stamp(2 + 3 * it);
@@ -805,7 +880,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
 // Per-device launch state: the 160 KiB dynamic-LDS attribute is a per-device function attribute and the CU count differs per
 // device, so a process that drives several GPUs (one engine per device) gets both for every device it touches.
 namespace {
-struct G8Dev { bool attr_done = false; int ncu = 0; float* zeros = nullptr; };   // zeros: the bias of a table kind called without one
+struct G8Dev { bool attr_done = false, x2_attr_done = false; int ncu = 0; float* zeros = nullptr; };   // zeros: the bias of a table kind called without one
 G8Dev g8_dev[64];
 }  // namespace
 
@@ -814,9 +889,40 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
   static const int disable = getenv("EC_GEMM8_OFF") ? atoi(getenv("EC_GEMM8_OFF")) : 0;
   if (disable) return 0;
   if (!p.ab_bf16 || p.batch != 1 || p.act == ACT_TANHGATE) return 0;
-  if (p.K % 128 != 0 || p.N % 16 != 0 || p.M < 1024 || p.N < 256) return 0;
+  // (fp16x2 operands: this kernel is their ONLY GEMM - any M, so that an image's features do not depend on the batch it rides in)
+  if (p.K % 128 != 0 || p.N % 16 != 0 || (p.M < 1024 && !p.x2) || p.N < 256) return 0;
   if ((long)p.M * p.lda * 2 >= (1l << 32) - (1l << 20) || (long)p.N * p.ldb * 2 >= (1l << 32) - (1l << 20)) return 0;   // 32-bit buffer offsets
   typedef void (*kern_t)(GemmP);
+  int dev = 0;
+  EC_HIP(hipGetDevice(&dev));
+  EC_REQUIRE(dev >= 0 && dev < 64, -1, "gemm8: device ordinal out of range");
+  G8Dev& ds = g8_dev[dev];
+  if (p.x2) {
+    // fp16x2 operands (GemmP::x2): QKV (fp32 out), proj / fc2 (LayerScale + in-place fp32 residual), fc1 (GELU, fp16x2 planes out)
+    EC_REQUIRE(p.h_f16 && p.x2 % 2 == 0 && p.K == 128 * p.x2 && !p.kwrap && !p.split && p.bias && !p.table && !p.aux, -1,
+               "gemm8: fp16x2 operands take K = 2 K_layer (16-bit units) = 128 * x2, K_layer % 128 == 0, fp16 main plane and a bias");
+    int k3;
+    if (p.c_x2 && p.act == ACT_GELU && !p.gamma && !p.resid && p.ldc >= 2l * p.N && (long)p.M * p.ldc * 2 < (1l << 31)) k3 = 2;
+    else if (!p.c_x2 && !p.c_bf16 && !p.c_x3 && p.act == ACT_NONE && p.ldc % 4 == 0 && (long)p.M * p.ldc * 4 < (1l << 31) && !p.resid && !p.gamma) k3 = 0;
+    else if (!p.c_x2 && !p.c_bf16 && !p.c_x3 && p.act == ACT_NONE && p.ldc % 4 == 0 && (long)p.M * p.ldc * 4 < (1l << 31) && p.resid == (const float*)p.C && p.ldr == p.ldc && p.gamma) k3 = 1;
+    else { set_error("gemm8: fp16x2 operands with an epilogue other than fp32 | LayerScale + in-place residual | GELU + fp16x2 planes"); return -1; }
+    static const kern_t x2_table[3][5] = {
+        {gemm8_bf16_kernel<G8_F32, 0, true, 0, true>, gemm8_bf16_kernel<G8_F32, 1, true, 0, true>, gemm8_bf16_kernel<G8_F32, 0, true, 0, true>, gemm8_bf16_kernel<G8_F32, 0, true, 0, true>, gemm8_bf16_kernel<G8_F32, 0, true, 0, true>},
+        {gemm8_bf16_kernel<G8_RES_F32, 0, true, 0, true>, gemm8_bf16_kernel<G8_RES_F32, 0, true, 0, true>, gemm8_bf16_kernel<G8_RES_F32, 2, true, 0, true>, gemm8_bf16_kernel<G8_RES_F32, 0, true, 0, true>, gemm8_bf16_kernel<G8_RES_F32, 4, true, 0, true>},
+        {gemm8_bf16_kernel<G8_GELU_X2, 3, true, 0, true>, gemm8_bf16_kernel<G8_GELU_X2, 3, true, 0, true>, gemm8_bf16_kernel<G8_GELU_X2, 3, true, 0, true>, gemm8_bf16_kernel<G8_GELU_X2, 3, true, 0, true>, gemm8_bf16_kernel<G8_GELU_X2, 3, true, 0, true>}};
+    if (!ds.x2_attr_done) {
+      for (int k = 0; k < 3; ++k)
+        for (int t = 0; t < 5; ++t) EC_HIP(hipFuncSetAttribute((const void*)x2_table[k][t], hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));
+      if (!ds.ncu) EC_HIP(hipDeviceGetAttribute(&ds.ncu, hipDeviceAttributeMultiprocessorCount, dev));
+      ds.x2_attr_done = true;
+    }
+    const long nt = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    GemmP q = p;
+    q.sched = nullptr;
+    hipLaunchKernelGGL(x2_table[k3][p.tag], dim3((unsigned)(nt < ds.ncu ? nt : ds.ncu)), dim3(512), G8_LDS, st, q);
+    EC_LAUNCH_CHECK();
+    return 1;
+  }
   // epilogue kind from the options; TAG only names the symbol for rocprof (1 qkv, 2 proj, 3 fc1, 4 fc2)
   int kind = G8_GENERIC;
   if (p.c_bf16 && p.bias && !p.resid && !p.table && (long)p.M * p.ldc * 2 < (1l << 31)) {
@@ -826,7 +932,7 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
   } else if (p.table && !p.resid && !p.gamma && !p.aux && p.act == ACT_NONE && p.period > 0 && p.ldt % 4 == 0 && p.ldc % 4 == 0 &&
              (long)p.M * p.ldc * (p.c_bf16 ? 2 : 4) < (1l << 31)) {
     kind = p.c_bf16 ? G8_TAB_H16 : G8_TAB_F32;   // (the A/B switch back to the generic epilogue, EC_G8_TAB, went in round 5)
-  } else if (p.c_x3 && !p.h_f16 && p.bias && p.act == ACT_GELU && !p.gamma && !p.resid && !p.table && (long)p.M * p.ldc * 2 < (1l << 31)) {
+  } else if (p.c_x3 && p.bias && p.act == ACT_GELU && !p.gamma && !p.resid && !p.table && (long)p.M * p.ldc * 2 < (1l << 31)) {
     kind = G8_GELU_X3;
   } else if (!p.c_bf16 && !p.c_x3 && p.bias && !p.table && !p.aux && p.act == ACT_NONE && p.ldc % 4 == 0 && (long)p.M * p.ldc * 4 < (1l << 31)) {
     // (measured against the generic epilogue behind a switch that is gone again, cfg2 bf16x3 / bf16x3, interleaved on one box:
@@ -844,13 +950,9 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
       {gemm8_bf16_kernel<5, 0, F>, gemm8_bf16_kernel<5, 0, F>, gemm8_bf16_kernel<5, 0, F>, gemm8_bf16_kernel<5, 0, F>, gemm8_bf16_kernel<5, 0, F>}, \
       {gemm8_bf16_kernel<6, 0, F>, gemm8_bf16_kernel<6, 1, F>, gemm8_bf16_kernel<6, 0, F>, gemm8_bf16_kernel<6, 0, F>, gemm8_bf16_kernel<6, 0, F>}, \
       {gemm8_bf16_kernel<7, 0, F>, gemm8_bf16_kernel<7, 0, F>, gemm8_bf16_kernel<7, 2, F>, gemm8_bf16_kernel<7, 0, F>, gemm8_bf16_kernel<7, 4, F>}, \
-      {gemm8_bf16_kernel<8, 3, false>, gemm8_bf16_kernel<8, 3, false>, gemm8_bf16_kernel<8, 3, false>, gemm8_bf16_kernel<8, 3, false>, gemm8_bf16_kernel<8, 3, false>}
+      {gemm8_bf16_kernel<8, 3, F>, gemm8_bf16_kernel<8, 3, F>, gemm8_bf16_kernel<8, 3, F>, gemm8_bf16_kernel<8, 3, F>, gemm8_bf16_kernel<8, 3, F>}
   static const kern_t table[2][9][5] = {{G8_ROW(false)}, {G8_ROW(true)}};
 #undef G8_ROW
-  int dev = 0;
-  EC_HIP(hipGetDevice(&dev));
-  EC_REQUIRE(dev >= 0 && dev < 64, -1, "gemm8: device ordinal out of range");
-  G8Dev& ds = g8_dev[dev];
   if (!ds.attr_done) {
     for (int f = 0; f < 2; ++f)
       for (int k = 0; k < 9; ++k)

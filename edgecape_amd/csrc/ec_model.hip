@@ -6,6 +6,7 @@
 // (bf16 for GEMM operands in bf16 mode), batch-first — unlike the reference's seq-first [L, bs, c] —
 // so every Linear is one NT GEMM over M = batch*tokens rows and attention reads heads as column slices.
 #include <math.h>
+#include <cmath>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -46,6 +47,8 @@ struct Lin {  // a Linear layer view: W [N,K] (+ optional bf16 copy), bias [N]
   const bf16_t* wf16 = nullptr;  // plain IEEE fp16 [N, K] copy (single-pass fp16 layers of the head's mixed precision): the 8-phase 16-bit
                                // GEMM runs the large image-row projections of the skeleton head on it when a 16-bit copy of A exists
   const bf16_t* w16x3 = nullptr; // bf16 [N, 2 K] = [W_hi | W_lo]: K-concatenated bf16x3 operand of the 8-phase GEMM (EC_BF16X3 backbone, GemmP::kwrap)
+  const void* w_x2 = nullptr;    // fp16x2 rows [K x fp16 W_hi | K x e4m3 of W * 2^s1 | K x e4m3 of (W - W_hi) * 2^s2], 4 K bytes each (EC_F16X2 backbone)
+  int x2_sa = 0;                 // ... E8M0 scale bytes of the two FP8 planes: (127 - s1) | (127 - s2) << 8 (GemmP::x2_sa)
   const float* b = nullptr;
   int N = 0, K = 0;
   bool w16_is_f16 = false;     // w16 holds IEEE fp16 (EC_F16 backbone) instead of bf16
@@ -86,6 +89,10 @@ struct ec_model {
   bool bbf16 = false;        // ... in IEEE fp16 (EC_F16) instead of bf16 (EC_BF16)
   bool bb_split = false;     // EC_BF16X3 backbone: fp32 activations, every MFMA operand split hi+lo bf16 (3 MFMAs per product)
   bool bb_x3 = false;        // ... its block GEMMs in the K-CONCATENATED form on the 8-phase 16-bit kernel (run_backbone); EC_BB_X3=0: A/B
+  bool bb_x3_f16 = false;    // ... over IEEE fp16 planes (22 significand bits per operand) instead of bf16 planes (16): the fp16x2 mode's patch
+                             // embedding; for the bf16x3 mode itself only behind EC_X3_F16=1 (measured at scale, not adopted)
+  bool bb_x2 = false;        // EC_F16X2 backbone: the block GEMMs on fp16x2 operands (ec_common.h split4_x2; two MFMA units per product); the
+                             // rest as the fp16-planes bf16x3 form (fp32 residual stream, split attention, fp16x3 patch embedding)
   bool head_split = false;   // head GEMMs in bf16x3 (ec_gemm.hip GM_SPLIT)
   bool head_mixed = false;   // ... except the Linear layers of the skeleton head and the decoder layers: single-pass fp16 (GM_SPLIT1)
   bool cur_h1 = false;       // build time: the Lin being made belongs to that set
@@ -261,8 +268,13 @@ static int upload_x3(ec_model* m, const float* W, long rows, long K, const bf16_
     bf16_t* row = &w3[(size_t)n * 2 * K];
     for (long k = 0; k < K; ++k) {
       const float w = W[n * K + k];
-      const bf16_t h = f2bf(w);
-      row[k] = h; row[K + k] = f2bf(w - bf2f(h));
+      if (m->bb_x3_f16) {   // fp16 planes: the lo part of a small weight is an fp16 subnormal (kept by the matrix pipe)
+        const bf16_t h = f2half_host(w);
+        row[k] = h; row[K + k] = f2half_host(w - half2f_host(h));
+      } else {
+        const bf16_t h = f2bf(w);
+        row[k] = h; row[K + k] = f2bf(w - bf2f(h));
+      }
     }
   }
   bf16_t* p3 = nullptr;
@@ -270,6 +282,57 @@ static int upload_x3(ec_model* m, const float* W, long rows, long K, const bf16_
   if (rc) return rc;
   EC_HIP(hipMemcpy(p3, w3.data(), w3.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
   *out = p3;
+  return 0;
+}
+// host: float -> OCP e4m3fn bit pattern, round to nearest even, saturating at +-448 (the weights' FP8 planes are packed once at ec_finalize)
+static uint8_t f2e4m3_host(float f) {
+  const uint8_t sgn = std::signbit(f) ? 0x80 : 0;
+  float a = std::fabs(f);
+  if (std::isnan(a)) return sgn | 0x7f;
+  if (a > 448.f) a = 448.f;
+  if (a < 0.0009765625f) return sgn;                                  // below 2^-10: half the smallest subnormal (a tie goes to the even 0)
+  int e;
+  (void)std::frexp(a, &e);
+  const int E = e - 1;                                                // a = 1.xxx * 2^E
+  if (E < -6) return sgn | (uint8_t)std::nearbyint(std::ldexp(a, 9));   // subnormal: multiples of 2^-9 (8 = the smallest normal's pattern)
+  int q = (int)std::nearbyint(std::ldexp(a, 3 - E)), Eb = E + 7;     // 8 .. 16
+  if (q == 16) { q = 8; ++Eb; }
+  const int code = (Eb << 3) | (q - 8);
+  return sgn | (uint8_t)(code > 0x7e ? 0x7e : code);
+}
+// fp16x2 weight rows (ec_common.h, split4_x2): [W_hi fp16 | e4m3(W * 2^s1) | e4m3((W - W_hi) * 2^s2)], s = the power of two that puts the
+// plane's largest magnitude into e4m3's top binade (256 .. 448]
+static int pack_x2_weights(const float* W, long rows, long K, std::vector<uint8_t>& w, int* sa) {
+  EC_REQUIRE(K % 128 == 0, EC_ERR_ARG, "fp16x2 packing needs K % 128 == 0");
+  float amax_w = 0.f, amax_l = 0.f;
+  for (long i = 0; i < rows * K; ++i) {
+    amax_w = std::max(amax_w, std::fabs(W[i]));
+    amax_l = std::max(amax_l, std::fabs(W[i] - half2f_host(f2half_host(W[i]))));
+  }
+  auto pow2 = [](float amax) { return amax > 0.f && std::isfinite(amax) ? std::min(100, std::max(-100, (int)std::floor(std::log2(448.0 / amax)))) : 0; };
+  const int s1 = pow2(amax_w), s2 = pow2(amax_l);
+  w.resize((size_t)rows * 4 * K);
+  for (long n = 0; n < rows; ++n) {
+    uint8_t* row = &w[(size_t)n * 4 * K];
+    for (long k = 0; k < K; ++k) {
+      const float v = W[n * K + k];
+      const bf16_t h = f2half_host(v);
+      ((bf16_t*)row)[k] = h;
+      row[2 * K + k] = f2e4m3_host(std::ldexp(v, s1));
+      row[3 * K + k] = f2e4m3_host(std::ldexp(v - half2f_host(h), s2));
+    }
+  }
+  *sa = (127 - s1) | ((127 - s2) << 8);
+  return 0;
+}
+static int upload_x2(ec_model* m, const float* W, long rows, long K, const void** out, int* sa) {
+  std::vector<uint8_t> w;
+  int rc = pack_x2_weights(W, rows, K, w, sa);
+  if (rc) return rc;
+  void* p = nullptr;
+  if ((rc = dmalloc(m, &p, w.size()))) return rc;
+  EC_HIP(hipMemcpy(p, w.data(), w.size(), hipMemcpyHostToDevice));
+  *out = p;
   return 0;
 }
 // fragment-major split packing for the row-chain kernel; shapes the kernel cannot take simply get no such copy
@@ -306,6 +369,9 @@ static int make_lin(ec_model* m, const std::string& wname, const std::string& bn
     int rc = upload16(m, w->host, &out->w16);
     if (rc) return rc;
     out->w16_is_f16 = m->bbf16;
+  } else if (m->bb_x2 && !name_is_head(wname)) {   // fp16x2 backbone: the only copy its block GEMMs read
+    int rc = upload_x2(m, w->host.data(), out->N, out->K, &out->w_x2, &out->x2_sa);
+    if (rc) return rc;
   } else if (m->bb_x3 && !name_is_head(wname)) {   // bf16x3 backbone, K-concatenated form: the only copy its GEMMs read
     int rc = upload_x3(m, w->host.data(), out->N, out->K, &out->w16x3);
     if (rc) return rc;
@@ -489,15 +555,30 @@ static int linear(const void* A, long lda, bool a16, const Lin& W, void* C, long
 // K-concatenated bf16x3 Linear: A = bf16 [M, 2 K] planes [hi | lo] (row stride 2 K), W.w16x3 = [W_hi | W_lo]; C fp32, or (c_x3) the
 // split planes of the result, row stride ldc
 static int linear_x3(const void* A, const Lin& W, void* C, long ldc, bool c_x3, int M, int act, hipStream_t st, const float* gamma,
-                     const float* resid, long ldr, int tag) {
+                     const float* resid, long ldr, int tag, bool f16) {
   EC_REQUIRE(W.w16x3 != nullptr, EC_ERR_STATE, "linear_x3: K-concatenated weight copy was not built");
   GemmP p;
   p.tag = tag;
-  p.A = A; p.lda = 2l * W.K; p.ab_bf16 = 1; p.h_f16 = 0;
+  p.A = A; p.lda = 2l * W.K; p.ab_bf16 = 1; p.h_f16 = f16 ? 1 : 0;
   p.B = W.w16x3; p.ldb = 2l * W.K; p.kwrap = W.K / 64;
   p.C = C; p.ldc = ldc; p.c_x3 = c_x3 ? 1 : 0;
   p.bias = W.b; p.gamma = gamma; p.resid = resid; p.ldr = ldr;
   p.M = M; p.N = W.N; p.K = 3 * W.K; p.act = act;
+  return gemm_nt(p, st);
+}
+
+// fp16x2 Linear (EC_F16X2 backbone): A = fp16x2 rows [hi | lo8 | hi8] of W.K values (row stride 2 K 16-bit units), W.w_x2 likewise; C fp32
+// (optionally LayerScale + the in-place residual), or (c_x2) the fp16x2 rows of gelu(.), row stride ldc 16-bit units
+static int linear_x2(const void* A, const Lin& W, void* C, long ldc, bool c_x2, int M, int act, hipStream_t st, const float* gamma,
+                     const float* resid, long ldr, int tag) {
+  EC_REQUIRE(W.w_x2 != nullptr, EC_ERR_STATE, "linear_x2: fp16x2 weight copy was not built");
+  GemmP p;
+  p.tag = tag;
+  p.A = A; p.lda = 2l * W.K; p.ab_bf16 = 1; p.h_f16 = 1;
+  p.B = W.w_x2; p.ldb = 2l * W.K; p.x2 = W.K / 64; p.x2_sa = W.x2_sa;
+  p.C = C; p.ldc = ldc; p.c_x2 = c_x2 ? 1 : 0;
+  p.bias = W.b; p.gamma = gamma; p.resid = resid; p.ldr = ldr;
+  p.M = M; p.N = W.N; p.K = 2 * W.K; p.act = act;
   return gemm_nt(p, st);
 }
 
@@ -539,11 +620,11 @@ static int run_backbone(ec_model* m, const float* const* imgs, const int* counts
   const int Kpe = pb3 ? 2 * m->Kp : px3 ? 3 * m->Kp : m->Kp;   // row length of the patch rows / weight rows in memory
   for (int s = 0, at = 0; s < n_src; at += counts[s], ++s)
     if (counts[s] > 0)
-      RUN(im2col14(imgs[s], (char*)m->bb_h + (size_t)at * T * Kpe * (h16 || pb3 ? 2 : 4), pb3 ? 4 : px3 ? 3 : hfmt, counts[s], m->H, m->W, m->gh, m->gw, m->Kp, st));
+      RUN(im2col14(imgs[s], (char*)m->bb_h + (size_t)at * T * Kpe * (h16 || pb3 ? 2 : 4), pb3 ? (m->bb_x3_f16 ? 5 : 4) : px3 ? 3 : hfmt, counts[s], m->H, m->W, m->gh, m->gw, m->Kp, st));
   {  // patch embedding: ONE GEMM over all n*T token rows (the zero cls rows produce bias + pos[0], overwritten below);
      // epilogue adds the conv bias and the positional table row m % T
     GemmP p;
-    p.A = m->bb_h; p.lda = Kpe; p.ab_bf16 = h16 || pb3; p.h_f16 = m->bbf16;
+    p.A = m->bb_h; p.lda = Kpe; p.ab_bf16 = h16 || pb3; p.h_f16 = m->bbf16 || (pb3 && m->bb_x3_f16);
     p.split = (m->bb_split && !pb3) ? 1 : 0;
     p.B = px3 ? (const void*)m->patch_w16x3 : h16 ? (const void*)m->patch.w16 : m->patch.wsel(m->bb_split); p.ldb = Kpe;
     p.C = m->bb_x; p.ldc = C;
@@ -563,13 +644,15 @@ static int run_backbone(ec_model* m, const float* const* imgs, const int* counts
   int* const sched = (m->g8_dyn_mode == 1 || (m->g8_dyn_mode == 2 && m->dq_active)) ? m->g8_sched : nullptr;
   for (size_t i = 0; i < m->blocks.size(); ++i) {
     const BBlock& b = m->blocks[i];
-    const bool x3 = m->bb_x3;
-    RUN(ln(m->bb_x, C, m->bb_xn, x3 ? 2 * C : C, x3 ? 3 : hfmt, b.n1, (int)M, C, 1e-6f, st, 0, pend, C, pend2));
+    const bool x3 = m->bb_x3, xf = m->bb_x3_f16, x2 = m->bb_x2;
+    RUN(ln(m->bb_x, C, m->bb_xn, x3 ? 2 * C : C, x2 ? 6 : x3 ? (xf ? 5 : 3) : hfmt, b.n1, (int)M, C, 1e-6f, st, 0, pend, C, pend2));
     pend = pend2 = nullptr;
     const bool prof = m->prof_on && (m->prof_mode != 2 || i == m->prof_pass % m->blocks.size()) && m->prof_used + 2 <= m->prof_ev.size();
     if (prof) EC_HIP(hipEventRecord(m->prof_ev[m->prof_used++], st));
-    if (x3) {
-      RUN(linear_x3(m->bb_xn, b.qkv, m->bb_qkv, 3 * C, false, (int)M, ACT_NONE, st, nullptr, nullptr, 0, 1));
+    if (x2) {
+      RUN(linear_x2(m->bb_xn, b.qkv, m->bb_qkv, 3 * C, false, (int)M, ACT_NONE, st, nullptr, nullptr, 0, 1));
+    } else if (x3) {
+      RUN(linear_x3(m->bb_xn, b.qkv, m->bb_qkv, 3 * C, false, (int)M, ACT_NONE, st, nullptr, nullptr, 0, 1, xf));
     } else {
       GemmP p;
       p.tag = 1;
@@ -589,17 +672,23 @@ static int run_backbone(ec_model* m, const float* const* imgs, const int* counts
     a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
     a.sQ = a.sK = a.sV = (long)T * 3 * C; a.sO = (long)T * C;
     a.B = n; a.H = nh; a.Lq = T; a.Lk = T; a.hd = C / nh; a.bf16 = h16; a.f16 = m->bbf16; a.split = m->bb_split ? 1 : 0;
-    if (x3) { a.o_x3 = 1; a.ldo = 2 * C; a.sO = (long)T * 2 * C; }
+    if (x3) { a.o_x3 = x2 ? 3 : xf ? 2 : 1; a.ldo = 2 * C; a.sO = (long)T * 2 * C; }
     RUN(attention(a, st));
-    if (x3) {
+    if (x2) {
+      // fp16x2 (round 6): the same four launches on fp16x2 operands - a_hi W_hi in fp16 MFMAs, both correction terms in one FP8 pass
+      RUN(linear_x2(m->bb_att, b.proj, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls1, m->bb_x, C, 2));
+      RUN(ln(m->bb_x, C, m->bb_xn, 2 * C, 6, b.n2, (int)M, C, 1e-6f, st));
+      RUN(linear_x2(m->bb_xn, b.fc1, m->bb_h, 8 * C, true, (int)M, ACT_GELU, st, nullptr, nullptr, 0, 3));
+      RUN(linear_x2(m->bb_h, b.fc2, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls2, m->bb_x, C, 4));
+    } else if (x3) {
       // K-concatenated bf16x3 (round 5): every block GEMM is ONE 16-bit GEMM of depth 3 K on the 8-phase kernel - activations as bf16
       // [hi | lo] planes written by their producers (LayerNorm, attention, the fc1 epilogue) and walked hi | lo | hi by the load stream,
       // weights [W_hi | W_lo] walked hi | hi | lo (GemmP::kwrap) - with the fp32 epilogue of the exact mode (residual added in place);
       // the same three products per multiply as the split-on-load kernel
-      RUN(linear_x3(m->bb_att, b.proj, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls1, m->bb_x, C, 2));
-      RUN(ln(m->bb_x, C, m->bb_xn, 2 * C, 3, b.n2, (int)M, C, 1e-6f, st));
-      RUN(linear_x3(m->bb_xn, b.fc1, m->bb_h, 8 * C, true, (int)M, ACT_GELU, st, nullptr, nullptr, 0, 3));
-      RUN(linear_x3(m->bb_h, b.fc2, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls2, m->bb_x, C, 4));
+      RUN(linear_x3(m->bb_att, b.proj, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls1, m->bb_x, C, 2, xf));
+      RUN(ln(m->bb_x, C, m->bb_xn, 2 * C, xf ? 5 : 3, b.n2, (int)M, C, 1e-6f, st));
+      RUN(linear_x3(m->bb_xn, b.fc1, m->bb_h, 8 * C, true, (int)M, ACT_GELU, st, nullptr, nullptr, 0, 3, xf));
+      RUN(linear_x3(m->bb_h, b.fc2, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls2, m->bb_x, C, 4, xf));
     } else if (h16) {
       RUN(linear(m->bb_att, C, true, b.proj, m->bb_y, C, true, (int)M, ACT_NONE, st, b.ls1, nullptr, 0, nullptr, 0, 1, nullptr, 0, 2));
       RUN(ln(m->bb_x, C, m->bb_xn, C, hfmt, b.n2, (int)M, C, 1e-6f, st, 0, m->bb_y, C, nullptr, false));
@@ -1691,10 +1780,16 @@ int ec_create(const ec_config* cfg, ec_handle* out) {
   m->gh = m->H / cfg->patch; m->gw = m->W / cfg->patch;
   m->HW = m->gh * m->gw; m->T = m->HW + 1; m->C = cfg->embed_dim; m->K = cfg->num_kpts; m->d = cfg->d_model;
   m->L = m->HW + m->K; m->E = 2 * m->d;
-  EC_REQUIRE(cfg->backbone_precision >= EC_F32 && cfg->backbone_precision <= EC_F16, EC_ERR_ARG,
-             "backbone_precision: EC_F32 (exact), EC_BF16X3 (split bf16, fp32-class), EC_BF16 or EC_F16 (16-bit MFMA operands)");
-  m->bb_split = cfg->backbone_precision == EC_BF16X3;
-  m->bb_x3 = m->bb_split && cfg->embed_dim % 128 == 0 && !(getenv("EC_BB_X3") && atoi(getenv("EC_BB_X3")) == 0);
+  EC_REQUIRE((cfg->backbone_precision >= EC_F32 && cfg->backbone_precision <= EC_F16) || cfg->backbone_precision == EC_F16X2, EC_ERR_ARG,
+             "backbone_precision: EC_F32 (exact), EC_BF16X3 (split bf16, fp32-class), EC_F16X2 (fp16 + FP8 corrections), EC_BF16 or EC_F16 (16-bit MFMA operands)");
+  m->bb_x2 = cfg->backbone_precision == EC_F16X2;
+  EC_REQUIRE(!m->bb_x2 || cfg->embed_dim % 128 == 0, EC_ERR_ARG, "backbone_precision EC_F16X2 needs embed_dim % 128 == 0");
+  m->bb_split = cfg->backbone_precision == EC_BF16X3 || m->bb_x2;
+  m->bb_x3 = m->bb_split && cfg->embed_dim % 128 == 0 && (m->bb_x2 || !(getenv("EC_BB_X3") && atoi(getenv("EC_BB_X3")) == 0));
+  // fp16 planes for the bf16x3 mode itself (three fp16 MFMAs per product) were measured at scale in round 6 and NOT adopted
+  // (profiles/r06_conformance_fp16planes_*.json: 0 / 0 / 2 / 1 argmax flips on cfg1 / 2 / 4 / 5 against 0 / 1 / 1 / 1 with bf16 planes, -2.4 %
+  // pairs/s); the plane format lives on as the fp16x2 mode's patch embedding (EC_X3_F16=1: the bf16x3 mode on fp16 planes, for A/B)
+  m->bb_x3_f16 = m->bb_x3 && (m->bb_x2 || (getenv("EC_X3_F16") && atoi(getenv("EC_X3_F16")) != 0));
   m->bb16 = cfg->backbone_precision == EC_BF16 || cfg->backbone_precision == EC_F16;
   m->bbf16 = cfg->backbone_precision == EC_F16;
   m->head_split = cfg->head_precision == EC_BF16X3 || cfg->head_precision == EC_MIXED;
@@ -2446,6 +2541,45 @@ int ec_op_linear_h16(const float* A, const float* W, const float* bias, const fl
   for (int i = 0; i < repeats && !rc; ++i) rc = gemm_nt(p, st);   // back to back: every launch overwrites C with the same values
   (void)hipStreamSynchronize(st);
   (void)hipFree(a16); (void)hipFree(w16);
+  return rc;
+}
+
+int ec_op_linear_x2(const float* A, const float* W, const float* bias, const float* gamma, float* C, void* planes, int M, int N, int K, int act,
+                    int repeats, void* stream, float* ms) {
+  EC_REQUIRE(A && W && bias && repeats >= 1 && M > 0 && N > 0 && K > 0, EC_ERR_ARG, "ec_op_linear_x2: bad argument");
+  EC_REQUIRE((act == ACT_GELU) == (planes != nullptr) && (act == ACT_NONE || act == ACT_GELU) && (planes || C) && !(gamma && planes), EC_ERR_ARG,
+             "ec_op_linear_x2: act 0 -> fp32 C (gamma: C = (A W^T + b) * gamma + C in place), act 2 -> fp16x2 planes");
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<float> wh((size_t)N * K);
+  EC_HIP(hipStreamSynchronize(st));
+  EC_HIP(hipMemcpy(wh.data(), W, wh.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<uint8_t> wp;
+  int sa = 0;
+  RUN(pack_x2_weights(wh.data(), N, K, wp, &sa));
+  void *a2 = nullptr, *w2 = nullptr;
+  EC_HIP(hipMalloc(&a2, (size_t)M * 4 * K));
+  EC_HIP(hipMalloc(&w2, wp.size()));
+  EC_HIP(hipMemcpy(w2, wp.data(), wp.size(), hipMemcpyHostToDevice));
+  int rc = pack_x2(A, K, a2, 2l * K, M, K, st);
+  GemmP p;
+  p.A = a2; p.lda = 2l * K; p.B = w2; p.ldb = 2l * K; p.ab_bf16 = 1; p.h_f16 = 1; p.x2 = K / 64; p.x2_sa = sa;
+  p.M = M; p.N = N; p.K = 2 * K; p.bias = bias; p.act = act;
+  if (planes) { p.C = planes; p.ldc = 2l * N; p.c_x2 = 1; p.tag = 3; }
+  else { p.C = C; p.ldc = N; p.gamma = gamma; if (gamma) { p.resid = C; p.ldr = N; p.tag = 4; } else p.tag = 1; }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ms) { EC_HIP(hipEventCreate(&e0)); EC_HIP(hipEventCreate(&e1)); EC_HIP(hipEventRecord(e0, st)); }
+  for (int i = 0; i < repeats && !rc; ++i) rc = gemm_nt(p, st);
+  if (ms && !rc) {
+    EC_HIP(hipEventRecord(e1, st));
+    EC_HIP(hipEventSynchronize(e1));
+    float t = 0.f;
+    EC_HIP(hipEventElapsedTime(&t, e0, e1));
+    *ms = t / (float)repeats;
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(a2); (void)hipFree(w2);
   return rc;
 }
 

@@ -10,7 +10,7 @@ namespace ec {
 // Optional second output y2 (fp32) = y + table[row % period2] (encoder: `src + pos` of the NEXT layer).
 struct LnP {
   const float* x = nullptr; long ldx = 0;
-  void* y = nullptr; long ldy = 0; int y_bf16 = 0;   // output format: 0 fp32, 1 bf16, 2 IEEE fp16, 3 bf16 split [hi | lo] (planes cols apart)
+  void* y = nullptr; long ldy = 0; int y_bf16 = 0;   // output format: 0 fp32, 1 bf16, 2 IEEE fp16, 3 bf16 split [hi | lo] (planes cols apart), 5 fp16 split, 6 fp16x2 row
   const float* w = nullptr; const float* b = nullptr;
   int rows = 0, cols = 0; float eps = 1e-5f;
   int drop_period = 0;
@@ -45,6 +45,9 @@ struct XferP {
 };
 int rows_xfer(XferP p, const int* idx_host, int n_rows, bool idx_is_dst, hipStream_t st);
 int f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t st, int f16 = 0);   // f16: IEEE fp16 instead of bf16
+// x [rows, cols] fp32 (row stride ldx) -> fp16x2 rows [cols x fp16 | cols x e5m2 lo8 | cols x e5m2 hi8] (ec_common.h split4_x2), row stride
+// ldy16 16-bit units (>= 2 cols); cols % 4 == 0.  The op-level test entry of the fp16x2 GEMM packs its A operand with it.
+int pack_x2(const float* x, long ldx, void* y, long ldy16, int rows, int cols, hipStream_t st);
 // src [B][L][E] fp32 -> dst [B][E][Lp] bf16 (columns >= L zeroed); test helper for the bf16 attention kernel
 int transpose_pad_bf16(const float* src, bf16_t* dst, int B, int L, int E, int Lp, hipStream_t st);
 int im2col14(const float* img, void* patches, int out_bf16, int n_img, int H, int W, int gh, int gw, int Kp, hipStream_t st);

@@ -13,6 +13,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // OUT: 0 = fp32 output, 1 = bf16, 2 = IEEE fp16 (the fused branch inputs `add` / `add2` are in the same 16-bit format),
 //      3 = bf16 split [hi | lo] in two planes `cols` elements apart (ldy >= 2 cols): the A operand of a K-concatenated bf16x3 GEMM
+//      5 = the same in IEEE fp16 planes; 6 = the fp16x2 row [fp16 | e5m2 lo8 | e5m2 hi8] (ldy >= 2 cols 16-bit units; split4_x2)
 template <int OUT, bool ADD, bool ADD_F16 = (OUT == 2)>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnP p) {
   constexpr bool OUT_BF16 = OUT != 0;
@@ -71,10 +72,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnP p) {
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * w[e] + b[e];
-      if constexpr (OUT == 3) {
+      if constexpr (OUT == 6) {   // fp16x2 row [fp16 | e5m2 lo8 | e5m2 hi8] (ec_common.h split4_x2): the A operand of an fp16x2 GEMM
+        char* y = (char*)p.y + orow * p.ldy * 2;
+        u32x2_t hi;
+        unsigned lo8, hi8;
+        split4_x2(o, hi, lo8, hi8);
+        *(u32x2_t*)(y + c * 2) = hi;
+        *(unsigned*)(y + 2 * p.cols + c) = lo8;
+        *(unsigned*)(y + 3 * p.cols + c) = hi8;
+      } else if constexpr (OUT == 3 || OUT == 5) {
         bf16_t* y = (bf16_t*)p.y + orow * p.ldy + c;
         u32x2_t hi, lo;
-        split4_bf16(o, hi, lo);
+        split4_h<OUT == 5>(o, hi, lo);
         *(u32x2_t*)y = hi;
         *(u32x2_t*)(y + p.cols) = lo;
       } else if (OUT_BF16) {
@@ -134,6 +143,19 @@ __global__ void mean_over_kernel(float* dst, const float* src, long stride, int 
   dst[i] = s / (float)n;
 }
 
+__global__ void pack_x2_kernel(const float* x, long ldx, char* y, long ldy16, int rows, int cols4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * cols4) return;
+  const int r = i / cols4, c = (i % cols4) * 4, cols = cols4 * 4;
+  u32x2_t hi;
+  unsigned lo8, hi8;
+  split4_x2(*(const f32x4*)(x + (long)r * ldx + c), hi, lo8, hi8);
+  char* row = y + (long)r * ldy16 * 2;
+  *(u32x2_t*)(row + c * 2) = hi;
+  *(unsigned*)(row + 2 * cols + c) = lo8;
+  *(unsigned*)(row + 3 * cols + c) = hi8;
+}
+
 template <bool F16>
 __global__ void f32_to_bf16_kernel(const float* src, bf16_t* dst, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -179,11 +201,11 @@ __global__ __launch_bounds__(256) void im2col14_kernel(const float* img, void* o
   __syncthreads();
   if constexpr (OUT == 0) {
     for (int i = threadIdx.x; i < Kp / 4; i += blockDim.x) *(f32x4*)((float*)out + orow * Kp + i * 4) = *(const f32x4*)(px + i * 4);
-  } else if constexpr (OUT == 4) {
+  } else if constexpr (OUT == 4 || OUT == 5) {
     const int c4n = Kp / 4;
     for (int i = threadIdx.x; i < c4n; i += blockDim.x) {
       u32x2_t h, l;
-      split4_bf16(*(const f32x4*)(px + i * 4), h, l);
+      split4_h<OUT == 5>(*(const f32x4*)(px + i * 4), h, l);
       bf16_t* o = (bf16_t*)out + orow * 2 * Kp + i * 4;
       *(u32x2_t*)o = h; *(u32x2_t*)(o + Kp) = l;
     }
@@ -793,9 +815,11 @@ int layernorm(const LnP& p, hipStream_t st) {
   // y_bf16: 0 fp32, 1 bf16, 2 fp16 output; a fused branch add is 16-bit in add_fmt's format (defaults to the output's, bf16 if fp32)
   const int afmt = p.add_fmt ? p.add_fmt : (p.y_bf16 ? p.y_bf16 : 1);
   EC_REQUIRE(!p.add || p.y_bf16 == 0 || afmt == p.y_bf16, -1, "layernorm: fused add and output must share the 16-bit format");
-  if (p.y_bf16 == 3) {
+  if (p.y_bf16 == 3 || p.y_bf16 == 5 || p.y_bf16 == 6) {
     EC_REQUIRE(!p.add && p.ldy >= 2 * (long)p.cols, -1, "layernorm: split output takes no fused add and needs ldy >= 2 cols");
-    hipLaunchKernelGGL((layernorm_kernel<3, false>), grid, dim3(256), 0, st, p);
+    if (p.y_bf16 == 6) hipLaunchKernelGGL((layernorm_kernel<6, false, false>), grid, dim3(256), 0, st, p);
+    else if (p.y_bf16 == 5) hipLaunchKernelGGL((layernorm_kernel<5, false, false>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((layernorm_kernel<3, false>), grid, dim3(256), 0, st, p);
   } else if (p.add) {
     if (p.y_bf16 == 2) hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, dim3(256), 0, st, p);
     else if (p.y_bf16 == 1) hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, dim3(256), 0, st, p);
@@ -987,6 +1011,13 @@ int mean_over(float* dst, const float* src, long stride, int n, long count, hipS
   return 0;
 }
 
+int pack_x2(const float* x, long ldx, void* y, long ldy16, int rows, int cols, hipStream_t st) {
+  EC_REQUIRE(cols % 4 == 0 && ldx % 4 == 0 && ldy16 >= 2l * cols && ldy16 % 2 == 0, -1, "pack_x2: cols % 4 == 0, ldy >= 2 cols");
+  hipLaunchKernelGGL(pack_x2_kernel, dim3(cdiv((long)rows * (cols / 4), 256)), dim3(256), 0, st, x, ldx, (char*)y, ldy16, rows, cols / 4);
+  EC_LAUNCH_CHECK();
+  return 0;
+}
+
 int f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t st, int f16) {
   if (n % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0) {
     if (f16) hipLaunchKernelGGL(f32_to_bf16_x4_kernel<true>, dim3(cdiv(n / 4, 256)), dim3(256), 0, st, src, dst, n / 4);
@@ -1009,7 +1040,8 @@ int transpose_pad_bf16(const float* src, bf16_t* dst, int B, int L, int E, int L
 int im2col14(const float* img, void* patches, int out_bf16, int n_img, int H, int W, int gh, int gw, int Kp, hipStream_t st) {
   EC_REQUIRE(Kp % 8 == 0 && Kp <= 1024, -1, "im2col14: padded row length must be a multiple of 8, at most 1024");
   const dim3 grid(n_img * (gh * gw + 1));
-  if (out_bf16 == 4) hipLaunchKernelGGL(im2col14_kernel<4>, grid, dim3(256), 0, st, img, patches, H, W, gh, gw, Kp);
+  if (out_bf16 == 5) hipLaunchKernelGGL(im2col14_kernel<5>, grid, dim3(256), 0, st, img, patches, H, W, gh, gw, Kp);
+  else if (out_bf16 == 4) hipLaunchKernelGGL(im2col14_kernel<4>, grid, dim3(256), 0, st, img, patches, H, W, gh, gw, Kp);
   else if (out_bf16 == 3) hipLaunchKernelGGL(im2col14_kernel<3>, grid, dim3(256), 0, st, img, patches, H, W, gh, gw, Kp);
   else if (out_bf16 == 2) hipLaunchKernelGGL(im2col14_kernel<2>, grid, dim3(256), 0, st, img, patches, H, W, gh, gw, Kp);
   else if (out_bf16) hipLaunchKernelGGL(im2col14_kernel<1>, grid, dim3(256), 0, st, img, patches, H, W, gh, gw, Kp);

@@ -90,22 +90,33 @@ class EdgeCape:
 
     @staticmethod
     def _support_key(meta):
-        """Identity of a pair's support set: per shot the annotation's image file, crop box and keypoints (whatever of them img_metas has)."""
-        parts = []
+        """Identity of a pair's support set: per shot the annotation's image file plus every annotation field img_metas carries - crop box
+        (centre, scale, rotation), keypoints and their visibility (which determine target_s / mask_s), bbox id.  None when the metas hold
+        NOTHING beyond the file names (a custom Collect, demo.py's `sample_image_file=['']`): two different annotations of one image
+        would then share a key and the second would silently get the first one's cached tokens - such a batch takes the plain path."""
+        def raw(v):
+            if isinstance(v, torch.Tensor):                        # (demo.py hands sample_joints_3d over as a CUDA tensor)
+                v = v.detach().cpu().numpy()
+            return np.ascontiguousarray(np.asarray(v)).tobytes()
+        parts, discriminating = [], False
         for s, f in enumerate(meta["sample_image_file"]):
             p = [str(f)]
-            for k in ("sample_center", "sample_scale", "sample_joints_3d", "sample_bbox_id"):
+            for k in ("sample_center", "sample_scale", "sample_rotation", "sample_joints_3d", "sample_joints_3d_visible", "sample_bbox_id"):
                 if k in meta:
-                    p.append(np.asarray(meta[k][s]).tobytes())
+                    p.append(k)
+                    p.append(raw(meta[k][s]))
+                    discriminating = discriminating or k in ("sample_center", "sample_scale", "sample_joints_3d", "sample_bbox_id")
             parts.append(tuple(p))
-        return (tuple(parts), np.asarray(meta["sample_skeleton"][0], np.int64).tobytes())
+        if not discriminating:
+            return None
+        return (tuple(parts), raw(np.asarray(meta["sample_skeleton"][0], np.int64)))
 
     def _device_forward(self, eng, img_q, img_s, target_s, mask_s, img_metas, pipelined=False):
         """Device part of one batch: plain (ec_forward / ec_forward_pipelined), or through the episode cache."""
         bs, K = img_q.shape[0], target_s[0].shape[1]
         skeletons = [m["sample_skeleton"][0] for m in img_metas]   # EdgeCape.py:179
         keys = [self._support_key(m) for m in img_metas] if self._episode_slots > 0 else None
-        if keys is None or len(set(keys)) > self._episode_slots:
+        if keys is None or any(k is None for k in keys) or len(set(keys)) > self._episode_slots:
             if not pipelined:
                 return eng.forward(img_q, img_s, target_s, mask_s, skeletons)
             iq, is_, ts = eng._dev(img_q), [eng._dev(x) for x in img_s], [eng._dev(t) for t in target_s]

@@ -93,9 +93,9 @@ class HipEngine:
         self.HW = self.gh * self.gw
         self.K, self.max_batch, self.max_shots = num_kpts, max_batch, max_shots
         self.dec_layers, self.max_hops = dec_layers, max_hops
-        prec = {"fp32": _lib.EC_F32, "bf16": _lib.EC_BF16, "bf16x3": _lib.EC_BF16X3, "fp16": _lib.EC_F16, "mixed": _lib.EC_MIXED}
-        if backbone_precision not in ("fp32", "bf16x3", "bf16", "fp16") or head_precision not in ("fp32", "bf16x3", "mixed"):
-            raise ValueError("backbone_precision must be fp32 / bf16x3 / bf16 / fp16 and head_precision fp32 / bf16x3 / mixed")
+        prec = {"fp32": _lib.EC_F32, "bf16": _lib.EC_BF16, "bf16x3": _lib.EC_BF16X3, "fp16": _lib.EC_F16, "mixed": _lib.EC_MIXED, "fp16x2": _lib.EC_F16X2}
+        if backbone_precision not in ("fp32", "bf16x3", "fp16x2", "bf16", "fp16") or head_precision not in ("fp32", "bf16x3", "mixed"):
+            raise ValueError("backbone_precision must be fp32 / bf16x3 / fp16x2 / bf16 / fp16 and head_precision fp32 / bf16x3 / mixed")
         cfg = _lib.EcConfig(embed_dim=a["C"], depth=a["depth"], num_heads=a["heads"], image_size=H, image_width=(0 if H == Wd else Wd), patch=PATCH,
                             num_kpts=num_kpts, d_model=d_model, nhead=nhead, enc_layers=enc_layers, dec_layers=dec_layers,
                             skel_layers=skel_layers, ffn_dim=ffn_dim, skel_ffn_dim=skel_ffn_dim or a["C"], max_hops=max_hops,

@@ -293,9 +293,11 @@ def make_pairs(bs, shots=1, image_size=224, seed=0, n_kp=17, K=100, fixed_n_kp=T
         vis[:nk] = 1
         img_q[i] = _smooth_image(rng, H, Wd)
         base = rng.uniform(8, hi - 8, size=(K, 2)).astype(np.float32)
+        kps = []
         for s in range(shots):
             img_s[s][i] = _smooth_image(rng, H, Wd)
             kp = np.clip(base + rng.normal(0, 2.0, base.shape), 0, hi - 1).astype(np.float32)
+            kps.append(kp)
             t, tw = msra_target(kp, vis, size)
             target_s[s][i], tw_s[s][i] = t, tw
         gq = np.clip(base + rng.normal(0, 4.0, base.shape), 0, hi - 1).astype(np.float32)
@@ -314,6 +316,14 @@ def make_pairs(bs, shots=1, image_size=224, seed=0, n_kp=17, K=100, fixed_n_kp=T
             "query_scale": np.array([Wd / 200 * 1.25, H / 200 * 1.25], np.float32),
             "query_image_file": f"synthetic/q{seed + first_index + i}.png",
             "sample_image_file": [f"synthetic/s{seed + first_index + i}_{s}.png" for s in range(shots)],
+            # the support annotations as the reference's Collect hands them over (test_base_dataset.py:171-184): what the detector's
+            # episode cache recognises a support set by (nothing above is derived from these: no random number is drawn for them)
+            "sample_center": [np.array([Wd / 2, H / 2], np.float32) for _ in range(shots)],
+            "sample_scale": [np.array([Wd / 200 * 1.25, H / 200 * 1.25], np.float32) for _ in range(shots)],
+            "sample_rotation": [0 for _ in range(shots)],
+            "sample_joints_3d": [np.concatenate([kp, np.zeros((K, 1), np.float32)], 1) for kp in kps],
+            "sample_joints_3d_visible": [np.repeat(vis[:, None], 3, 1) for _ in range(shots)],
+            "sample_bbox_id": [first_index + i for _ in range(shots)],
             "query_bbox_score": 1.0,
             "bbox_id": first_index + i,
             "query_bbox": np.array([0, 0, Wd, H], np.float32),

@@ -59,13 +59,19 @@ enum ec_precision {
                      producers, weights [W_hi | W_lo], one GEMM of depth 3 K per Linear */
   EC_F16 = 3,     /* IEEE fp16 operands (11 significand bits, same MFMA rate as bf16), fp32 accumulate: the backbone mode that
                      keeps output_kpts inside the 1e-3 tolerance at bf16 speed (backbone only) */
-  EC_MIXED = 4    /* head only: EC_BF16X3 everywhere the proposal generator's argmax depends on (input projections, support pooling,
+  EC_MIXED = 4,   /* head only: EC_BF16X3 everywhere the proposal generator's argmax depends on (input projections, support pooling,
                      encoder, proposal generator - encoder_decoder.py:91-110 is the path's one discontinuity) and in the small MLPs;
                      single-pass fp16 MFMAs (fp32 data rounded to fp16 operands, fp32 accumulate) in the Linear layers AND the
                      attentions of the skeleton head (skeleton.py:58-161) and of the decoder layers (encoder_decoder.py:584-651),
                      whose image K|V are also stored as fp16 - all of which only move the output continuously: with the fp16 backbone,
                      max |d kpt| on flip-free samples 2.0e-4 (cfg2) / 2.4e-4 (ViT-S/14 @ 224) over 512 disjoint pairs each, 12 / 11 argmax
                      flips of ~20 000 valid keypoints (profiles/r04_conformance_*.json) */
+  EC_F16X2 = 5    /* backbone only (round 6): fp32 data, TWO MFMA units per product instead of the three of EC_BF16X3 -
+                     a W ~ a_hi W_hi in fp16 MFMAs plus BOTH correction terms a_lo W_hi + a_hi W_lo in ONE block-scaled FP8 pass
+                     (v_mfma_scale_f32_16x16x128_f8f6f4: activations e5m2 with fixed power-of-two scales, weights e4m3 with one static
+                     scale per tensor and plane), ~2^-14 relative.  Rows of K values travel as [K x fp16 | K x e5m2 | K x e5m2] (4 K
+                     bytes), written by their producers (LayerNorm, attention, the fc1 epilogue).  Needs embed_dim % 128 == 0.  Its GEMMs
+                     run on ONE kernel whatever the batch, so an image's features do not depend on the batch it rides in */
 };
 enum ec_dtype { EC_DT_F32 = 0, EC_DT_F16 = 1, EC_DT_BF16 = 2, EC_DT_F64 = 3 };
 enum ec_layout { EC_LAYOUT_TOKENS = 0, EC_LAYOUT_NCHW = 1 };
@@ -254,6 +260,15 @@ int ec_op_linear(const float* A_dev, const float* W_dev, const float* bias_dev, 
  * act 0 or 2 (not both gamma and act).  The launch is repeated `repeats` times back to back (race screens). */
 int ec_op_linear_h16(const float* A_dev, const float* W_dev, const float* bias_dev, const float* gamma_dev, uint16_t* C_dev, int M, int N,
                      int K, int act, int precision, int repeats, void* stream);
+/* The block GEMMs of the EC_F16X2 backbone as the model runs them (ec_gemm8.hip, X2 instantiations): A [M,K] and W [N,K] fp32 on device
+ * are packed into fp16x2 rows ([K x fp16 | K x FP8 | K x FP8]: activations e5m2 with fixed scales, weights e4m3 with one static
+ * power-of-two scale per plane) and multiplied as a_hi W_hi (fp16 MFMAs) + a_lo8 W_hi8 + a_hi8 W_lo8 (block-scaled FP8 MFMAs).
+ *   act = 0, gamma NULL: C_dev [M,N] fp32 = A W^T + bias                                   (QKV)
+ *   act = 0, gamma:      C_dev = (A W^T + bias) * gamma + C_dev, in place                  (proj / fc2: LayerScale + residual)
+ *   act = 2:             planes_dev [M, 4 N] bytes = fp16x2 rows of gelu(A W^T + bias)     (fc1); C_dev unused
+ * K % 128 == 0, N % 16 == 0, N >= 256, any M.  Repeated `repeats` times back to back; *ms (may be NULL) = mean launch time. */
+int ec_op_linear_x2(const float* A_dev, const float* W_dev, const float* bias_dev, const float* gamma_dev, float* C_dev, void* planes_dev,
+                    int M, int N, int K, int act, int repeats, void* stream, float* ms);
 /* Same GEMM on operands already in the precision's storage type (bf16 as uint16_t bit patterns), repeated
  * `iters` times; returns mean kernel time in ms via *ms (HIP events on `stream`).  Used by bench.py roofline. */
 int ec_op_gemm_bench(const void* A_dev, const void* W_dev, const float* bias_dev, void* C_dev, int M, int N, int K,

@@ -527,14 +527,16 @@ def test_detector_episode_cache_is_a_drop_in(shots):
     order[-1] = 0                                      # the last pair returns to support set 0, long after it left a 2-slot cache
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x))
 
-    def loader():
+    def loader(files_only=False):
         for b0 in range(0, len(order), bs):
             e = np.array(order[b0:b0 + bs])
             q = np.arange(b0, b0 + len(e))
             metas = []
             for qi, ei in zip(q, e):
                 m = dict(qry["img_metas"][qi])
-                for k in ("sample_skeleton", "sample_image_file"):
+                for k in [k for k in m if k.startswith("sample_")]:
+                    del m[k]
+                for k in (("sample_skeleton", "sample_image_file") if files_only else [k for k in sup["img_metas"][ei] if k.startswith("sample_")]):
                     m[k] = sup["img_metas"][ei][k]
                 m["bbox_id"] = int(qi)
                 metas.append(m)
@@ -542,12 +544,12 @@ def test_detector_episode_cache_is_a_drop_in(shots):
                        target_weight_s=[t(x[e]) for x in sup["target_weight_s"]], target_q=t(qry["target_q"][q]),
                        target_weight_q=t(qry["target_weight_q"][q]), img_metas=metas)
 
-    def run(cache_slots, pipelined):
+    def run(cache_slots, pipelined, files_only=False):
         model = EdgeCape(keypoint_head=head_cfg, encoder_config=dict(), train_cfg=dict(), test_cfg=dict(flip_test=False), pretrained=arch)
         model.load_state_dict(sd)
         if cache_slots:
             model.enable_episode_cache(cache_slots)
-        return apis.single_gpu_test(model, loader(), pipelined=pipelined), model
+        return apis.single_gpu_test(model, loader(files_only), pipelined=pipelined), model
 
     ref, _ = run(0, False)
     for slots, pipelined in ((2, False), (8, False), (2, True)):
@@ -558,6 +560,12 @@ def test_detector_episode_cache_is_a_drop_in(shots):
             assert np.abs(a["preds"] - b["preds"]).max() < 1e-3, (slots, pipelined, float(np.abs(a["preds"] - b["preds"]).max()))   # pixels of a 224 px box
         st = next(iter(model._episodes.values()))
         assert len(st["slot_of"]) == min(slots, n_ep)   # three support sets seen, at most `slots` kept
+    # metas that carry nothing but the file names cannot tell two annotations of one image apart - such batches take the
+    # plain path (no cache state is built) and return the plain path's records
+    got, model = run(8, False, files_only=True)
+    assert not model._episodes
+    for a, b in zip(got, ref):
+        assert np.array_equal(a["preds"], b["preds"]) and a["bbox_ids"] == b["bbox_ids"]
 
 
 def test_forward_episodes_stress_ragged_stream():

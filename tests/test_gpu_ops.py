@@ -568,3 +568,89 @@ def test_row_chain(lib, rows, K1, Kcat, N2, act2, period, third, alias, h1):
     if third:
         e3 = (x3d.cpu().double() - x3).abs().max().item()
         assert e3 < tol, e3
+
+
+# ---- fp16x2 operands (EC_F16X2 backbone, round 6): a_hi W_hi in fp16 MFMAs + both correction terms in ONE block-scaled FP8 pass --------
+def _x2_emulate(A, W):
+    """The fp16x2 product as ec_common.h split4_x2 / ec_model.hip pack_x2_weights define it, in fp64 on the rounded operands:
+    activations fp16 + e5m2((a - hi) * 2^11) + e5m2(a) with fixed scales, weights fp16 + e4m3 planes with one power-of-two scale each."""
+    q5 = lambda t: t.clamp(-57344.0, 57344.0).to(torch.float8_e5m2).double()
+    q4 = lambda t: t.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).double()
+    sat = lambda t: t.clamp(-65504.0, 65504.0)
+    ah = sat(A).half().float()
+    al8 = q5((A - ah) * 2048.0) / 2048.0
+    ah8 = q5(A)
+    wh = W.half().float()
+    wl = W - wh
+    planes = []
+    for t in (W, wl):
+        amax = float(t.abs().max())
+        s = int(np.floor(np.log2(448.0 / amax))) if amax > 0 else 0
+        planes.append(q4(t * 2.0 ** s) * 2.0 ** -s)
+    return ah.double() @ wh.double().T + al8 @ planes[0].T + ah8 @ planes[1].T
+
+
+@pytest.mark.parametrize("M,N,K,kind", [(20800, 2304, 768, "bias"), (20800, 768, 768, "res"), (4099, 3072, 768, "gelu"), (4099, 768, 3072, "res"),
+                                        (2600, 1152, 384, "bias"), (2600, 384, 1536, "res"), (1300, 1536, 384, "gelu"), (5840, 1024, 1024, "bias"),
+                                        (325, 1152, 384, "bias"), (77, 1536, 384, "gelu"), (1, 384, 1536, "res")])
+def test_linear_x2_output_kinds(lib, M, N, K, kind):
+    """The block GEMMs of the EC_F16X2 backbone on the 8-phase kernel (ec_gemm8.hip, X2 instantiations) at ViT-S / -B / -L shapes with
+    ragged and tiny M (this mode has no other GEMM: one image = 325 rows, one row): (a) against the fp64 emulation of the SCHEME on
+    the rounded operands - only fp32 accumulation noise is allowed, so a wrong K mapping of the FP8 fragments, a wrong scale byte or a
+    wrong plane order fails by orders of magnitude; (b) the scheme itself against the exact product: ~2^-14 relative to the row's
+    |a| . |w| (two MFMA units per product; bf16x3 spends three for ~2^-17); nothing stored past M rows; repeated launches bit-identical."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))      # rows of different magnitude
+    A[:, 3] *= 60.0                                                                      # an outlier channel
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    gam = (torch.rand(N, generator=g) + 0.5) if kind == "res" else None
+    R = torch.randn(M, N, generator=g) if kind == "res" else None
+    emu = _x2_emulate(A, W) + b.double()
+    exact = A.double() @ W.double().T + b.double()
+    scale = (A.double().abs() @ W.double().abs().T)                                      # |a| . |w| per output: what the rounding errors scale with
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
+    guard = 40
+    outs = []
+    for it in range(3):
+        if kind == "gelu":
+            buf = torch.full(((M + guard) * 4 * N,), 0x55, device="cuda", dtype=torch.uint8)
+            _chk(lib, lib.ec_op_linear_x2(_p(Ad), _p(Wd), _p(bd), None, None, _p(buf), M, N, K, 2, 1 if it == 0 else 4, None, None))
+        else:
+            buf = torch.full(((M + guard) * N,), 7.0, device="cuda")
+            if kind == "res":
+                buf[:M * N] = R.cuda().flatten()
+                reps = 1                                                                  # (in place: every launch adds again)
+            else:
+                reps = 1 if it == 0 else 4
+            _chk(lib, lib.ec_op_linear_x2(_p(Ad), _p(Wd), _p(bd), _p(gam.cuda()) if gam is not None else None, _p(buf), None, M, N, K, 0, reps, None, None))
+        torch.cuda.synchronize()
+        if kind == "gelu":
+            assert torch.all(buf[M * 4 * N:] == 0x55), "stored past the last row"
+            outs.append(buf[:M * 4 * N].view(M, 4 * N).cpu())
+        else:
+            assert torch.all(buf[M * N:] == 7.0), "stored past the last row"
+            outs.append(buf[:M * N].view(M, N).cpu())
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    if kind == "gelu":
+        rows = outs[0]
+        hi = rows[:, :2 * N].contiguous().view(torch.float16).double()
+        lo8 = rows[:, 2 * N:3 * N].contiguous().view(torch.float8_e5m2).double() / 2048.0
+        hi8 = rows[:, 3 * N:].contiguous().view(torch.float8_e5m2).double()
+        ref = torch.nn.functional.gelu(emu)
+        tol = scale * 3e-6 + 2e-6 + ref.abs() * 2.0 ** -13                                # accumulation + GELU form (6.4e-7) + the e5m2 rounding of lo (2^-11 * 2^-3)
+        bad = (hi + lo8 - ref).abs() > tol
+        assert not bad.any(), (int(bad.sum()), float((hi + lo8 - ref).abs().max()))
+        assert ((hi - ref).abs() <= ref.abs() * 2.0 ** -11 + tol).all()                   # the fp16 plane alone: half an ulp
+        assert ((hi8 - ref).abs() <= ref.abs() * 2.0 ** -3 + tol + 2.0 ** -17).all()      # the e5m2 plane: half an ulp of 2 mantissa bits
+        return
+    got = outs[0].double()
+    if kind == "res":
+        emu, exact = emu * gam.double() + R.double(), exact * gam.double() + R.double()
+        scale = scale * gam.double()
+    err_emu = (got - emu).abs()
+    assert (err_emu <= scale * 3e-6 + 2e-6).all(), float((err_emu / (scale * 3e-6 + 2e-6)).max())
+    rel = ((got - exact).abs() / scale)
+    print(f"fp16x2 {M}x{N}x{K} {kind}: |got - exact| / (|a|.|w|) max {float(rel.max()):.2e} rms {float((rel ** 2).mean().sqrt()):.2e}; vs emulation max {float((err_emu / scale).max()):.2e}")
+    assert float(rel.max()) < 2.0 ** -13 and float((rel ** 2).mean().sqrt()) < 2.0 ** -16

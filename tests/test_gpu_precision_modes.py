@@ -217,6 +217,19 @@ def test_parity_mode_bf16x3(name):
     assert s["pck_vs_oracle"] == 1.0
 
 
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg4", "cfg5"])
+def test_parity_mode_fp16x2(name):
+    """fp16x2 backbone (fp16 MFMAs + both correction terms in one block-scaled FP8 pass: two MFMA units per product) + bf16x3 head: the
+    tolerance-conforming mode at two thirds of the bf16x3 backbone's matrix work.  Full batch of the BASELINE config vs the oracle,
+    the same gates as the bf16x3 parity mode."""
+    s = _run(name, "fp16x2", "bf16x3")
+    print(name, "fp16x2/bf16x3", s)
+    assert s["flips"] == 0
+    assert s["max_all"] < 1e-3, s
+    assert s["p99"] < 1e-4 and s["adj_err"] < 1e-4
+    assert s["pck_vs_oracle"] == 1.0
+
+
 def _headline_gates(s, name):
     """One full batch of a configuration in the bench's default backbone precision.  Observed on every configuration (rounds 2-4):
     0 flips on these batches, max |d| 1.4-1.9e-4, p99 <= 8e-5, median <= 6e-6; gates = that + <= 50 %.  A near-tie may flip on another

@@ -105,4 +105,12 @@ def test_detector_support_key_tells_support_sets_apart():
     assert k(base) != k(dict(base, sample_center=[np.array([11., 20.]), np.array([5., 5.])]))
     assert k(base) != k(dict(base, sample_skeleton=[[[0, 1]]] * 2))
     assert k(base) != k(dict(base, sample_image_file=["b.jpg", "a.jpg"]))
-    assert k(dict(sample_image_file=["a.jpg"], sample_skeleton=[[]])) == k(dict(sample_image_file=["a.jpg"], sample_skeleton=[[]]))
+    # visibility and rotation are part of the identity (they determine mask_s / target_s); tensors are accepted (demo.py hands
+    # CUDA tensors over; here a CPU tensor); metas with nothing but file names give NO key - the detector then takes the plain path
+    import torch
+    vis = [np.ones((3, 3), np.float32), np.ones((3, 3), np.float32)]
+    assert k(dict(base, sample_joints_3d_visible=vis)) != k(dict(base, sample_joints_3d_visible=[vis[0], vis[1] * 0]))
+    assert k(dict(base, sample_rotation=[0, 0])) != k(dict(base, sample_rotation=[0, 30]))
+    assert k(dict(base, sample_joints_3d=[torch.ones(3, 3), torch.zeros(3, 3)])) == k(dict(base, sample_joints_3d=[np.ones((3, 3), np.float32), np.zeros((3, 3), np.float32)]))
+    assert k(dict(sample_image_file=["a.jpg"], sample_skeleton=[[]])) is None
+    assert k(dict(sample_image_file=[""], sample_skeleton=[[]], sample_rotation=[0])) is None
