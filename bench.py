@@ -175,7 +175,7 @@ def main():
                      "note": "the same pipelined steps for >= %.0f s in the same process, same engine, right after the K timed steps of `value`" % args.sustained_seconds}
     episode = None
     if not args.no_episode:
-        episode = episode_mode(args, sd, synth, bs, S, H, arch, apis, rank, world)
+        episode = episode_mode(args, sd, synth, bs, S, H, arch, apis, rank, world, parity_episodes=0 if args.no_cpu_baseline else 2)
         if not args.episode_images and torch.cuda.is_available():
             # the same protocol in calls of twice the size (288 GB of HBM: the call size is free; the head's ~190 launches per call
             # are then shared by twice the queries)
@@ -338,7 +338,8 @@ def pmc_traffic(args, bs, S, H, arch, source_hash):
             "mfma_util_pmc": d.get("mfma_util"), "traffic_source": os.path.relpath(path, ROOT)}
 
 
-def episode_mode(args, sd, synth, bs, S, H, arch, apis, rank=0, world=1, n_ep=32, qpe=15, passes=6, n_img=0, precision=None, head_precision=None):
+def episode_mode(args, sd, synth, bs, S, H, arch, apis, rank=0, world=1, n_ep=32, qpe=15, passes=6, n_img=0, precision=None, head_precision=None,
+                 parity_episodes=0):
     """The reference's real evaluation protocol (not `value`): every support set is paired with 15 queries
     (EdgeCape/datasets/datasets/mp100/test_dataset.py:86-99), so `n_ep` episodes are `n_ep * 15` pairs.  Streamed through
     ec_forward_episodes: a call takes the next q queries of the pair order and encodes the episodes that start in it - their support
@@ -394,7 +395,38 @@ def episode_mode(args, sd, synth, bs, S, H, arch, apis, rank=0, world=1, n_ep=32
     dt = apis.timed_steps(one_pass, passes, 1, collective=closing)     # warm-up: one whole protocol pass
     n_calls, n_pairs = passes * len(prepared), passes * len(ep)
     imgs = len(ep) + n_ep * S
-    return {"value": round(world * n_pairs / dt, 2), "unit": "images/s", "queries_per_episode": qpe, "episodes": n_ep, "pairs": len(ep), "shots": S,
+    parity = None
+    if parity_episodes > 0 and rank == 0 and world == 1 and torch.cuda.is_available():
+        # AFTER the timed region: the first call of the stream once more (it encodes its own episodes), and its first `parity_episodes`
+        # episodes - the same support sets, the same query images as in every timed pass - against the CPU oracle on the expanded pairs
+        # (the episode figure had no oracle-checked sample at its benched size)
+        from oracle import edgecape_oracle as orc   # checker only
+        outs = eng._outputs(prepared[0]["bs"])
+        eng.forward_episodes(cache, prepared=prepared[0], outputs=outs, pipelined=True)
+        eng.pipeline_flush()
+        torch.cuda.synchronize()
+        n_par = min(parity_episodes * qpe, len(calls[0]["queries"]))
+        e = ep[calls[0]["queries"][:n_par]]
+        pair_batch = dict(img_q=qry["img_q"][:n_par], img_s=[x[e] for x in sup["img_s"]], target_s=[x[e] for x in sup["target_s"]],
+                          target_weight_s=[x[e] for x in sup["target_weight_s"]],
+                          img_metas=[dict(qry["img_metas"][i], sample_skeleton=[skels[j]] * S) for i, j in enumerate(e)])
+        torch.set_num_threads(min(16, max(1, physical_cores()[0])))
+        _, ref = orc.forward_test(sd, pair_batch, synth.ARCHS[arch]["heads"])
+        valid = (mask[:, :, 0] > 0)[e]
+        got = outs[0]["output_kpts"].cpu().numpy()[:, :n_par]
+        d_all = np.abs(got - ref["output_kpts"].numpy())
+        am_g = outs[0]["similarity_map"].cpu().numpy()[:n_par].reshape(n_par, valid.shape[1], -1).argmax(-1)
+        am_r = ref["similarity_map"].numpy().reshape(n_par, valid.shape[1], -1).argmax(-1)
+        flips = (am_g != am_r) & valid
+        clean = ~flips.any(axis=1)
+        d = d_all[:, valid]
+        d_clean = d_all[:, clean][:, valid[clean]] if clean.any() else np.zeros(1)
+        parity = {"pairs": int(n_par), "episodes": int(len(set(e.tolist()))), "call": f"the stream's first call ({len(calls[0]['queries'])} queries + "
+                  f"{len(calls[0]['new_episodes']) * S} support images), re-issued behind the timed region", "tolerance": 1e-3,
+                  "max_abs_kpt_err_valid": float(d.max()), "max_abs_kpt_err_flip_free": float(d_clean.max()), "p99_abs_kpt_err_valid": float(np.quantile(d, 0.99)),
+                  "frac_gt_1e-3": float((d > 1e-3).mean()), "argmax_flips": int(flips.sum()), "valid_keypoints": int(valid.sum()),
+                  "within_tolerance": bool(d.max() < 1e-3), "oracle": "oracle/edgecape_oracle.py forward_test on the expanded (support set, query) pairs"}
+    return {"value": round(world * n_pairs / dt, 2), **({"parity_sample": parity} if parity else {}), "unit": "images/s", "queries_per_episode": qpe, "episodes": n_ep, "pairs": len(ep), "shots": S,
             "queries_per_call": q, "calls_per_pass": len(prepared), "passes_timed": passes, "seconds": round(dt, 6), "ms_per_call": round(dt / n_calls * 1e3, 3),
             "backbone_images_per_pair": round(imgs / len(ep), 3), "backbone_images_per_pair_uncached": 1 + S,
             "entry_point": "ec_forward_episodes, pipelined; every encode inside the timed region",

@@ -10,6 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libedgecape_hip.so")
 ARCH = "gfx950"
+CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]   # every source of the library (tools/isa_guard.py compiles with the same)
 
 
 def hipcc_path():
@@ -79,7 +80,7 @@ def build(force=False, verbose=True, lab=False):
     for s in sources():
         o = os.path.join(objdir, f"{os.path.basename(s)[:-4]}.{os.getpid()}.o")
         objs.append(o)
-        cmd = [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-c", s, "-o", o]
+        cmd = [cc, f"--offload-arch={ARCH}"] + CXXFLAGS + ["-c", s, "-o", o]
         if lab:
             cmd.insert(1, "-DEC_G8_LAB")
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

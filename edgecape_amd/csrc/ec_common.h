@@ -145,12 +145,24 @@ template <bool F16, bool OVFL = false> __device__ __forceinline__ void split4_h(
 // saturate at +-57344).  A weight row is [ W_hi: K x fp16 | W_hi8: K x e4m3 of W * 2^s1 | W_lo8: K x e4m3 of (W - W_hi) * 2^s2 ] with one
 // static power-of-two scale per tensor and plane (ec_finalize knows the weights).  The GEMM's load stream walks both rows straight
 // through (no K wrap): K / 64 K-tiles of fp16 MFMAs, then K / 64 K-tiles of FP8 MFMAs - 128 bytes of a row are one 16x16x128 operand.
-__device__ __forceinline__ unsigned pack4_e5m2(f32x4 v) {
+// Four fp32 values -> four e5m2 bytes of v * 2^SHIFT (round to nearest even).  v_cvt_pk_bf8_f32 does NOT saturate (tools/fp8_mfma_probe.hip:
+// >= 61440 -> inf), so the magnitude is clamped first (one v_med3: a NaN comes out finite here - the fp16 plane of the same value carries
+// the NaN into the product); the power of two rides in the scaled conversion (v_cvt_scalef32_pk_bf8_f32 divides by its scale operand).
+template <int SHIFT> __device__ __forceinline__ unsigned pack4_e5m2(f32x4 v) {
+  constexpr float lim = SHIFT == 0 ? 57344.f : 57344.f / (float)(1 << SHIFT);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], 0.f, __builtin_amdgcn_fmed3f(v[e], -57344.f, 57344.f));   // saturate, NaN stays NaN (sat_h16's form)
-  int r = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], 0, false);
-  r = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], r, true);
-  return (unsigned)r;
+  for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -lim, lim);
+  typedef __attribute__((ext_vector_type(2))) short s16x2_;
+  if constexpr (SHIFT == 0) {
+    int r = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], 0, false);
+    return (unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], r, true);
+  } else {
+    constexpr float inv = 1.f / (float)(1 << SHIFT);
+    s16x2_ r = {0, 0};
+    r = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(r, v[0], v[1], inv, false);
+    r = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(r, v[2], v[3], inv, true);
+    return __builtin_bit_cast(unsigned, r);
+  }
 }
 // OVFL: the caller has MODE.FP16_OVFL on (8-phase GEMM epilogue): the fp16 conversion saturates by itself
 template <bool OVFL = false> __device__ __forceinline__ void split4_x2(f32x4 v, u32x2_t& hi, unsigned& lo8, unsigned& hi8) {
@@ -163,9 +175,9 @@ template <bool OVFL = false> __device__ __forceinline__ void split4_x2(f32x4 v, 
   hi = __builtin_bit_cast(u32x2_t, h);
   f32x4 r;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) r[e] = (v[e] - (float)h[e]) * 2048.f;
-  lo8 = pack4_e5m2(r);
-  hi8 = pack4_e5m2(v);
+  for (int e = 0; e < 4; ++e) r[e] = v[e] - (float)h[e];
+  lo8 = pack4_e5m2<11>(r);      // |a - hi| <= 16 for any a inside the fp16 range: the clamp (28) only bites on saturated values
+  hi8 = pack4_e5m2<0>(v);
 }
 constexpr int X2_SCALE_LO8 = 127 - 11, X2_SCALE_HI8 = 127;   // E8M0 scale bytes of the two activation planes
 template <bool F16> __device__ __forceinline__ bf16_t f2h(float f) {
@@ -245,6 +257,36 @@ __device__ __forceinline__ float gelu_fast32(float x) {
   return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * q));
 }
 
+// GELU for 16-bit outputs (erf form: nn.GELU default, dinov2 Mlp) with ONE transcendental (round 4):
+//     gelu(x) = x Phi(x) = max(x, 0) - |x| Phi(-|x|),      Phi(-a) = 2^L(a),  L(a) = log2 Phi(-a)  smooth and concave on a >= 0
+// (for x > 0 by Phi(x) = 1 - Phi(-x)).  L is replaced by a polynomial in a = |x|, a weighted minimax fit (weight a Phi(-a) ln 2, the
+// sensitivity of the result to L; tools/gelu_fit.py: Lawson iteration on [0, 6]) whose leading coefficient is negative, so the
+// polynomial runs to -inf beyond the fitted range, 2^ -> 0 and the result goes to its exact limits x / -0 without a clamp.
+//   fp16 outputs: degree 5, max |err| 6.4e-7 in fp32 arithmetic on |x| <= 12 (the round-2/3 form 1 / (1 + 2^(x P(x^2))) had 3.0e-6);
+//   bf16 outputs: degree 3, max |err| 5.5e-5 (far below the bf16 rounding of the result).
+// Cost per element: 5 (3) v_fma + v_exp + v_max + v_fma = 7 (5) full-rate and ONE quarter-rate instruction; the old form was 8 (6)
+// full-rate and TWO quarter-rate ones (v_exp + v_rcp = 16 of its ~34 cycles; measured and rejected in round 3: a degree-2 polynomial,
+// packed-fp16 polynomials - both kept the two transcendentals).  |x| and -|x| are source modifiers, NaN goes through the last fma.
+// The limits hold for FINITE x; an infinite accumulator (an fp32 overflow, or an infinite activation) comes out as NaN for either
+// sign: q = -inf, 2^q = 0 and -|x| * 0 = NaN (the exact GELU would give +inf / -0).  Pinned by test_linear_h16_fp16_nan_in_nan_out.
+template <bool F16>
+__device__ __forceinline__ float gelu_fast8(float x) {
+  const float a = fabsf(x);
+  float q;
+  if constexpr (F16) {
+    q = fmaf(-4.732939302e-04f, a, 7.084460654e-03f);
+    q = fmaf(q, a, -5.182716738e-02f);
+    q = fmaf(q, a, -4.599926465e-01f);
+    q = fmaf(q, a, -1.150787770e+00f);
+    q = fmaf(q, a, -1.000037632e+00f);
+  } else {
+    q = fmaf(-2.487393087e-02f, a, -4.988535682e-01f);
+    q = fmaf(q, a, -1.129219622e+00f);
+    q = fmaf(q, a, -1.003536762e+00f);
+  }
+  return fmaf(-a, __builtin_amdgcn_exp2f(q), fmaxf(x, 0.f));
+}
+
 // ---------------------------------------------------------------------------------------------
 // GEMM (ec_gemm.hip):  C = epilogue(A[M,K] @ B[N,K]^T), optional batch via blockIdx.z.
 // epilogue:  v = acc + bias[n] + table[m % period][n];  v = act(v);
@@ -269,7 +311,9 @@ struct GemmP {
   int act = ACT_NONE;
   int c_bf16 = 0;   // store C as bf16
   int c_x3 = 0;     // store C as the bf16 split [hi | lo] of the fp32 result (split4_bf16): 16-bit rows of stride ldc, the two
-                    // planes N elements apart (ldc >= 2 N) - the A operand of a following K-concatenated bf16x3 GEMM; exact GELU
+                    // planes N elements apart (ldc >= 2 N) - the A operand of a following K-concatenated bf16x3 GEMM; GELU = gelu_fast8<true>
+                    // (6.4e-7) in EVERY epilogue that writes this format (8-phase staged / generic, 2-barrier fallback): an image's features
+                    // do not change form with the kernel its batch size selects
   int kwrap = 0;    // 16-bit operands only: K-CONCATENATED bf16x3 product over TWO-plane operands.  kwrap = K-steps (64 elements) per plane;
                     // K = 3 * 64 * kwrap logical steps, step kt reads A at plane step (kt < 2 kwrap ? kt : kt - 2 kwrap) - planes
                     // [hi | lo | hi] of A = [hi | lo] - and B at (kt < kwrap ? kt : kt - kwrap) - planes [hi | hi | lo] of B = [W_hi | W_lo]:

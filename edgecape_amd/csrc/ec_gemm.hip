@@ -311,7 +311,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_nt_kernel(GemmP p) {
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
           } else if (p.act == ACT_GELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = p.c_bf16 ? gelu_fast(v[e]) : gelu_erf(v[e]);
+            for (int e = 0; e < 8; ++e) v[e] = p.c_bf16 ? gelu_fast(v[e]) : p.c_x3 ? gelu_fast8<true>(v[e]) : gelu_erf(v[e]);   // (c_x3: the form of the 8-phase epilogues, ec_common.h)
           } else if (p.act == ACT_TANHGATE) {
             const float* ap = aux + (long)m * p.ldaux + n;
 #pragma unroll
@@ -580,7 +580,11 @@ int gemm_nt(const GemmP& p, hipStream_t st) {
   // matters for the head's small problems (M = bs*K = 3200 rows, N = 256) is how evenly the tiles spread over the 256
   // CUs: pick the tile minimising  ceil(tiles / CUs) * tile_area / efficiency.  256x256 only pays for the big backbone
   // GEMMs (fp32 parity mode) where operand re-reads dominate.
+#ifdef EC_G8_LAB   // kernel-lab build only (python -m edgecape_amd.build --lab): force a tile configuration, EC_GEMM_TILE=256/256128/128/12864/64
   static const int force = getenv("EC_GEMM_TILE") ? atoi(getenv("EC_GEMM_TILE")) : 0;
+#else
+  constexpr int force = 0;
+#endif
   // (a larger stage ring measured neutral on the head's shapes - kp 3200x256x256: 8.0 vs 8.2 us; 10368x256x768: 30 vs 37 us: those
   // kernels sit at the per-launch floor, not at the load latency - and was removed in round 3: the 2-stage ring is the only form)
   static int ncu_dev[64] = {};

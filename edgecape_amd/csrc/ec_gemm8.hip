@@ -86,35 +86,7 @@ constexpr int G8_AHEAD = 5;               // half-tiles the load stream runs ahe
 enum { G8_GENERIC = 0, G8_BIAS_BF16 = 1, G8_SCALE_BF16 = 2, G8_GELU_BF16 = 3, G8_TAB_H16 = 4, G8_TAB_F32 = 5, G8_F32 = 6, G8_RES_F32 = 7, G8_GELU_X3 = 8, G8_GELU_X2 = 9 };
 constexpr bool g8_f32_out(int kind) { return kind == G8_TAB_F32 || kind == G8_F32 || kind == G8_RES_F32; }
 
-// GELU for 16-bit outputs (erf form: nn.GELU default, dinov2 Mlp) with ONE transcendental (round 4):
-//     gelu(x) = x Phi(x) = max(x, 0) - |x| Phi(-|x|),      Phi(-a) = 2^L(a),  L(a) = log2 Phi(-a)  smooth and concave on a >= 0
-// (for x > 0 by Phi(x) = 1 - Phi(-x)).  L is replaced by a polynomial in a = |x|, a weighted minimax fit (weight a Phi(-a) ln 2, the
-// sensitivity of the result to L; tools/gelu_fit.py: Lawson iteration on [0, 6]) whose leading coefficient is negative, so the
-// polynomial runs to -inf beyond the fitted range, 2^ -> 0 and the result goes to its exact limits x / -0 without a clamp.
-//   fp16 outputs: degree 5, max |err| 6.4e-7 in fp32 arithmetic on |x| <= 12 (the round-2/3 form 1 / (1 + 2^(x P(x^2))) had 3.0e-6);
-//   bf16 outputs: degree 3, max |err| 5.5e-5 (far below the bf16 rounding of the result).
-// Cost per element: 5 (3) v_fma + v_exp + v_max + v_fma = 7 (5) full-rate and ONE quarter-rate instruction; the old form was 8 (6)
-// full-rate and TWO quarter-rate ones (v_exp + v_rcp = 16 of its ~34 cycles; measured and rejected in round 3: a degree-2 polynomial,
-// packed-fp16 polynomials - both kept the two transcendentals).  |x| and -|x| are source modifiers, NaN goes through the last fma.
-// The limits hold for FINITE x; an infinite accumulator (an fp32 overflow, or an infinite activation) comes out as NaN for either
-// sign: q = -inf, 2^q = 0 and -|x| * 0 = NaN (the exact GELU would give +inf / -0).  Pinned by test_linear_h16_fp16_nan_in_nan_out.
-template <bool F16>
-__device__ __forceinline__ float gelu_fast8(float x) {
-  const float a = fabsf(x);
-  float q;
-  if constexpr (F16) {
-    q = fmaf(-4.732939302e-04f, a, 7.084460654e-03f);
-    q = fmaf(q, a, -5.182716738e-02f);
-    q = fmaf(q, a, -4.599926465e-01f);
-    q = fmaf(q, a, -1.150787770e+00f);
-    q = fmaf(q, a, -1.000037632e+00f);
-  } else {
-    q = fmaf(-2.487393087e-02f, a, -4.988535682e-01f);
-    q = fmaf(q, a, -1.129219622e+00f);
-    q = fmaf(q, a, -1.003536762e+00f);
-  }
-  return fmaf(-a, __builtin_amdgcn_exp2f(q), fmaxf(x, 0.f));
-}
+// (gelu_fast8, the single-transcendental GELU of the 16-bit and split-plane epilogues: ec_common.h)
 
 // acc[mi][ni] (f32x4) of lane l: row m = m0 + wr*128 + mi*16 + (l&15),
 //                                cols n = n0 + wc*64 + (ni>>1)*32 + (ni&1)*16 + (l>>4)*4 .. +3
@@ -150,7 +122,7 @@ __device__ __forceinline__ void g8_epilogue_generic(const GemmP& p, f32x4 (&acc)
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       } else if (p.act == ACT_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = p.c_bf16 ? gelu_fast8<F16>(v[e]) : p.c_x3 ? gelu_fast32(v[e]) : gelu_erf(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = p.c_bf16 ? gelu_fast8<F16>(v[e]) : p.c_x3 ? gelu_fast8<true>(v[e]) : gelu_erf(v[e]);   // (c_x3: ONE form in every epilogue of the mode)
       }
       v *= gam4[ni];
       if (p.resid) v += *(const f32x4*)(p.resid + (long)m * p.ldr + n);
@@ -232,7 +204,7 @@ __device__ __forceinline__ void g8_piece(f32x4 (&a)[4], const __amdgpu_buffer_rs
       const int c0 = (ni >> 1) * 32 + (ni & 1) * 16 + wq * 4;
       f32x4 v = a[ni] + *(const f32x4*)(bias_lds + c0 * 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = F16 ? gelu_fast32(v[e]) : gelu_fast8<true>(v[e]);   // fp16 planes carry 22 bits: 6.7e-8 instead of 6.4e-7
+      for (int e = 0; e < 4; ++e) v[e] = gelu_fast8<true>(v[e]);
       split4_h<F16, true>(v, vh[ni], vl[ni]);
       a[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -519,7 +491,7 @@ __global__ __launch_bounds__(512) void gemm8_bf16_kernel(GemmP p) {
   // The last workgroup to leave re-arms the counters (sched[8] counts leavers) for the next launch on the stream.
   // (compiled into the bias and bias + GELU kinds only - QKV and fc1, the multi-round shapes of the backbone; the LayerScale kind of
   //  proj / fc2, one tile per workgroup, has no register to spare for it)
-  constexpr bool DYN_OK = KIND == G8_BIAS_BF16 || KIND == G8_GELU_BF16;
+  constexpr bool DYN_OK = KIND == G8_BIAS_BF16 || KIND == G8_GELU_BF16 || (X2 && (KIND == G8_F32 || KIND == G8_GELU_X2));   // (fp16x2: QKV, fc1)
   const bool dyn = DYN_OK && p.sched != nullptr;
   // A workgroup is counted as a leaver as soon as it knows that it will not ask again (its last answer was past the range), i.e.
   // during its last tile's K loop, not at its end: the count's round trip is off the launch's tail.  left_s: the scalar atomic's
@@ -918,7 +890,7 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
     }
     const long nt = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     GemmP q = p;
-    q.sched = nullptr;
+    if (nt <= ds.ncu || ds.ncu < 8 || p.x2 < 4 || k3 == 1) q.sched = nullptr;   // dynamic tile schedule: multi-round QKV / fc1 only (the hand-over spans three fp16 K-tiles)
     hipLaunchKernelGGL(x2_table[k3][p.tag], dim3((unsigned)(nt < ds.ncu ? nt : ds.ncu)), dim3(512), G8_LDS, st, q);
     EC_LAUNCH_CHECK();
     return 1;

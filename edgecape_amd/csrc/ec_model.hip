@@ -570,10 +570,10 @@ static int linear_x3(const void* A, const Lin& W, void* C, long ldc, bool c_x3, 
 // fp16x2 Linear (EC_F16X2 backbone): A = fp16x2 rows [hi | lo8 | hi8] of W.K values (row stride 2 K 16-bit units), W.w_x2 likewise; C fp32
 // (optionally LayerScale + the in-place residual), or (c_x2) the fp16x2 rows of gelu(.), row stride ldc 16-bit units
 static int linear_x2(const void* A, const Lin& W, void* C, long ldc, bool c_x2, int M, int act, hipStream_t st, const float* gamma,
-                     const float* resid, long ldr, int tag) {
+                     const float* resid, long ldr, int tag, int* sched = nullptr) {
   EC_REQUIRE(W.w_x2 != nullptr, EC_ERR_STATE, "linear_x2: fp16x2 weight copy was not built");
   GemmP p;
-  p.tag = tag;
+  p.tag = tag; p.sched = sched;
   p.A = A; p.lda = 2l * W.K; p.ab_bf16 = 1; p.h_f16 = 1;
   p.B = W.w_x2; p.ldb = 2l * W.K; p.x2 = W.K / 64; p.x2_sa = W.x2_sa;
   p.C = C; p.ldc = ldc; p.c_x2 = c_x2 ? 1 : 0;
@@ -650,7 +650,7 @@ static int run_backbone(ec_model* m, const float* const* imgs, const int* counts
     const bool prof = m->prof_on && (m->prof_mode != 2 || i == m->prof_pass % m->blocks.size()) && m->prof_used + 2 <= m->prof_ev.size();
     if (prof) EC_HIP(hipEventRecord(m->prof_ev[m->prof_used++], st));
     if (x2) {
-      RUN(linear_x2(m->bb_xn, b.qkv, m->bb_qkv, 3 * C, false, (int)M, ACT_NONE, st, nullptr, nullptr, 0, 1));
+      RUN(linear_x2(m->bb_xn, b.qkv, m->bb_qkv, 3 * C, false, (int)M, ACT_NONE, st, nullptr, nullptr, 0, 1, sched));
     } else if (x3) {
       RUN(linear_x3(m->bb_xn, b.qkv, m->bb_qkv, 3 * C, false, (int)M, ACT_NONE, st, nullptr, nullptr, 0, 1, xf));
     } else {
@@ -678,7 +678,7 @@ static int run_backbone(ec_model* m, const float* const* imgs, const int* counts
       // fp16x2 (round 6): the same four launches on fp16x2 operands - a_hi W_hi in fp16 MFMAs, both correction terms in one FP8 pass
       RUN(linear_x2(m->bb_att, b.proj, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls1, m->bb_x, C, 2));
       RUN(ln(m->bb_x, C, m->bb_xn, 2 * C, 6, b.n2, (int)M, C, 1e-6f, st));
-      RUN(linear_x2(m->bb_xn, b.fc1, m->bb_h, 8 * C, true, (int)M, ACT_GELU, st, nullptr, nullptr, 0, 3));
+      RUN(linear_x2(m->bb_xn, b.fc1, m->bb_h, 8 * C, true, (int)M, ACT_GELU, st, nullptr, nullptr, 0, 3, sched));
       RUN(linear_x2(m->bb_h, b.fc2, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls2, m->bb_x, C, 4));
     } else if (x3) {
       // K-concatenated bf16x3 (round 5): every block GEMM is ONE 16-bit GEMM of depth 3 K on the 8-phase kernel - activations as bf16
@@ -2319,11 +2319,11 @@ static int episodes_impl(ec_handle m, ec_support_t c, const float* const* img_s,
       RUN(join_on_error(m, scatter_b(m->side)));
       EC_HIP(hipEventRecord(m->ev_join, m->side));
     }
-    mark_filled();
     RUN(join_on_error(m, run_head_query(m, m->feat, bs, m->dq, out, ws, n_new > 0 ? m->ev_sk : nullptr, n_new > 0 ? m->ev_join : nullptr,
                                         gather_a, gather_b)));
     EC_HIP(hipStreamWaitEvent(st, m->ev_inputs, 0));
     m->feat_read_pending = true;
+    mark_filled();                                   // (only once every enqueue of the call has succeeded: ADVICE r5)
     return tl_dump(m);
   }
 
@@ -2339,17 +2339,17 @@ static int episodes_impl(ec_handle m, ec_support_t c, const float* const* img_s,
     RUN(join_on_error(m, run_head_support(m, fsp.data(), target_s, mask_s, n_new, S, m->side, sg, m->ev_sk, 0, scatter_a)));
     RUN(join_on_error(m, scatter_b(m->side)));
     EC_HIP(hipEventRecord(m->ev_join, m->side));
-    mark_filled();
     RUN(join_on_error(m, run_head_query(m, m->feat, bs, st, out, ws, m->ev_sk, m->ev_join, gather_a, gather_b)));
     if (m->dq_active) EC_HIP(hipStreamWaitEvent(st, m->ev_feat_read, 0));   // (see run_head)
+    mark_filled();
     return tl_dump(m);
   }
   if (n_new > 0) {
     RUN(join_on_error(m, run_head_support(m, fsp.data(), target_s, mask_s, n_new, S, st, sg, nullptr, 0, scatter_a)));
     RUN(join_on_error(m, scatter_b(st)));
-    mark_filled();
   }
   if (bs > 0) RUN(join_on_error(m, run_head_query(m, m->feat, bs, st, out, ws, nullptr, nullptr, gather_a, gather_b)));
+  mark_filled();
   return tl_dump(m);
 }
 
@@ -2362,20 +2362,29 @@ int ec_support_encode(ec_handle m, ec_support_t c, const float* const* img_s, co
   const std::vector<char> before = c->filled;
   std::fill(c->filled.begin(), c->filled.end(), 0);   // the cache then holds exactly these episodes, slots 0 .. n_episodes - 1
   const int rc = episodes_impl(m, c, img_s, target_s, mask_s, edges, off, slots.data(), n_episodes, S, nullptr, nullptr, 0, stream, nullptr, false);
-  if (rc) c->filled = before;
+  if (rc) {
+    // a scatter into slots 0 .. n - 1 may already have been enqueued when a later step failed: the episodes that were there are gone,
+    // the others are what they were (restoring every flag claimed that partly overwritten slots were still valid)
+    c->filled = before;
+    for (int i = 0; i < n_episodes; ++i) c->filled[i] = 0;
+  }
   return rc;
 }
 
 int ec_forward_cached(ec_handle m, ec_support_t c, const float* img_q, const int32_t* episode_of_query, int bs, void* stream,
                       const ec_outputs* out) {
-  EC_REQUIRE(bs > 0, EC_ERR_ARG, "bs / S exceed the configured maxima");
+  EC_REQUIRE(bs > 0, EC_ERR_ARG, "ec_forward_cached: bs must be positive");
   return episodes_impl(m, c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, img_q, episode_of_query, bs, stream, out, false);
 }
 
 int ec_forward_episodes(ec_handle m, ec_support_t c, const float* const* img_s, const float* const* target_s, const float* mask_s,
                         const int32_t* edges, const int32_t* off, const int32_t* slots, int n_new, int S, const float* img_q,
                         const int32_t* slot_of_query, int bs, void* stream, const ec_outputs* out, int pipelined) {
-  return episodes_impl(m, c, img_s, target_s, mask_s, edges, off, slots, n_new, S, img_q, slot_of_query, bs, stream, out, pipelined != 0);
+  const int rc = episodes_impl(m, c, img_s, target_s, mask_s, edges, off, slots, n_new, S, img_q, slot_of_query, bs, stream, out, pipelined != 0);
+  if (rc && c && slots)   // the slots this call targeted may hold partly written state: they are empty until encoded again
+    for (int i = 0; i < n_new; ++i)
+      if (slots[i] >= 0 && slots[i] < c->cap) c->filled[slots[i]] = 0;
+  return rc;
 }
 
 // ---- on-device input pipeline ---------------------------------------------------------------

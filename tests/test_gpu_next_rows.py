@@ -329,16 +329,19 @@ def test_forward_pipelined_stress():
             assert torch.equal(host[k], ref[bi][k].cpu()), (step, bi, k)
 
 
-@pytest.mark.parametrize("arch,H,bs,S,nb", [("dinov2_vits14", 224, 4, 1, 5), ("dinov2_vits14", 224, 4, 5, 5), ("dinov2_vitb14", 256, 32, 1, 3),
-                                               ("dinov2_vits14", 224, 32, 1, 3), ("dinov2_vitl14", 384, 8, 1, 3), ("dinov2_vitb14", 256, 16, 5, 3)])
-def test_forward_pipelined_bit_equal(arch, H, bs, S, nb):
+@pytest.mark.parametrize("arch,H,bs,S,nb,prec", [("dinov2_vits14", 224, 4, 1, 5, "fp16/mixed"), ("dinov2_vits14", 224, 4, 5, 5, "fp16/mixed"),
+                                                    ("dinov2_vitb14", 256, 32, 1, 3, "fp16/mixed"), ("dinov2_vits14", 224, 32, 1, 3, "fp16/mixed"),
+                                                    ("dinov2_vitl14", 384, 8, 1, 3, "fp16/mixed"), ("dinov2_vitb14", 256, 16, 5, 3, "fp16/mixed"),
+                                                    ("dinov2_vitb14", 256, 32, 1, 3, "fp16x2/bf16x3"), ("dinov2_vits14", 224, 4, 1, 3, "fp16x2/bf16x3")])
+def test_forward_pipelined_bit_equal(arch, H, bs, S, nb, prec):
     """ec_forward_pipelined (the head of call i beside the backbone of call i+1) against ec_forward on the same batches: every
     output of every batch bit-equal, with alternating output sets, results fetched through a copy stream behind ec_pipeline_flush,
     and with plain ec_forward calls mixed into the sequence (every other entry point waits for a pending head).  The cfg2-sized case
-    also runs the backbone's QKV / fc1 GEMMs on their DYNAMIC tile schedule in the pipelined calls (static in ec_forward)."""
+    also runs the backbone's QKV / fc1 GEMMs on their DYNAMIC tile schedule in the pipelined calls (static in ec_forward) - in the
+    headline precision and in the conforming one (fp16x2 backbone / bf16x3 head, round 6)."""
     from edgecape_amd.engine import HipEngine
     sd = synth.make_weights(arch, seed=3)
-    eng = HipEngine(sd, arch=arch, image_size=H, max_batch=bs, max_shots=S, backbone_precision="fp16", head_precision="mixed")
+    eng = HipEngine(sd, arch=arch, image_size=H, max_batch=bs, max_shots=S, backbone_precision=prec.split("/")[0], head_precision=prec.split("/")[1])
     dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
     batches = []
     for i in range(nb):
@@ -424,7 +427,8 @@ def test_forward_episodes_stream(shots, precision):
     the queries' backbone pass).  (a) every call equals ec_forward on its expanded (support set, query) pairs - which the oracle and
     the golden fixtures pin - to 1e-6 (fp32) / the precision gates' bound (fp16 / mixed: the backbone batch composition differs, the
     arithmetic per image does not); (b) the same stream through the PIPELINED form, head of call i beside the backbone of call
-    i + 1, row compaction on, is bit-equal to the plain one; (c) and so is ec_support_encode + ec_forward_cached."""
+    i + 1, row compaction on, is bit-equal to the plain one; (c) and so is ec_support_encode + ec_forward_cached; (d) every call against
+    the CPU oracle on its expanded pairs."""
     from edgecape_amd.engine import HipEngine, SupportCache
     from edgecape_amd.episodes import stream_schedule
     arch, H, n_ep, qpe, bs = "dinov2_vits14", 224, 5, 5, 6
@@ -451,6 +455,27 @@ def test_forward_episodes_stream(shots, precision):
                 tol = {"similarity_map": 0.5, "adj": 1e-3, "attn_adj": 1e-3}.get(k, 5e-3)
             assert d < tol, (i, k, d)
             assert np.array_equal(got, piped[i][k]), (i, k, float(np.abs(got - piped[i][k]).max()))
+    # (d) against the ORACLE (the streaming form was only ever compared with ec_forward): every expanded (support set, query)
+    # pair of every call through the CPU restatement of the reference, which recomputes the support side per pair (EdgeCape.py:131-163)
+    from oracle import edgecape_oracle as orc   # the checker
+    heads = synth.ARCHS[arch]["heads"]
+    for i, c in enumerate(calls):
+        e = ep[c["queries"]]
+        with torch.no_grad():
+            fq = orc.dinov2_features(sd, img_q[c["queries"]], heads)
+            fs = [orc.dinov2_features(sd, x[e], heads) for x in sup["img_s"]]
+            ref = orc.head_forward(sd, fq, fs, [x[e] for x in sup["target_s"]], orc._t(mask[e]), [skels[j] for j in e])
+        valid = mask[e][:, :, 0] > 0
+        am_g = plain[i]["similarity_map"].reshape(len(e), valid.shape[1], -1).argmax(-1)
+        am_r = ref["similarity_map"].numpy().reshape(len(e), valid.shape[1], -1).argmax(-1)
+        flip = (am_g != am_r) & valid
+        clean = ~flip.any(1)
+        d = np.abs(plain[i]["output_kpts"] - ref["output_kpts"].numpy())
+        dmax = float(d[:, clean][:, valid[clean]].max()) if clean.any() else 0.0
+        # fp32 engine: exact-fp32 MFMAs, 1e-6 observed; fp16 / mixed: the headline precision's single-batch gates (max 3e-4 on flip-free samples, <= 1 flip)
+        assert int(flip.sum()) <= (0 if precision == "fp32" else 1), (i, int(flip.sum()))
+        assert dmax < (5e-5 if precision == "fp32" else 3e-4), (i, dmax)
+        assert np.abs(plain[i]["adj"] - ref["adj"].numpy()).max() < (1e-5 if precision == "fp32" else 1e-3), i
     # (c) the two-call form on the same queries: all episodes encoded at once, then the queries of call 1 (episodes 1 and 2)
     cache = eng.support_encode(sup["img_s"], sup["target_s"], mask, skels)
     got = eng.forward_cached(img_q[calls[1]["queries"]], cache, ep[calls[1]["queries"]])

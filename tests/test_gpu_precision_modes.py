@@ -94,6 +94,145 @@ def _oracle_task(task):
     return path
 
 
+# ---- the reference's evaluation protocol (test_dataset.py:86-99): episodes of one support set and `qpe` consecutive queries ------------
+def episode_set(name, wseed, n_ep, qpe=15):
+    """n_ep synthetic episodes of a configuration: support sets from one generator stream, n_ep * qpe query images from another (disjoint
+    from the pairwise conformance sets' seeds).  Returns (sup batch, query images, mask [n_ep,K,1], skeletons, episode_of_pair, query metas)."""
+    c = CFG[name]
+    sup = synth.make_pairs(n_ep, c["S"], c["H"], seed=c["iseed"] + 300000 * (1 + wseed), fixed_n_kp=False)
+    qry = synth.make_pairs(n_ep * qpe, 1, c["H"], seed=c["iseed"] + 400000 * (1 + wseed))
+    mask = sup["target_weight_s"][0].copy()
+    for tw in sup["target_weight_s"]:
+        mask = mask * tw
+    skels = [m["sample_skeleton"][0] for m in sup["img_metas"]]
+    return sup, qry["img_q"], mask, skels, np.repeat(np.arange(n_ep, dtype=np.int32), qpe), qry["img_metas"]
+
+
+def expanded_pairs(sup, img_q, skels, ep, metas_q, idx):
+    """the (support set, query) pairs `idx` of an episode set as the batch dict the reference's forward_test takes (what the
+    reference evaluates: every pair on its own, support side recomputed per pair)"""
+    e = ep[idx]
+    S = len(sup["img_s"])
+    metas = []
+    for i, ei in zip(idx, e):
+        m = dict(metas_q[i])
+        m["sample_skeleton"] = [skels[ei] for _ in range(S)]
+        m["sample_image_file"] = sup["img_metas"][ei]["sample_image_file"]
+        metas.append(m)
+    return dict(img_q=img_q[idx], img_s=[x[e] for x in sup["img_s"]], target_s=[x[e] for x in sup["target_s"]],
+                target_weight_s=[x[e] for x in sup["target_weight_s"]], img_metas=metas)
+
+
+def _oracle_episode_path(name, wseed, n_ep, qpe, chunk, chunk_pairs, outliers=False):
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in (os.path.join(root, "oracle", "edgecape_oracle.py"), os.path.join(root, "edgecape_amd", "synth.py")):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    c = CFG[name]
+    h.update(repr(("episodes", c["arch"], c["H"], c["S"], c["iseed"], wseed, n_ep, qpe, chunk, chunk_pairs, bool(outliers))).encode())
+    d = os.path.join(os.environ.get("EC_ORACLE_CACHE", "/tmp/ec_oracle_cache"))
+    os.makedirs(d, exist_ok=True)
+    return os.path.join(d, "ep_" + h.hexdigest()[:24] + ".npz")
+
+
+def _oracle_episode_task(task):
+    name, wseed, n_ep, qpe, chunk, chunk_pairs, outliers, threads = task
+    path = _oracle_episode_path(name, wseed, n_ep, qpe, chunk, chunk_pairs, outliers)
+    if os.path.exists(path):
+        return path
+    from oracle import edgecape_oracle as orc   # the checker
+    c = CFG[name]
+    torch.set_num_threads(threads)
+    w = synth.make_weights(c["arch"], seed=wseed, outliers=outliers)
+    sup, img_q, mask, skels, ep, metas_q = episode_set(name, wseed, n_ep, qpe)
+    idx = np.arange(chunk * chunk_pairs, min((chunk + 1) * chunk_pairs, len(ep)))
+    with torch.no_grad():
+        _, out = orc.forward_test(w, expanded_pairs(sup, img_q, skels, ep, metas_q, idx), synth.ARCHS[c["arch"]]["heads"])
+    tmp = path + ".%d.tmp.npz" % os.getpid()
+    np.savez(tmp, **{k: out[k].numpy() for k in ORACLE_KEYS})
+    os.replace(tmp, path)
+    return path
+
+
+def oracle_episode_outputs(name, wseed, n_ep, qpe=15, chunk_pairs=30, outliers=False):
+    """The oracle's answers for all n_ep * qpe expanded pairs of an episode set, in pair order (cached per chunk of chunk_pairs pairs)."""
+    n_chunks = (n_ep * qpe + chunk_pairs - 1) // chunk_pairs
+    ncpu = effective_cpus()
+    tasks = [(name, wseed, n_ep, qpe, ch, chunk_pairs, outliers) for ch in range(n_chunks)]
+    missing = [t for t in tasks if not os.path.exists(_oracle_episode_path(*t))]
+    workers = max(1, min(len(missing), 8, ncpu // 16))
+    threads = max(4, min(32, ncpu // max(workers, 1)))
+    if len(missing) > 1 and workers > 1:
+        import multiprocessing as mp
+        with mp.get_context("spawn").Pool(workers) as pool:
+            pool.map(_oracle_episode_task, [t + (threads,) for t in missing], chunksize=1)
+    else:
+        for t in missing:
+            _oracle_episode_task(t + (threads,))
+    outs = []
+    for t in tasks:
+        with np.load(_oracle_episode_path(*t)) as z:
+            outs.append({k: z[k] for k in ORACLE_KEYS})
+    return dict(output_kpts=np.concatenate([o["output_kpts"] for o in outs], 1), similarity_map=np.concatenate([o["similarity_map"] for o in outs], 0),
+                adj=np.concatenate([o["adj"] for o in outs], 0))
+
+
+def episode_call_size(name, qpe=15):
+    """queries per ec_forward_episodes call as bench.py's episode leg sizes them: a call's backbone pass holds about as many images as a
+    pairwise step of the configuration ((1 + S) * bs): 60 + 4 at cfg2, 72 + 20..25 at cfg4."""
+    c = CFG[name]
+    return max(1, (1 + c["S"]) * c["bs"] * qpe // (qpe + c["S"]))
+
+
+def conformance_episodes(n_ep=17, wseeds=(0, 1), backbone="fp16", head="mixed", name="cfg2", qpe=15, pipelined=True, outliers=False):
+    """A precision mode against the oracle through ec_forward_episodes - the entry point of the reference's evaluation protocol (15 queries
+    per support set, test_dataset.py:86-99) - at the call size bench.py's `episode_cached` leg uses: n_ep episodes per weight seed
+    (17 x 15 = 255 pairs) streamed in calls of episode_call_size() queries, the support sets of the episodes that start in a call riding
+    in its backbone pass, slot cache, pipelined heads.  The oracle evaluates every expanded (support set, query) pair on its own, as
+    the reference does.  Same statistics as conformance_at_scale."""
+    from edgecape_amd.engine import HipEngine
+    from edgecape_amd.episodes import stream_schedule
+    c = CFG[name]
+    q = episode_call_size(name, qpe)
+    cap = (q + qpe - 1) // qpe + 2
+    per_seed, pg, pr, pv = [], [], [], []
+    for ws in wseeds:
+        ref = oracle_episode_outputs(name, ws, n_ep, qpe, outliers=outliers)
+        sup, img_q, mask, skels, ep, _ = episode_set(name, ws, n_ep, qpe)
+        w = synth.make_weights(c["arch"], seed=ws, outliers=outliers)
+        eng = HipEngine(w, arch=c["arch"], image_size=c["H"], max_batch=q, max_shots=c["S"], backbone_precision=backbone, head_precision=head)
+        cache = eng.support_cache(cap)
+        res = []
+        for call in stream_schedule(ep, q, cap):
+            new = None
+            if len(call["new_episodes"]):
+                e = np.asarray(call["new_episodes"])
+                new = dict(img_s=[x[e] for x in sup["img_s"]], target_s=[x[e] for x in sup["target_s"]], mask_s=mask[e],
+                           skeletons=[skels[i] for i in e], slots=call["new_slots"])
+            res.append(eng.forward_episodes(cache, img_q[call["queries"]], call["slot_of_query"], new=new, pipelined=pipelined))
+        if pipelined:
+            eng.pipeline_flush()
+        torch.cuda.synchronize()
+        got = dict(output_kpts=np.concatenate([o["output_kpts"].cpu().numpy() for o in res], 1),
+                   similarity_map=np.concatenate([o["similarity_map"].cpu().numpy() for o in res], 0),
+                   adj=np.concatenate([o["adj"].cpu().numpy() for o in res], 0))
+        del eng, cache, res
+        valid = (mask[:, :, 0] > 0)[ep]
+        st = stats(got, ref, valid, c["H"])
+        st["weight_seed"], st["pairs"], st["episodes"] = ws, int(valid.shape[0]), n_ep
+        per_seed.append(st)
+        pg.append(got); pr.append(ref); pv.append(valid)
+    cat = lambda L, k, ax: np.concatenate([x[k] for x in L], ax)
+    pooled = stats(dict(output_kpts=cat(pg, "output_kpts", 1), similarity_map=cat(pg, "similarity_map", 0), adj=cat(pg, "adj", 0)),
+                   dict(output_kpts=cat(pr, "output_kpts", 1), similarity_map=cat(pr, "similarity_map", 0), adj=cat(pr, "adj", 0)),
+                   np.concatenate(pv, 0), c["H"])
+    pooled["pairs"] = int(sum(v.shape[0] for v in pv))
+    pooled["queries_per_call"], pooled["queries_per_episode"], pooled["cache_slots"] = q, qpe, cap
+    return per_seed, pooled
+
+
 def effective_cpus():
     """CPUs this process can really use: the affinity mask, cut down to the cgroup's CPU quota (a GPU box of the pool shows 256 logical
     CPUs and grants a fraction of them: eight 32-thread workers under such a quota ran an order of magnitude SLOWER than one)."""

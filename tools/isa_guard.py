@@ -55,9 +55,15 @@ def main():
     if len(sys.argv) > 1:
         path = sys.argv[1]
     else:
+        sys.path.insert(0, ROOT)
+        from edgecape_amd import build     # the compiler, target and flags the shipped library is built with
         path = os.path.join(tempfile.mkdtemp(prefix="isa_guard_"), "ec_gemm8.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                        os.path.join(ROOT, "edgecape_amd", "csrc", "ec_gemm8.hip"), "-o", path], check=True, stderr=subprocess.DEVNULL)
+        cmd = [build.hipcc_path(), f"--offload-arch={build.ARCH}"] + build.CXXFLAGS + ["-S", "--cuda-device-only",
+               os.path.join(build.CSRC, "ec_gemm8.hip"), "-o", path]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            print("compile failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+            return 2
     n, bad = check(path)
     print(f"{n} scalar atomics, {len(bad)} with their register touched before the collecting wait")
     for b in bad:

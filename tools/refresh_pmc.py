@@ -47,7 +47,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     bench_cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-episode", "--no-alt", "--sustained-seconds", "0", "--steps", "2", "--warmup", "1",
              "--precision", args.precision, "--batch", str(args.batch), "--shots", str(args.shots), "--image-size", str(args.image_size),
-             "--arch", args.arch] + (["--head-precision", "bf16x3"] if args.precision == "bf16x3" else [])
+             "--arch", args.arch] + (["--head-precision", "bf16x3"] if args.precision in ("bf16x3", "fp16x2") else [])
     env = dict(os.environ, TMPDIR="/tmp")
     merged = {}
     for tag, counters in PASSES:
@@ -72,7 +72,8 @@ def main():
 
     f16 = "true" if args.precision == "fp16" else "false"
     x3 = args.precision == "bf16x3"    # K-concatenated form: bf16 [hi | lo | hi] x [W_hi | W_hi | W_lo], depth 3 K, fp32 output (G8_F32 kind, tag 1)
-    name = next((kn for (kn, cn) in merged if kn.startswith("gemm8_bf16_kernel<6, 1, false" if x3 else "gemm8_bf16_kernel<1, 1, " + f16)), None)
+    x2 = args.precision == "fp16x2"    # fp16x2 operands: rows [fp16 | e5m2 | e5m2] x [fp16 | e4m3 | e4m3], 4 bytes per value, fp32 output (G8_F32 kind, tag 1, X2)
+    name = next((kn for (kn, cn) in merged if kn.startswith("gemm8_bf16_kernel<6, 1, true, 0, true" if x2 else "gemm8_bf16_kernel<6, 1, false" if x3 else "gemm8_bf16_kernel<1, 1, " + f16)), None)
     if name is None:
         sys.exit("QKV kernel symbol not found among: " + ", ".join(sorted({k for k, _ in merged})))
     get = lambda c: merged[(name, c)][1]
@@ -80,14 +81,14 @@ def main():
     T = (args.image_size // 14) ** 2 + 1
     M, K, N = (1 + args.shots) * args.batch * T, a["C"], 3 * a["C"]
     algorithmic = M * K * 2 + N * K * 2 + M * N * 2 + N * 4          # A + W + C (16-bit) + bias
-    if x3:
-        algorithmic = M * 2 * K * 2 + N * 2 * K * 2 + M * N * 4 + N * 4   # two bf16 planes of A and of W in memory (GemmP::kwrap), fp32 C
+    if x3 or x2:
+        algorithmic = M * 2 * K * 2 + N * 2 * K * 2 + M * N * 4 + N * 4   # two bf16 planes (fp16x2: one fp16 + two FP8 planes) of A and of W in memory, fp32 C
     fetch_kb, write_kb = get("FETCH_SIZE"), get("WRITE_SIZE")
     traffic = (2.0 * fetch_kb + write_kb) * 1024.0
     gui = get("GRBM_GUI_ACTIVE")
     dur_ns = merged[(name, "SQ_WAVE_CYCLES")][2]
     out = {
-        "kernel": f"{name} (backbone QKV GEMM, M={M} K={3 * K if x3 else K} N={N}, {args.precision})",
+        "kernel": f"{name} (backbone QKV GEMM, M={M} K={3 * K if x3 else K} N={N}, {args.precision})" + (" - fp16x2: K fp16 + 2 K FP8 deep" if x2 else ""),
         "workload": [args.batch, args.shots, args.image_size, args.arch, args.precision],
         "source_hash": build.source_hash(),
         "command": "rocprofv3 --pmc <counters> --kernel-trace -- " + " ".join(bench_cmd[1:]).replace(ROOT + "/", ""),
