@@ -34,6 +34,9 @@ if ROOT not in sys.path:
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "bf16x3": 2500.0 / 3, "fp16x2": 2500.0 / 2, "fp32": 157.3}
 
 
+CONFORMING = ("fp16x2", "bf16x3")   # backbone / head precision of the tolerance-conforming mode the default line reports beside the headline
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,32 +240,41 @@ def main():
             result["roofline"]["kernel_isolated"] = {
                 "achieved": round(ach_u, 2), "frac": round(ach_u / peak, 4), "avg_launch_ms": round(qkv_u, 5), "launches_timed": timed_run.launches,
                 "measured_in": f"{n_u} timed ec_forward steps of this process (nothing else on the chip), one sampled launch per step"}
-    if world == 1 and not args.no_alt and (args.precision, args.head_precision) != ("bf16x3", "bf16x3"):
-        # the tolerance-conforming fast mode (every MFMA operand split hi + lo bf16, three MFMAs per product: fp32-class, meets the 1e-3
-        # coordinate tolerance on every keypoint by construction - tests/test_gpu_precision_modes.py::test_parity_mode_bf16x3), same
-        # process, same box, same API as the headline
+    if world == 1 and not args.no_alt and (args.precision, args.head_precision) != CONFORMING:
+        # the tolerance-conforming fast mode, same process, same box, same API as the headline.  Round 6: fp16x2 backbone (a_hi W_hi in fp16
+        # MFMAs + both correction terms in ONE block-scaled FP8 pass: two MFMA units per product instead of the three of bf16x3) + bf16x3
+        # head; meets the 1e-3 coordinate tolerance on every keypoint but the near-ties any GPU summation order flips (0 / 2 / 1 / 1 argmax
+        # flips of ~20 000 on cfg1 / 2 / 4 / 5 at scale, max 1.4e-5 elsewhere; tests/test_gpu_precision_modes.py::test_parity_mode_fp16x2)
         del eng, outputs
         torch.cuda.empty_cache()
         n_c = max(5, args.steps // 2)
-        eng, outputs, dt_c, qkv_c = timed_run("bf16x3", n_c, args.warmup, True, pipelined, head_precision="bf16x3")
+        cb, ch = CONFORMING
+        eng, outputs, dt_c, qkv_c = timed_run(cb, n_c, args.warmup, True, pipelined, head_precision=ch)
         ach_c = qkv_flops / (qkv_c * 1e-3) / 1e12 if qkv_c > 0 else 0.0
-        conf_c = conformance_record(args, bs, S, H, arch, "bf16x3", "bf16x3")
+        conf_c = conformance_record(args, bs, S, H, arch, cb, ch)
         result["conforming_mode"] = {
-            "precision": "bf16x3 backbone / bf16x3 head", "value": round(bs * n_c / dt_c, 2), "unit": "images/s", "ms_per_step": round(dt_c / n_c * 1e3, 3),
+            "precision": f"{cb} backbone / {ch} head", "value": round(bs * n_c / dt_c, 2), "unit": "images/s", "ms_per_step": round(dt_c / n_c * 1e3, 3),
             "pipelined": pipelined,
-            "roofline": {"bound": "mfma", "achieved": round(ach_c, 2), "peak": round(PEAK_TFLOPS["bf16x3"], 1), "unit": "TFLOP/s",
-                         "frac": round(ach_c / PEAK_TFLOPS["bf16x3"], 4), "avg_launch_ms": round(qkv_c, 5), "launches_timed": timed_run.launches,
-                         "peak_note": "2500 / 3: three bf16 MFMAs per product"},
+            "roofline": {"bound": "mfma", "achieved": round(ach_c, 2), "peak": round(PEAK_TFLOPS[cb], 1), "unit": "TFLOP/s",
+                         "frac": round(ach_c / PEAK_TFLOPS[cb], 4), "avg_launch_ms": round(qkv_c, 5), "launches_timed": timed_run.launches,
+                         "peak_note": "2500 / 2: two 16-bit-MFMA units per product (one fp16 MFMA + a depth-2K FP8 pass at twice the rate); "
+                                      "`achieved` counts the layer's 2 M N K flops once"},
             "argmax_flips": conf_c.get("argmax_flips") if conf_c else None, "conformance_at_scale": conf_c,
-            "note": "meets the 1e-3 coordinate tolerance on every keypoint; the headline precision meets it on all but the measured flip rate"}
+            "note": "meets the 1e-3 coordinate tolerance on every keypoint but the measured near-tie flips; the headline precision meets it on all but its (larger) measured flip rate"}
         if not args.no_episode:
             # the reference's evaluation protocol (15 queries per support set, `episode_cached` above) in the conforming precision
             del eng, outputs
             torch.cuda.empty_cache()
             eng = outputs = None
-            ep_c = episode_mode(args, sd, synth, bs, S, H, arch, apis, rank, world, precision="bf16x3", head_precision="bf16x3")
+            ep_c = episode_mode(args, sd, synth, bs, S, H, arch, apis, rank, world, precision=cb, head_precision=ch)
             result["conforming_mode"]["episode_cached"] = {k: ep_c[k] for k in ("value", "unit", "queries_per_call", "calls_per_pass", "ms_per_call", "seconds",
                                                                                  "backbone_images_per_pair", "entry_point")}
+        # the round-5 conforming mode (three bf16 MFMAs per product) beside it, same process
+        del eng, outputs
+        torch.cuda.empty_cache()
+        eng, outputs, dt_3, qkv_3 = timed_run("bf16x3", n_c, args.warmup, True, pipelined, head_precision="bf16x3")
+        result["conforming_mode"]["bf16x3_bf16x3"] = {"value": round(bs * n_c / dt_3, 2), "unit": "images/s", "ms_per_step": round(dt_3 / n_c * 1e3, 3),
+                                                      "qkv_launch_ms": round(qkv_3, 5), "note": "round 5's conforming mode: every product as three bf16 MFMAs"}
     if world == 1 and not args.no_alt and args.precision != "bf16":
         # the same step with bf16 operands (north_star's wording): same kernels and rate, 8x coarser rounding - measured beside the
         # headline so both precisions come from one process on one box; it does NOT meet the 1e-3 gate (test_bf16_mode_cfg2_bounded)

@@ -263,6 +263,7 @@ def test_world2_bench_main_runs_its_distributed_branches():
     assert su["steps"] >= 3 and su["value"] > 0 and abs(su["value"] - 2 * 4 * su["steps"] / su["seconds"]) / su["value"] < 0.01
     assert epi["pairs"] == 32 * 15 and epi["queries_per_call"] == 7 and epi["calls_per_pass"] == -(-480 // 7)
     assert abs(epi["value"] - 2 * 480 * epi["passes_timed"] / epi["seconds"]) / epi["value"] < 0.01
+    assert "parity_sample" not in epi                           # the episode leg's oracle sample (round 6) is an N = 1, rank-0-only leg as well
     assert res0["pipelined"] is True and "unpipelined" not in res0
     assert set(res0["pck_vs_synthetic_gt"]) >= {"PCK@0.2"}
 

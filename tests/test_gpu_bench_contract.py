@@ -82,7 +82,9 @@ def test_bench_unpipelined_flag_and_companion_run():
     assert r["kernel_isolated"]["frac"] > 0 and r["kernel_isolated"]["avg_launch_ms"] > 0
     assert d["value_reference_contract"] == d["unpipelined"]["value"]
     c = d["conforming_mode"]                                 # the tolerance-conforming mode, measured in the same process
-    assert c["value"] > 0 and c["roofline"]["peak"] < 834 and 0 < c["roofline"]["frac"] < 1 and c["precision"].startswith("bf16x3")
+    assert c["value"] > 0 and c["roofline"]["peak"] == 1250.0 and 0 < c["roofline"]["frac"] < 1 and c["precision"].startswith("fp16x2 backbone / bf16x3")
+    assert c["bf16x3_bf16x3"]["value"] > 0                   # round 5's conforming mode, measured beside it
+    assert c["value"] > 0.9 * c["bf16x3_bf16x3"]["value"]    # two MFMA units per product against three (this 8-image step is launch-bound: no more than a sanity bound)
     out = subprocess.run(base + ["--no-pipeline", "--no-alt"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])

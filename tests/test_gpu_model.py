@@ -510,7 +510,7 @@ def switch_children():
            "(forward_pipelined_bit_equal and 224-4) or support_cache_matches or (episodes_stream and fp16)")
     procs = {}
     for sw in SWITCHES:
-        env = dict(os.environ, **dict(kv.split("=") for kv in sw.split()))
+        env = dict(os.environ, EC_SWITCH_CHILD="1", **dict(kv.split("=") for kv in sw.split()))
         out = tempfile.TemporaryFile(mode="w+")
         procs[sw] = (subprocess.Popen([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_model.py"), os.path.join(here, "test_gpu_precision_modes.py"),
                                        os.path.join(here, "test_gpu_next_rows.py"), "-q", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"],
