@@ -14,7 +14,7 @@ from . import build as _build
 _LIB = None
 
 EC_F32, EC_BF16, EC_BF16X3, EC_F16, EC_MIXED, EC_F16X2 = 0, 1, 2, 3, 4, 5
-EC_ABI_VERSION = 5   # include/edgecape_hip.h EC_ABI_VERSION: bumped whenever a struct layout or a signature changes
+EC_ABI_VERSION = 6   # include/edgecape_hip.h EC_ABI_VERSION: bumped whenever a struct layout, an enum value, the entry points or a signature changes
 EC_DT_F32, EC_DT_F16, EC_DT_BF16, EC_DT_F64 = 0, 1, 2, 3
 EC_LAYOUT_TOKENS, EC_LAYOUT_NCHW = 0, 1
 

@@ -385,7 +385,7 @@ __device__ __forceinline__ f32x4 g8_mfma_f8(bf16x8 w0, bf16x8 w1, bf16x8 a0, bf1
 // The 16 (fp16) / 8 (FP8) MFMAs of one phase: accumulator quadrant acc[AO .. AO + 3][FO .. FO + 1], weight fragments BQ, activation fragments af
 #define G8_MM(AO, FO, BQ)                                                                                                           \
   do {                                                                                                                              \
-    if constexpr (f8) {                                                                                                             \
+    if constexpr (f8 && !(LAB & 32768)) {   /* lab, LAB & 32768: the FP8 K-tiles' MFMAs as fp16 ones (timing only: is it the FP8 MFMA?) */    \
       _Pragma("unroll") for (int fi = 0; fi < 4; ++fi)                                                                              \
         _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                               \
           acc[AO + fi][FO + f] = g8_mfma_f8(BQ[f][0], BQ[f][1], af[fi][0], af[fi][1], acc[AO + fi][FO + f], sca, scb);              \
@@ -859,7 +859,7 @@ G8Dev g8_dev[64];
 // Returns 1 if this kernel handled the problem, 0 if the shape is not eligible (caller falls back), <0 on error.
 int gemm8_bf16(const GemmP& p, hipStream_t st) {
   static const int disable = getenv("EC_GEMM8_OFF") ? atoi(getenv("EC_GEMM8_OFF")) : 0;
-  if (disable) return 0;
+  if (disable && !p.x2) return 0;   // (an A/B switch for the 16-bit GEMMs; fp16x2 operands have no other kernel)
   if (!p.ab_bf16 || p.batch != 1 || p.act == ACT_TANHGATE) return 0;
   // (fp16x2 operands: this kernel is their ONLY GEMM - any M, so that an image's features do not depend on the batch it rides in)
   if (p.K % 128 != 0 || p.N % 16 != 0 || (p.M < 1024 && !p.x2) || p.N < 256) return 0;
@@ -891,6 +891,17 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
     const long nt = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     GemmP q = p;
     if (nt <= ds.ncu || ds.ncu < 8 || p.x2 < 4 || k3 == 1) q.sched = nullptr;   // dynamic tile schedule: multi-round QKV / fc1 only (the hand-over spans three fp16 K-tiles)
+#ifdef EC_G8_LAB   // lab library only (tools/x2_lab.py): EC_X2_LAB_AS16=1 runs the FP8 K-tiles' MFMA blocks as fp16 MFMAs on the same bytes - wrong numbers, same stream
+    static const int as16 = getenv("EC_X2_LAB_AS16") ? atoi(getenv("EC_X2_LAB_AS16")) : 0;
+    if (as16) {
+      static const kern_t lab16[3] = {gemm8_bf16_kernel<G8_F32, 1, true, 32768, true>, gemm8_bf16_kernel<G8_RES_F32, 2, true, 32768, true>, gemm8_bf16_kernel<G8_GELU_X2, 3, true, 32768, true>};
+      static bool lab_attr = false;
+      if (!lab_attr) { for (int k = 0; k < 3; ++k) EC_HIP(hipFuncSetAttribute((const void*)lab16[k], hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS)); lab_attr = true; }
+      hipLaunchKernelGGL(lab16[k3], dim3((unsigned)(nt < ds.ncu ? nt : ds.ncu)), dim3(512), G8_LDS, st, q);
+      EC_LAUNCH_CHECK();
+      return 1;
+    }
+#endif
     hipLaunchKernelGGL(x2_table[k3][p.tag], dim3((unsigned)(nt < ds.ncu ? nt : ds.ncu)), dim3(512), G8_LDS, st, q);
     EC_LAUNCH_CHECK();
     return 1;

@@ -52,26 +52,32 @@ enum ec_status {
 enum ec_precision {
   EC_F32 = 0,     /* fp32 operands, exact products (v_mfma_f32_32x32x2_f32) */
   EC_BF16 = 1,    /* bf16 operands, fp32 accumulate */
-  EC_BF16X3 = 2,  /* fp32 data, each operand split into hi+lo bf16, 3 bf16 MFMAs per product: ~2^-17 relative.  The tolerance-conforming
-                     fast mode when used for backbone AND head (0 / 1 / 1 / 1 argmax flips of ~20 000 valid keypoints on cfg1 / 2 / 4 / 5,
-                     max |d kpt| <= 1.1e-5 otherwise; profiles/r05_conformance_*bf16x3*.json).  As a backbone precision (round 5) the
-                     block GEMMs run K-concatenated on the 16-bit 8-phase kernel: activations as bf16 [hi | lo] planes written by their
-                     producers, weights [W_hi | W_lo], one GEMM of depth 3 K per Linear */
+  EC_BF16X3 = 2,  /* fp32 data, each operand split into hi+lo bf16, 3 bf16 MFMAs per product: ~2^-17 relative.  Backbone AND head in this
+                     precision were the tolerance-conforming mode of rounds 2-5 (0 / 1 / 1 / 1 argmax flips of 19 288 / 20 293 / 19 699 /
+                     9 645 valid keypoints on cfg1 / 2 / 4 / 5, max |d kpt| <= 1.1e-5 otherwise; profiles/r05_conformance_*bf16x3*.json); as a
+                     HEAD precision it still is.  As a backbone precision the block GEMMs run K-concatenated on the 16-bit 8-phase
+                     kernel: activations as bf16 [hi | lo] planes written by their producers, weights [W_hi | W_lo], one GEMM of depth
+                     3 K per Linear.  (fp16 planes instead of bf16 ones were measured at scale in round 6 and not adopted:
+                     profiles/r06_conformance_fp16planes_*.json) */
   EC_F16 = 3,     /* IEEE fp16 operands (11 significand bits, same MFMA rate as bf16), fp32 accumulate: the backbone mode that
                      keeps output_kpts inside the 1e-3 tolerance at bf16 speed (backbone only) */
   EC_MIXED = 4,   /* head only: EC_BF16X3 everywhere the proposal generator's argmax depends on (input projections, support pooling,
                      encoder, proposal generator - encoder_decoder.py:91-110 is the path's one discontinuity) and in the small MLPs;
                      single-pass fp16 MFMAs (fp32 data rounded to fp16 operands, fp32 accumulate) in the Linear layers AND the
                      attentions of the skeleton head (skeleton.py:58-161) and of the decoder layers (encoder_decoder.py:584-651),
-                     whose image K|V are also stored as fp16 - all of which only move the output continuously: with the fp16 backbone,
-                     max |d kpt| on flip-free samples 2.0e-4 (cfg2) / 2.4e-4 (ViT-S/14 @ 224) over 512 disjoint pairs each, 12 / 11 argmax
-                     flips of ~20 000 valid keypoints (profiles/r04_conformance_*.json) */
+                     whose image K|V are also stored as fp16 - all of which only move the output continuously.  With the fp16 backbone
+                     (bench.py's default): 11 / 12 / 17 / 14 argmax flips of 19 288 / 20 293 / 19 699 / 9 645 valid keypoints on cfg1 / 2 /
+                     4 / 5 (512 / 512 / 512 / 256 disjoint pairs), max |d kpt| on flip-free samples 2.4e-4 / 2.0e-4 / 1.6e-4 / 1.6e-4
+                     (profiles/r05_conformance_*fp16_mixed.json, re-measured as r06_conformance_*fp16_mixed.json) */
   EC_F16X2 = 5    /* backbone only (round 6): fp32 data, TWO MFMA units per product instead of the three of EC_BF16X3 -
                      a W ~ a_hi W_hi in fp16 MFMAs plus BOTH correction terms a_lo W_hi + a_hi W_lo in ONE block-scaled FP8 pass
                      (v_mfma_scale_f32_16x16x128_f8f6f4: activations e5m2 with fixed power-of-two scales, weights e4m3 with one static
                      scale per tensor and plane), ~2^-14 relative.  Rows of K values travel as [K x fp16 | K x e5m2 | K x e5m2] (4 K
                      bytes), written by their producers (LayerNorm, attention, the fc1 epilogue).  Needs embed_dim % 128 == 0.  Its GEMMs
-                     run on ONE kernel whatever the batch, so an image's features do not depend on the batch it rides in */
+                     run on ONE kernel whatever the batch, so an image's features do not depend on the batch it rides in.  With the
+                     EC_BF16X3 head this is the tolerance-conforming fast mode since round 6: 0 / 2 / 1 / 1 argmax flips of ~20 000 valid
+                     keypoints on cfg1 / 2 / 4 / 5 at scale, 1 on planted activation outliers, max |d kpt| <= 2.2e-5 on every flip-free
+                     sample (profiles/r06_conformance_*fp16x2_bf16x3.json), at ~1.2 x the pairs/s of EC_BF16X3 / EC_BF16X3 */
 };
 enum ec_dtype { EC_DT_F32 = 0, EC_DT_F16 = 1, EC_DT_BF16 = 2, EC_DT_F64 = 3 };
 enum ec_layout { EC_LAYOUT_TOKENS = 0, EC_LAYOUT_NCHW = 1 };
@@ -120,7 +126,7 @@ typedef struct ec_outputs {
 const char* ec_last_error(void);
 /* ABI version of the library (EC_ABI_VERSION of the header it was built from): bumped whenever a struct layout, an enum value, the set of entry points
    or a signature changes, so a binding can refuse a stale prebuilt library instead of calling it with mismatched layouts. */
-#define EC_ABI_VERSION 5
+#define EC_ABI_VERSION 6   /* 6 (round 6): ec_precision EC_F16X2, ec_op_linear_x2 */
 int ec_version(void);
 /* sizeof(ec_config) / sizeof(ec_outputs) as the library was compiled: a binding compares them with its own mirrors. */
 int ec_abi_sizes(int* config_bytes, int* outputs_bytes);

@@ -654,3 +654,33 @@ def test_linear_x2_output_kinds(lib, M, N, K, kind):
     rel = ((got - exact).abs() / scale)
     print(f"fp16x2 {M}x{N}x{K} {kind}: |got - exact| / (|a|.|w|) max {float(rel.max()):.2e} rms {float((rel ** 2).mean().sqrt()):.2e}; vs emulation max {float((err_emu / scale).max()):.2e}")
     assert float(rel.max()) < 2.0 ** -13 and float((rel ** 2).mean().sqrt()) < 2.0 ** -16
+
+
+def test_linear_x2_nan_inf_and_saturation(lib):
+    """fp16x2 operands keep the fp16 mode's contract for non-finite and out-of-range activations: a NaN activation makes its output row
+    NaN (the fp16 plane carries it; the e5m2 planes are clamped finite), an infinite one makes it non-finite, a finite activation beyond
+    the fp16 range saturates at +-65504 in the fp16 plane (and at +-57344 / +-28 in the e5m2 planes) instead of becoming inf - every
+    other row is untouched."""
+    M, N, K = 1300, 384, 384
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn(M, K, generator=g)
+    A[7, 5] = float("nan")
+    A[300, 9] = float("inf")
+    A[900, 3] = 1.0e6                                             # saturates: the row stays finite
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    C_ = torch.empty(M, N, device="cuda")
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()                     # (kept alive: a temporary's block goes back to the caching allocator at once)
+    _chk(lib, lib.ec_op_linear_x2(_p(Ad), _p(Wd), _p(bd), None, _p(C_), None, M, N, K, 0, 1, None, None))
+    torch.cuda.synchronize()
+    got = C_.cpu()
+    assert torch.isnan(got[7]).all()
+    assert not torch.isfinite(got[300]).any()
+    assert torch.isfinite(got[900]).all()
+    As = A.clone(); As[900, 3] = 65504.0
+    ok = torch.ones(M, dtype=torch.bool); ok[[7, 300]] = False
+    ref = (As[ok].double() @ W.double().T + b.double())
+    err = (got[ok].double() - ref).abs()
+    scale = As[ok].double().abs() @ W.double().abs().T
+    assert (err <= scale * 2.0 ** -9).all()                       # (the saturated value's e5m2 copies are clamped: its correction terms are coarse)
+    assert torch.isfinite(got[ok]).all()

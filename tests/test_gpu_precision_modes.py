@@ -487,6 +487,23 @@ def test_headline_conformance_at_scale(name):
     assert g["flips_caught"] == g["flips"] and g["sample_frac"] > 0.25, g
 
 
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg4", "cfg5"])
+def test_conforming_mode_at_scale(name):
+    """fp16x2 backbone + bf16x3 head (the conforming mode, round 6) on the SAME disjoint pairs as test_headline_conformance_at_scale (the
+    oracle's answers come from the cache that test filled).  Full-scale records (profiles/r06_conformance_*fp16x2_bf16x3.json, 512 / 512 /
+    512 / 256 pairs): 0 / 2 / 1 / 1 argmax flips of 19 288 / 20 293 / 19 699 / 9 645 valid keypoints - near-ties with top-2 gaps of ~2e-5 in a
+    map of scale ~45, of which the EXACT fp32-MFMA mode flips one as well - and max |d kpt| 1.0e-5 .. 1.4e-5 on the flip-free samples.
+    Gates: every flip-free sample 20 x inside the tolerance; at most the handful of near-tie flips the records show."""
+    o = AT_SCALE[name]
+    per_seed, pooled = conformance_at_scale(n_batches=o["n_batches"], backbone="fp16x2", head="bf16x3", name=name)
+    print("conformance fp16x2/bf16x3", name, {k: v for k, v in pooled.items() if k != "near_tie_guard"})
+    assert pooled["pairs"] == o["pairs"]
+    assert pooled["flips"] <= 2, pooled
+    assert pooled["max_clean"] < 5e-5 and pooled["p99"] < 2e-5 and pooled["median"] < 1e-6, pooled
+    assert pooled["pairs"] - pooled["clean_samples"] <= 2
+    assert pooled["pck_vs_oracle"] >= 1.0 - 2.0 * 45 / o["n_valid"], pooled
+
+
 def test_fp16_backbone_on_outlier_activation_statistics():
     """Model-level evidence that the fp16 backbone survives the activation statistics of released DINOv2 checkpoints (VERDICT r3
     missing item 5; the checkpoints are unreachable offline, so the statistics are planted into random-init weights by
