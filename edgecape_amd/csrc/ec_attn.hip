@@ -760,7 +760,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
           f32x4 v;
           v[0] = ot[d][4 * g] * inv; v[1] = ot[d][4 * g + 1] * inv; v[2] = ot[d][4 * g + 2] * inv; v[3] = ot[d][4 * g + 3] * inv;
           u32x2_t vh, vl;
-          if (p.o_x3 == 2) split4_h<true>(v, vh, vl); else split4_bf16(v, vh, vl);
+          split4_bf16(v, vh, vl);
           bf16_t* o = O + d * 32 + 8 * g + 4 * hi;
           *(u32x2_t*)o = vh;
           *(u32x2_t*)(o + plane) = vl;

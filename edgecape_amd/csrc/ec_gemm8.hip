@@ -915,7 +915,7 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
   } else if (p.table && !p.resid && !p.gamma && !p.aux && p.act == ACT_NONE && p.period > 0 && p.ldt % 4 == 0 && p.ldc % 4 == 0 &&
              (long)p.M * p.ldc * (p.c_bf16 ? 2 : 4) < (1l << 31)) {
     kind = p.c_bf16 ? G8_TAB_H16 : G8_TAB_F32;   // (the A/B switch back to the generic epilogue, EC_G8_TAB, went in round 5)
-  } else if (p.c_x3 && p.bias && p.act == ACT_GELU && !p.gamma && !p.resid && !p.table && (long)p.M * p.ldc * 2 < (1l << 31)) {
+  } else if (p.c_x3 && !p.h_f16 && p.bias && p.act == ACT_GELU && !p.gamma && !p.resid && !p.table && (long)p.M * p.ldc * 2 < (1l << 31)) {
     kind = G8_GELU_X3;
   } else if (!p.c_bf16 && !p.c_x3 && p.bias && !p.table && !p.aux && p.act == ACT_NONE && p.ldc % 4 == 0 && (long)p.M * p.ldc * 4 < (1l << 31)) {
     // (measured against the generic epilogue behind a switch that is gone again, cfg2 bf16x3 / bf16x3, interleaved on one box:
@@ -933,7 +933,7 @@ int gemm8_bf16(const GemmP& p, hipStream_t st) {
       {gemm8_bf16_kernel<5, 0, F>, gemm8_bf16_kernel<5, 0, F>, gemm8_bf16_kernel<5, 0, F>, gemm8_bf16_kernel<5, 0, F>, gemm8_bf16_kernel<5, 0, F>}, \
       {gemm8_bf16_kernel<6, 0, F>, gemm8_bf16_kernel<6, 1, F>, gemm8_bf16_kernel<6, 0, F>, gemm8_bf16_kernel<6, 0, F>, gemm8_bf16_kernel<6, 0, F>}, \
       {gemm8_bf16_kernel<7, 0, F>, gemm8_bf16_kernel<7, 0, F>, gemm8_bf16_kernel<7, 2, F>, gemm8_bf16_kernel<7, 0, F>, gemm8_bf16_kernel<7, 4, F>}, \
-      {gemm8_bf16_kernel<8, 3, F>, gemm8_bf16_kernel<8, 3, F>, gemm8_bf16_kernel<8, 3, F>, gemm8_bf16_kernel<8, 3, F>, gemm8_bf16_kernel<8, 3, F>}
+      {gemm8_bf16_kernel<8, 3, false>, gemm8_bf16_kernel<8, 3, false>, gemm8_bf16_kernel<8, 3, false>, gemm8_bf16_kernel<8, 3, false>, gemm8_bf16_kernel<8, 3, false>}
   static const kern_t table[2][9][5] = {{G8_ROW(false)}, {G8_ROW(true)}};
 #undef G8_ROW
   if (!ds.attr_done) {

@@ -90,7 +90,7 @@ struct ec_model {
   bool bb_split = false;     // EC_BF16X3 backbone: fp32 activations, every MFMA operand split hi+lo bf16 (3 MFMAs per product)
   bool bb_x3 = false;        // ... its block GEMMs in the K-CONCATENATED form on the 8-phase 16-bit kernel (run_backbone); EC_BB_X3=0: A/B
   bool bb_x3_f16 = false;    // ... over IEEE fp16 planes (22 significand bits per operand) instead of bf16 planes (16): the fp16x2 mode's patch
-                             // embedding; for the bf16x3 mode itself only behind EC_X3_F16=1 (measured at scale, not adopted)
+                             // embedding (for the bf16x3 mode itself: measured at scale in round 6, not adopted)
   bool bb_x2 = false;        // EC_F16X2 backbone: the block GEMMs on fp16x2 operands (ec_common.h split4_x2; two MFMA units per product); the
                              // rest as the fp16-planes bf16x3 form (fp32 residual stream, split attention, fp16x3 patch embedding)
   bool head_split = false;   // head GEMMs in bf16x3 (ec_gemm.hip GM_SPLIT)
@@ -644,15 +644,15 @@ static int run_backbone(ec_model* m, const float* const* imgs, const int* counts
   int* const sched = (m->g8_dyn_mode == 1 || (m->g8_dyn_mode == 2 && m->dq_active)) ? m->g8_sched : nullptr;
   for (size_t i = 0; i < m->blocks.size(); ++i) {
     const BBlock& b = m->blocks[i];
-    const bool x3 = m->bb_x3, xf = m->bb_x3_f16, x2 = m->bb_x2;
-    RUN(ln(m->bb_x, C, m->bb_xn, x3 ? 2 * C : C, x2 ? 6 : x3 ? (xf ? 5 : 3) : hfmt, b.n1, (int)M, C, 1e-6f, st, 0, pend, C, pend2));
+    const bool x3 = m->bb_x3, x2 = m->bb_x2;
+    RUN(ln(m->bb_x, C, m->bb_xn, x3 ? 2 * C : C, x2 ? 6 : x3 ? 3 : hfmt, b.n1, (int)M, C, 1e-6f, st, 0, pend, C, pend2));
     pend = pend2 = nullptr;
     const bool prof = m->prof_on && (m->prof_mode != 2 || i == m->prof_pass % m->blocks.size()) && m->prof_used + 2 <= m->prof_ev.size();
     if (prof) EC_HIP(hipEventRecord(m->prof_ev[m->prof_used++], st));
     if (x2) {
       RUN(linear_x2(m->bb_xn, b.qkv, m->bb_qkv, 3 * C, false, (int)M, ACT_NONE, st, nullptr, nullptr, 0, 1, sched));
     } else if (x3) {
-      RUN(linear_x3(m->bb_xn, b.qkv, m->bb_qkv, 3 * C, false, (int)M, ACT_NONE, st, nullptr, nullptr, 0, 1, xf));
+      RUN(linear_x3(m->bb_xn, b.qkv, m->bb_qkv, 3 * C, false, (int)M, ACT_NONE, st, nullptr, nullptr, 0, 1, false));
     } else {
       GemmP p;
       p.tag = 1;
@@ -672,7 +672,7 @@ static int run_backbone(ec_model* m, const float* const* imgs, const int* counts
     a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
     a.sQ = a.sK = a.sV = (long)T * 3 * C; a.sO = (long)T * C;
     a.B = n; a.H = nh; a.Lq = T; a.Lk = T; a.hd = C / nh; a.bf16 = h16; a.f16 = m->bbf16; a.split = m->bb_split ? 1 : 0;
-    if (x3) { a.o_x3 = x2 ? 3 : xf ? 2 : 1; a.ldo = 2 * C; a.sO = (long)T * 2 * C; }
+    if (x3) { a.o_x3 = x2 ? 3 : 1; a.ldo = 2 * C; a.sO = (long)T * 2 * C; }
     RUN(attention(a, st));
     if (x2) {
       // fp16x2 (round 6): the same four launches on fp16x2 operands - a_hi W_hi in fp16 MFMAs, both correction terms in one FP8 pass
@@ -685,10 +685,10 @@ static int run_backbone(ec_model* m, const float* const* imgs, const int* counts
       // [hi | lo] planes written by their producers (LayerNorm, attention, the fc1 epilogue) and walked hi | lo | hi by the load stream,
       // weights [W_hi | W_lo] walked hi | hi | lo (GemmP::kwrap) - with the fp32 epilogue of the exact mode (residual added in place);
       // the same three products per multiply as the split-on-load kernel
-      RUN(linear_x3(m->bb_att, b.proj, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls1, m->bb_x, C, 2, xf));
-      RUN(ln(m->bb_x, C, m->bb_xn, 2 * C, xf ? 5 : 3, b.n2, (int)M, C, 1e-6f, st));
-      RUN(linear_x3(m->bb_xn, b.fc1, m->bb_h, 8 * C, true, (int)M, ACT_GELU, st, nullptr, nullptr, 0, 3, xf));
-      RUN(linear_x3(m->bb_h, b.fc2, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls2, m->bb_x, C, 4, xf));
+      RUN(linear_x3(m->bb_att, b.proj, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls1, m->bb_x, C, 2, false));
+      RUN(ln(m->bb_x, C, m->bb_xn, 2 * C, 3, b.n2, (int)M, C, 1e-6f, st));
+      RUN(linear_x3(m->bb_xn, b.fc1, m->bb_h, 8 * C, true, (int)M, ACT_GELU, st, nullptr, nullptr, 0, 3, false));
+      RUN(linear_x3(m->bb_h, b.fc2, m->bb_x, C, false, (int)M, ACT_NONE, st, b.ls2, m->bb_x, C, 4, false));
     } else if (h16) {
       RUN(linear(m->bb_att, C, true, b.proj, m->bb_y, C, true, (int)M, ACT_NONE, st, b.ls1, nullptr, 0, nullptr, 0, 1, nullptr, 0, 2));
       RUN(ln(m->bb_x, C, m->bb_xn, C, hfmt, b.n2, (int)M, C, 1e-6f, st, 0, m->bb_y, C, nullptr, false));
@@ -1788,8 +1788,8 @@ int ec_create(const ec_config* cfg, ec_handle* out) {
   m->bb_x3 = m->bb_split && cfg->embed_dim % 128 == 0 && (m->bb_x2 || !(getenv("EC_BB_X3") && atoi(getenv("EC_BB_X3")) == 0));
   // fp16 planes for the bf16x3 mode itself (three fp16 MFMAs per product) were measured at scale in round 6 and NOT adopted
   // (profiles/r06_conformance_fp16planes_*.json: 0 / 0 / 2 / 1 argmax flips on cfg1 / 2 / 4 / 5 against 0 / 1 / 1 / 1 with bf16 planes, -2.4 %
-  // pairs/s); the plane format lives on as the fp16x2 mode's patch embedding (EC_X3_F16=1: the bf16x3 mode on fp16 planes, for A/B)
-  m->bb_x3_f16 = m->bb_x3 && (m->bb_x2 || (getenv("EC_X3_F16") && atoi(getenv("EC_X3_F16")) != 0));
+  // pairs/s); the plane format lives on as the fp16x2 mode's patch embedding
+  m->bb_x3_f16 = m->bb_x2;
   m->bb16 = cfg->backbone_precision == EC_BF16 || cfg->backbone_precision == EC_F16;
   m->bbf16 = cfg->backbone_precision == EC_F16;
   m->head_split = cfg->head_precision == EC_BF16X3 || cfg->head_precision == EC_MIXED;

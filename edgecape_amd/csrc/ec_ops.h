@@ -10,7 +10,7 @@ namespace ec {
 // Optional second output y2 (fp32) = y + table[row % period2] (encoder: `src + pos` of the NEXT layer).
 struct LnP {
   const float* x = nullptr; long ldx = 0;
-  void* y = nullptr; long ldy = 0; int y_bf16 = 0;   // output format: 0 fp32, 1 bf16, 2 IEEE fp16, 3 bf16 split [hi | lo] (planes cols apart), 5 fp16 split, 6 fp16x2 row
+  void* y = nullptr; long ldy = 0; int y_bf16 = 0;   // output format: 0 fp32, 1 bf16, 2 IEEE fp16, 3 bf16 split [hi | lo] (planes cols apart), 6 fp16x2 row
   const float* w = nullptr; const float* b = nullptr;
   int rows = 0, cols = 0; float eps = 1e-5f;
   int drop_period = 0;

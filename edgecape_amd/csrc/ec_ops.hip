@@ -13,7 +13,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // OUT: 0 = fp32 output, 1 = bf16, 2 = IEEE fp16 (the fused branch inputs `add` / `add2` are in the same 16-bit format),
 //      3 = bf16 split [hi | lo] in two planes `cols` elements apart (ldy >= 2 cols): the A operand of a K-concatenated bf16x3 GEMM
-//      5 = the same in IEEE fp16 planes; 6 = the fp16x2 row [fp16 | e5m2 lo8 | e5m2 hi8] (ldy >= 2 cols 16-bit units; split4_x2)
+//      6 = the fp16x2 row [fp16 | e5m2 lo8 | e5m2 hi8] (ldy >= 2 cols 16-bit units; split4_x2)
 template <int OUT, bool ADD, bool ADD_F16 = (OUT == 2)>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnP p) {
   constexpr bool OUT_BF16 = OUT != 0;
@@ -80,10 +80,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnP p) {
         *(u32x2_t*)(y + c * 2) = hi;
         *(unsigned*)(y + 2 * p.cols + c) = lo8;
         *(unsigned*)(y + 3 * p.cols + c) = hi8;
-      } else if constexpr (OUT == 3 || OUT == 5) {
+      } else if constexpr (OUT == 3) {
         bf16_t* y = (bf16_t*)p.y + orow * p.ldy + c;
         u32x2_t hi, lo;
-        split4_h<OUT == 5>(o, hi, lo);
+        split4_bf16(o, hi, lo);
         *(u32x2_t*)y = hi;
         *(u32x2_t*)(y + p.cols) = lo;
       } else if (OUT_BF16) {
@@ -815,10 +815,9 @@ int layernorm(const LnP& p, hipStream_t st) {
   // y_bf16: 0 fp32, 1 bf16, 2 fp16 output; a fused branch add is 16-bit in add_fmt's format (defaults to the output's, bf16 if fp32)
   const int afmt = p.add_fmt ? p.add_fmt : (p.y_bf16 ? p.y_bf16 : 1);
   EC_REQUIRE(!p.add || p.y_bf16 == 0 || afmt == p.y_bf16, -1, "layernorm: fused add and output must share the 16-bit format");
-  if (p.y_bf16 == 3 || p.y_bf16 == 5 || p.y_bf16 == 6) {
+  if (p.y_bf16 == 3 || p.y_bf16 == 6) {
     EC_REQUIRE(!p.add && p.ldy >= 2 * (long)p.cols, -1, "layernorm: split output takes no fused add and needs ldy >= 2 cols");
     if (p.y_bf16 == 6) hipLaunchKernelGGL((layernorm_kernel<6, false, false>), grid, dim3(256), 0, st, p);
-    else if (p.y_bf16 == 5) hipLaunchKernelGGL((layernorm_kernel<5, false, false>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((layernorm_kernel<3, false>), grid, dim3(256), 0, st, p);
   } else if (p.add) {
     if (p.y_bf16 == 2) hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, dim3(256), 0, st, p);
