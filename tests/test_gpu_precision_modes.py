@@ -186,7 +186,7 @@ def episode_call_size(name, qpe=15):
     return max(1, (1 + c["S"]) * c["bs"] * qpe // (qpe + c["S"]))
 
 
-def conformance_episodes(n_ep=17, wseeds=(0, 1), backbone="fp16", head="mixed", name="cfg2", qpe=15, pipelined=True, outliers=False):
+def conformance_episodes(n_ep=17, wseeds=(0, 1), backbone="fp16", head="mixed", name="cfg2", qpe=15, pipelined=True, outliers=False, also_pairwise=False):
     """A precision mode against the oracle through ec_forward_episodes - the entry point of the reference's evaluation protocol (15 queries
     per support set, test_dataset.py:86-99) - at the call size bench.py's `episode_cached` leg uses: n_ep episodes per weight seed
     (17 x 15 = 255 pairs) streamed in calls of episode_call_size() queries, the support sets of the episodes that start in a call riding
@@ -218,10 +218,28 @@ def conformance_episodes(n_ep=17, wseeds=(0, 1), backbone="fp16", head="mixed", 
         got = dict(output_kpts=np.concatenate([o["output_kpts"].cpu().numpy() for o in res], 1),
                    similarity_map=np.concatenate([o["similarity_map"].cpu().numpy() for o in res], 0),
                    adj=np.concatenate([o["adj"].cpu().numpy() for o in res], 0))
-        del eng, cache, res
+        del cache, res
         valid = (mask[:, :, 0] > 0)[ep]
         st = stats(got, ref, valid, c["H"])
         st["weight_seed"], st["pairs"], st["episodes"] = ws, int(valid.shape[0]), n_ep
+        if also_pairwise:
+            # the SAME expanded pairs through the pairwise entry point (ec_forward, batches of q): is a flip the data's (a near-tie of this
+            # pair) or the entry point's?
+            outs = []
+            for i0 in range(0, len(ep), q):
+                idx = np.arange(i0, min(i0 + q, len(ep)))
+                e = ep[idx]
+                o = eng.forward(img_q[idx], [x[e] for x in sup["img_s"]], [x[e] for x in sup["target_s"]], mask[e], [skels[j] for j in e])
+                torch.cuda.synchronize()
+                outs.append({k: o[k].cpu().numpy() for k in ORACLE_KEYS})
+            gp = dict(output_kpts=np.concatenate([o["output_kpts"] for o in outs], 1), similarity_map=np.concatenate([o["similarity_map"] for o in outs], 0),
+                      adj=np.concatenate([o["adj"] for o in outs], 0))
+            sp = stats(gp, ref, valid, c["H"])
+            am = lambda t: t["similarity_map"].reshape(valid.shape[0], valid.shape[1], -1).argmax(-1)
+            fe, fp_ = (am(got) != am(ref)) & valid, (am(gp) != am(ref)) & valid
+            st["pairwise_same_pairs"] = dict(flips=sp["flips"], max_clean=sp["max_clean"], p99=sp["p99"], flips_in_both=int((fe & fp_).sum()),
+                                             flips_only_episodes=int((fe & ~fp_).sum()), flips_only_pairwise=int((~fe & fp_).sum()))
+        del eng
         per_seed.append(st)
         pg.append(got); pr.append(ref); pv.append(valid)
     cat = lambda L, k, ax: np.concatenate([x[k] for x in L], ax)
@@ -230,6 +248,9 @@ def conformance_episodes(n_ep=17, wseeds=(0, 1), backbone="fp16", head="mixed", 
                    np.concatenate(pv, 0), c["H"])
     pooled["pairs"] = int(sum(v.shape[0] for v in pv))
     pooled["queries_per_call"], pooled["queries_per_episode"], pooled["cache_slots"] = q, qpe, cap
+    if also_pairwise:
+        pooled["pairwise_same_pairs"] = {k: (max if k in ("max_clean", "p99") else sum)(st["pairwise_same_pairs"][k] for st in per_seed)
+                                         for k in per_seed[0]["pairwise_same_pairs"]}
     return per_seed, pooled
 
 

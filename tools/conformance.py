@@ -23,11 +23,12 @@ ap.add_argument("--outliers", action="store_true", help="weights with planted DI
 ap.add_argument("--episodes", type=int, default=0,
                 help="N > 0: the reference's evaluation PROTOCOL instead of pairwise batches - N episodes of 15 queries per weight seed streamed through "
                      "ec_forward_episodes in calls sized like bench.py's episode leg (tests/test_gpu_precision_modes.py conformance_episodes)")
+ap.add_argument("--also-pairwise", action="store_true", help="with --episodes: the same expanded pairs through ec_forward as well (whose flips are the data's?)")
 ap.add_argument("--out", default=None)
 a = ap.parse_args()
 c = T.CFG[a.config]
 if a.episodes:
-    per_seed, pooled = T.conformance_episodes(a.episodes, tuple(int(x) for x in a.seeds.split(",")), a.backbone, a.head, a.config, outliers=a.outliers)
+    per_seed, pooled = T.conformance_episodes(a.episodes, tuple(int(x) for x in a.seeds.split(",")), a.backbone, a.head, a.config, outliers=a.outliers, also_pairwise=a.also_pairwise)
     what = (f"{a.config}: {c['S']}-shot, {c['H']}x{c['H']}, {c['arch']}; {a.episodes} episodes x 15 queries per weight seed through ec_forward_episodes (pipelined), "
             f"{pooled['queries_per_call']} queries per call + the support images of the episodes that start in it")
 else:
