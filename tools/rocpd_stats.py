@@ -10,9 +10,10 @@ import sys
 
 
 def step_starts(rows):
-    """indices of the launches that open a step / call: its im2col launches (one per image source, back to back on the caller's stream)"""
+    """indices of the launches that open a step / call: its im2col launches (one per image source, back to back on the caller's stream -
+    kernels of OTHER streams, the previous step's deferred head, may lie between them in the trace and do not split the group)"""
     idx = [i for i, r in enumerate(rows) if "im2col" in r[0]]
-    return [i for j, i in enumerate(idx) if j == 0 or not all("im2col" in rows[x][0] for x in range(idx[j - 1], i))]
+    return [i for j, i in enumerate(idx) if j == 0 or not all("im2col" in rows[x][0] or rows[x][3] != rows[i][3] for x in range(idx[j - 1], i))]
 
 
 def main(db_path, out_path=None, last_steps=0):
@@ -23,14 +24,14 @@ def main(db_path, out_path=None, last_steps=0):
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else "kernel_name"
-    rows = cur.execute(f"select {name_col}, start, end from kernels order by start").fetchall()
+    rows = cur.execute(f"select {name_col}, start, end, stream_id from kernels order by start").fetchall()
     if last_steps > 0:
         st = step_starts(rows)
         if len(st) < last_steps:
             raise SystemExit(f"trace holds {len(st)} steps, {last_steps} asked for")
         rows = rows[st[-last_steps]:]
     agg = {}
-    for name, s, e in rows:
+    for name, s, e, _ in rows:
         d = e - s
         a = agg.setdefault(name, [0, 0, 1 << 62, 0])
         a[0] += 1
