@@ -180,9 +180,12 @@ def test_backbone_vs_hf_golden(arch, image_size):
     assert np.abs(tok.mean(0) - gold["feat_mean"]).max() < 3e-4
 
 
+@pytest.mark.parametrize("prec", ["fp32/fp32", "fp16x2/bf16x3"])
 @pytest.mark.parametrize("name", ["det_vits14_224_s1", "det_vits14_224_s5", "det_vits14_229x311_s2"])
-def test_forward_test_vs_reference_golden(name):
-    """Whole `model(..., return_loss=False)` through the reference-shaped Python face."""
+def test_forward_test_vs_reference_golden(name, prec):
+    """Whole `model(..., return_loss=False)` through the reference-shaped Python face, against the outputs of the REAL reference detector
+    (oracle/make_golden.py): the exact engine, and the tolerance-conforming fast mode (fp16x2 backbone + bf16x3 head, round 6) at the same
+    1e-3 tolerance."""
     from edgecape_amd import Config  # noqa: F401
     from edgecape_amd.detector import EdgeCape, hip_library_loaded
     gold, meta = load_golden(name)
@@ -200,7 +203,7 @@ def test_forward_test_vs_reference_golden(name):
                     skeleton_head=dict(type="SkeletonPredictor", learn_skeleton=True), learn_skeleton=True,
                     masked_supervision=True, masking_ratio=0.5, model_freeze="skeleton")
     model = EdgeCape(keypoint_head=head_cfg, encoder_config=dict(), train_cfg=dict(), test_cfg=dict(flip_test=False),
-                     pretrained=arch)
+                     pretrained=arch, backbone_precision=prec.split("/")[0], head_precision=prec.split("/")[1])
     model.load_state_dict(sd)
     model.eval()
     t = lambda x: torch.from_numpy(x)
@@ -210,7 +213,7 @@ def test_forward_test_vs_reference_golden(name):
     assert hip_library_loaded()
     valid = batch["target_weight_s"][0][:, :, 0] > 0
     ep = np.abs(res["points"] - gold["points"])
-    print(name, "points err valid", ep[:, valid].max(), "all", ep.max(), "skeleton", np.abs(res["skeleton"] - gold["skeleton"]).max())
+    print(name, prec, "points err valid", ep[:, valid].max(), "all", ep.max(), "skeleton", np.abs(res["skeleton"] - gold["skeleton"]).max())
     assert ep[:, valid].max() < 1e-3                      # north star: 1e-3 abs on normalised coordinates
     assert np.abs(res["skeleton"] - gold["skeleton"]).max() < 1e-4
     assert np.abs(res["preds"] - gold["preds"])[valid].max() < 0.4   # pixels: 1e-3 * 224 (311) * 1.25
