@@ -17,6 +17,7 @@ Schemes (oracle/correction_terms_study.py has the others):
              power-of-two scale per tensor and plane (known at ec_finalize).  2 MFMA units per product.
   fp16x2e4   the same with e4m3 activations under a per-row dynamic scale (what a block-scaled producer could do at best)
   fp16x25    a_hi W_hi + q5(a_lo) q4(W_hi)  [FP8]  + a_hi W_lo16 [fp16 MFMA]: 2.5 units
+  fp16x15e2m3 / fp16x15e3m2   (round 6, a LEAD, nothing built) both correction terms in MX FP6 under block-32 scales: 1.5 units
     python oracle/x2_at_scale.py --config cfg2 --batches 8 --seeds 0,1 --schemes bf16x3,fp16x2 --out profiles/r06_x2_emulation_cfg2.json
 """
 import argparse
@@ -60,6 +61,25 @@ def w_planes(w):
     return wh, out[0], out[1], wl
 
 
+def q6(x, fmt, block=32):
+    """MX FP6 along the last (K) axis: one power-of-two scale per `block` elements that puts the block's largest magnitude into the format's top
+    binade, elements rounded to nearest even on the format's grid, saturating.
+    e2m3: 1 + 2 + 3 bits, bias 1, values {0, 0.125 .. 0.875 (subnormal), 1 .. 7.5}; e3m2: 1 + 3 + 2 bits, bias 3, max 28.  De-quantised (exact in fp32)."""
+    mant, emax, fmax, emin = {"e2m3": (3, 2, 7.5, 0), "e3m2": (2, 4, 28.0, -2)}[fmt]
+    K = x.shape[-1]
+    pad = (-K) % block
+    xp = F.pad(x, (0, pad)) if pad else x
+    xb = xp.reshape(*xp.shape[:-1], -1, block)
+    amax = xb.abs().amax(-1, keepdim=True).clamp_min(2.0 ** -100)
+    scale = torch.exp2(torch.floor(torch.log2(amax)) - emax)
+    v = (xb / scale).clamp(-fmax, fmax)
+    e = torch.floor(torch.log2(v.abs().clamp_min(2.0 ** -40))).clamp_min(float(emin))      # binade of the element (subnormals share the lowest one)
+    step = torch.exp2(e - mant)
+    y = (torch.round(v / step) * step).clamp(-fmax, fmax) * scale                          # (round half to even: torch.round)
+    y = y.reshape(xp.shape)
+    return y[..., :K] if pad else y
+
+
 _wcache = {}
 
 
@@ -78,6 +98,11 @@ def linear_x2(a, w, b, scheme, key):
             s = torch.exp2(torch.floor(torch.log2(E4MAX / amax)))
             return q4(t * s) / s
         y = y + F.linear(rowq(al), wh8) + F.linear(rowq(a), wl8)
+    elif scheme in ("fp16x15e2m3", "fp16x15e3m2"):
+        # the lead of DESIGN section 10: both correction terms in MX FP6 (block-32 scales on activations AND weights) - the f8f6f4 MFMA runs FP6
+        # at twice the FP8 rate: 1.5 units per product
+        f = scheme[-4:]
+        y = y + F.linear(q6(al, f), q6(w, f)) + F.linear(q6(a, f), q6(wl, f))
     elif scheme == "fp16x25":
         y = y + F.linear(q5(al * 2048.0) * (1.0 / 2048.0), wh8) + F.linear(ah, wl.half().float())
     else:
