@@ -155,7 +155,7 @@ int main() {
     for (int i = 0; i < 16; ++i) for (int k = 0; k < 128; ++k) A[i][k] = rand() % 9 - 4;
     for (int k = 0; k < 128; ++k) for (int j = 0; j < 16; ++j) B[k][j] = rand() % 7 - 3;
     for (int i = 0; i < 16; ++i) for (int g = 0; g < 4; ++g) { sA[i][g] = 127 + (rand() % 5 - 2); sB[i][g] = 127 + (rand() % 5 - 2); }
-    for (int hyp = 0; hyp < 2; ++hyp) {
+    for (int hyp = 0; hyp < 3; ++hyp) {   // 2 (added after tools/mfma_scale_layout_probe.hip): byte placement of hypothesis 1, scales per LOGICAL block of 32 consecutive k
       // hypothesis 0: lane l = (row l & 15, group l >> 4) holds k = 32 g + byte;  hypothesis 1: bytes 0-15 -> k = 16 g + b, bytes 16-31 -> k = 64 + 16 g + (b - 16)
       std::vector<i32x8> ha(64), hb(64);
       std::vector<int> hsa(64), hsb(64);
@@ -163,7 +163,7 @@ int main() {
         uint8_t ba[32], bb[32];
         int r = l & 15, g = l >> 4;
         for (int b = 0; b < 32; ++b) {
-          int k = hyp == 0 ? 32 * g + b : (b < 16 ? 16 * g + b : 64 + 16 * g + (b - 16));
+          int k = hyp == 0 ? 32 * g + b : (b < 16 ? 16 * g + b : 64 + 16 * g + (b - 16));   // (hyp 2 places bytes as hyp 1)
           ba[b] = e4m3_enc_int(A[r][k]);
           bb[b] = e5m2_enc_int(B[k][r]);
         }
@@ -207,7 +207,7 @@ int main() {
             if (op == 1 && fabs(reft - o[l * 4 + e]) > 1e-3 * (1 + fabs(reft))) ++bad_t;
           }
         printf("MFMA e4m3 x e5m2, byte hypothesis %d (%s), op_sel %d: %d / 256 mismatches against 'lane (r, g): row r, k-group g; C row = (l>>4)*4+e, col = l&15; scale byte op_sel, value 2^(s-127), per lane (row, group)'%s\n",
-               hyp, hyp == 0 ? "k = 32 g + byte" : "bytes 0-15: k = 16 g + b, 16-31: k = 64 + 16 g + b - 16", op == 0 ? 0 : op == 1 ? 2 : 1, bad,
+               hyp, hyp == 0 ? "k = 32 g + byte" : hyp == 1 ? "bytes 0-15: k = 16 g + b, 16-31: k = 64 + 16 g + b - 16; scale = the lane's own k set" : "bytes as hypothesis 1; the scale of lane (r, g) belongs to the LOGICAL block k = 32 g .. 32 g + 31", op == 0 ? 0 : op == 1 ? 2 : 1, bad,
                op == 1 ? (bad_t == 0 ? "  [the TRANSPOSED C layout also matches?!]" : "") : "");
       }
       CK(hipFree(da)); CK(hipFree(db)); CK(hipFree(dsa)); CK(hipFree(dsb)); CK(hipFree(dout2));
